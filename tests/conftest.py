@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_q():
+    import numpy as np
+
+    return np.load(os.path.join(GOLDEN, "quantizers.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_fwd():
+    import json
+
+    import numpy as np
+
+    with open(os.path.join(GOLDEN, "forward_configs.json")) as fh:
+        cfgs = json.load(fh)
+    return np.load(os.path.join(GOLDEN, "forward.npz")), cfgs

@@ -1,0 +1,122 @@
+"""The oracle (oracle/lqer_oracle.py) against vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only; never reads /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lqer_oracle as O
+
+
+def _qnames(g):
+    return sorted({k.split("/")[1] for k in g.files if k.startswith("q/")})
+
+
+def test_golden_present(golden_q, golden_fwd):
+    assert len(_qnames(golden_q)) >= 20
+    assert len(golden_fwd[0].files) > 50
+
+
+@pytest.mark.parametrize("via_unfold", [False, True])
+def test_mxint_quantizer_bit_exact(golden_q, via_unfold):
+    for name in _qnames(golden_q):
+        x = torch.from_numpy(golden_q[f"q/{name}/x"])
+        y = torch.from_numpy(golden_q[f"q/{name}/y"])
+        meta = golden_q[f"q/{name}/meta"].tolist()
+        width, skip, block = meta[0], bool(meta[1]), meta[2:]
+        got = O.mxint_quantize(x, width=width, block_size=block, skip_first_dim=skip, via_unfold=via_unfold)
+        assert got.dtype == torch.float32 and got.shape == y.shape
+        assert torch.equal(got.view(torch.int32), y.view(torch.int32)) or torch.equal(got, y), name
+
+
+def test_mxint_libm_route_agrees(golden_q):
+    """The bit-pattern ceil(log2) rule and torch's own log2 give the same quantizer output."""
+    for name in _qnames(golden_q):
+        x = torch.from_numpy(golden_q[f"q/{name}/x"])
+        meta = golden_q[f"q/{name}/meta"].tolist()
+        a = O.mxint_quantize(x, width=meta[0], block_size=meta[2:], skip_first_dim=bool(meta[1]))
+        b = O.mxint_quantize(x, width=meta[0], block_size=meta[2:], skip_first_dim=bool(meta[1]), libm_log2=True)
+        assert torch.equal(a, b), name
+
+
+def test_ceil_log2_rule_table(golden_q):
+    ks = golden_q["log2_rule/k"]
+    slack = golden_q["log2_rule/slack"]
+    got = O._slack_ulps(torch.from_numpy(ks)).numpy()
+    assert np.array_equal(got, slack)
+    # and every neighbour up to 63 ulps
+    for k, s in zip(ks.tolist(), slack.tolist()):
+        bits = np.uint32((k + 127) << 23) + np.arange(0, 64, dtype=np.uint32)
+        v = torch.from_numpy(bits.view(np.float32).copy())
+        e = O.ceil_log2_f32(v).numpy()
+        want = np.where(np.arange(64) <= s, k, k + 1)
+        assert np.array_equal(e, want), k
+
+
+def test_decompose_consistent(golden_q):
+    for name in _qnames(golden_q):
+        meta = golden_q[f"q/{name}/meta"].tolist()
+        width, skip, block = meta[0], bool(meta[1]), meta[2:]
+        x = torch.from_numpy(golden_q[f"q/{name}/x"])
+        if x.ndim != 2 or skip is False and block[0] != 1:
+            continue
+        y, codes, exps = O.mxint_quantize(x, width=width, block_size=block, skip_first_dim=skip, decompose=True)
+        L = O.infer_block_shape([1, x.shape[1]], block)[-1]
+        e = exps.reshape(x.shape[0], -1).repeat_interleave(L, dim=1)[:, : x.shape[1]].float()
+        rebuilt = codes.float() * torch.pow(2.0, e - (width - 1))
+        ref = torch.where(x.abs() <= 1e-8, torch.zeros_like(y), y)
+        assert torch.equal(rebuilt, ref), name
+        assert int(codes.abs().max()) <= 2 ** (width - 1) - 1
+
+
+def test_integer_quantizer(golden_q):
+    for key in [k for k in golden_q.files if k.startswith("int/") and k.endswith("/x")]:
+        tag = key.split("/")[1]
+        w, f = tag[1:].split("f")
+        got = O.integer_quantize(torch.from_numpy(golden_q[key]), int(w), int(f))
+        assert torch.equal(got, torch.from_numpy(golden_q[f"int/{tag}/y"]))
+
+
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "int128", "introw", "ragged"]
+
+
+@pytest.mark.parametrize("name", FWD_CASES)
+def test_forward_matches_reference(golden_fwd, name):
+    g, cfgs = golden_fwd
+    t = lambda k: torch.from_numpy(g[f"{name}/{k}"])
+    bias = t("bias") if f"{name}/bias" in g.files else None
+    out = O.lqer_linear_forward(t("x"), t("W"), bias, t("A"), t("B"), cfgs[name], intermediates=True)
+    assert torch.equal(out["xq"], t("xq"))
+    assert torch.equal(out["wq"], t("wq"))
+    if bias is not None:
+        assert torch.equal(out["bq"], t("bq"))
+    for k in ("xA", "xAq", "xAB", "xABq", "y"):
+        ref = t(k)
+        err = (out[k] - ref).norm() / ref.norm().clamp_min(1e-30)
+        assert err <= 1e-6, (k, float(err))
+    # the quantizers applied to the reference's own intermediates are bit exact
+    qs = O.resolve_linear_quantizers(cfgs[name])
+    assert torch.equal(O.get_quantizer(qs["A_out"])(t("xA")), t("xAq"))
+    assert torch.equal(O.get_quantizer(qs["B_out"])(t("xAB")), t("xABq"))
+
+
+def test_forward_no_side_path(golden_fwd):
+    g, cfgs = golden_fwd
+    t = lambda k: torch.from_numpy(g[f"flex/{k}"])
+    y = O.lqer_linear_forward(t("x"), t("W"), t("bias"), None, None, cfgs["flex"])
+    assert (y - t("y")).norm() / t("y").norm() <= 1e-6
+
+
+def test_pack_unpack_roundtrip(golden_q):
+    for name, block in (("w4_b16", 16), ("w4_b128", 128), ("w4_row", -1), ("w4_ragged", 16)):
+        x = torch.from_numpy(golden_q[f"q/{name}/x"])
+        y = torch.from_numpy(golden_q[f"q/{name}/y"])
+        codes, exps = O.pack_weight_mxint4(x, block, n_pad=8, k_pad=64)
+        assert codes.dtype == torch.uint8 and exps.dtype == torch.int8
+        assert codes.shape[0] % 8 == 0 and (codes.shape[1] * 2) % 64 == 0
+        w = O.unpack_weight_mxint4(codes, exps, x.shape[0], x.shape[1], block)
+        ref = torch.where(x.abs() <= 1e-8, torch.zeros_like(y), y)  # declared flush, block_fp.py:79-80
+        assert torch.equal(w, ref), name
+
+
+def test_flop_model():
+    assert O.flops(2048, 4096, 4096, 32) == 2 * 2048 * 4096 * 4096 + 2 * 2048 * 4096 * 32 + 2 * 2048 * 32 * 4096
