@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Benchmark of the LQER quantized-Linear hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--no-cpu-baseline]
+
+A step = one pass of the hot path (x fp16 in -> activation quantize -> rank-r side GEMM ->
+fused W4A8 GEMM -> y fp16 out) over one batch of synthetic tokens, inputs resident in HBM.
+Default workload = BASELINE.json configs[1]: one LqerLinear 4096 -> 4096, rank 32, W4A8 MXINT
+(block 16), M = 2048 tokens.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank runs its own independent Linear(s) - the path shards into independent units with no data-path
+collective - and the value is the whole-job aggregate: weak scaling.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra
+objects: "roofline" (dominant kernel: algorithmic FLOPs / its HIP-event time, against the dense
+bf16 MFMA peak) and "cpu_baseline" (the CPU oracle timed on this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _bfp(width, block, skip):
+    return dict(name="block_fp", width=width, exponent_width=8, exponent_bias=None, block_size=block, skip_first_dim=skip)
+
+
+# reference experiments/configs/template/llama-7b.toml:78-105 (W4A8 MXINT, blocks of 16)
+MXINT_Q = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=_bfp(8, [1, 16], True),
+               w_quantizer=_bfp(4, [1, 16], False), b_quantizer=_bfp(8, [-1], False))
+# opt-6.7b.toml:98-102: bias in blocks of 16
+OPT_Q = dict(MXINT_Q, b_quantizer=_bfp(8, [1, 16], False))
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+INT8_MFMA_PEAK_TOPS = 5000.0    # 2x bf16 per clock (same guide, "Matrix cores", I8 row)
+
+WORKLOADS = {
+    # name: (description, M, rank, bias, q_config, [(K, N, count per layer)], layers)
+    "c2": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=2048 (BASELINE configs[1])", 2048, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
+    "c3": ("Llama-7B 7 projections x 32 layers rank32 W4A8-MXINT16 M=2048 (BASELINE configs[2])", 2048, 32, False, MXINT_Q,
+           [(4096, 4096, 4), (4096, 11008, 2), (11008, 4096, 1)], 32),
+    "c5": ("OPT-6.7B 6 projections x 32 layers rank128 W4A8-MXINT16 M=2048 (BASELINE configs[4])", 2048, 128, True, OPT_Q,
+           [(4096, 4096, 4), (4096, 16384, 1), (16384, 4096, 1)], 32),
+}
+
+
+def flops(M, K, N, r):
+    """Reference multiply model (experiments/hw_performance/README.md:81-106) x 2."""
+    return 2 * M * K * N + 2 * M * K * r + 2 * M * r * N
+
+
+def make_case(M, K, N, r, seed=0, bias=False):
+    """Synthetic inputs of SURVEY.md §8d: x ~ N(0,1) with three x30 outlier channels, W ~ N(0, 0.02^2),
+    A, B ~ 0.01 N(0,1) snapped to the 8-bit MXINT grid (blocks of 16 along K / rank) like the
+    reference's approximator output (llama-7b.toml:60-73)."""
+    from oracle import lqer_oracle as O  # generator for synthetic A/B only (never on the timed path)
+
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g)
+    for c in (7, 1033, 2900):
+        if c < K:
+            x[:, c] *= 30.0
+    W = 0.02 * torch.randn(N, K, generator=g)
+    if r > 0:
+        A = O.mxint_quantize(0.01 * torch.randn(K, r, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
+        B = O.mxint_quantize(0.01 * torch.randn(r, N, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
+    else:
+        A = B = None
+    if bias:
+        return x, W, A, B, 0.01 * torch.randn(N, generator=g)
+    return x, W, A, B
+
+
+def cpu_baseline(M, K, N, r, q_config, reps=3):
+    """The CPU oracle (a port of the reference's eager-torch emulation, routed through the same
+    pad/unfold/fold blocking ops as the reference) timed on all host cores; steady state, i.e. the
+    one-time weight quantization (reference linear.py:149-153) is done before the clock starts."""
+    from oracle import lqer_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x, W, A, B = make_case(M, K, N, r, seed=0)
+    x = x.half().float()
+    wq = O.mxint_quantize(W, width=4, block_size=[1, 16], skip_first_dim=False)
+    O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)  # warm-up
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(flops(M, K, N, r) / best / 1e12, 4), "unit": "TFLOP/s-equiv", "cores": cores, "kind": "port",
+            "ms": round(best * 1e3, 2), "tokens_per_s": round(M / best, 1),
+            "sample": f"full workload M={M} K={K} N={N} r={r}, fp32 eager torch-CPU, min of {reps} after warm-up, weights pre-quantized"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also verify y against the CPU oracle (rank 0)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ctypes as C
+
+    import lqer_amd
+    from lqer_amd import _lib, ops
+
+    desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS[args.workload]
+    # this rank's units: one module per distinct projection shape (weights differ per rank by seed);
+    # a model sweep re-runs each shape `count * layers_per_rank` times per step
+    layers_here = layers  # weak scaling: every rank runs a full unit list of its own
+    mods = []
+    for i, (K, N, cnt) in enumerate(shapes):
+        case = make_case(M, K, N, r, seed=1000 * rank + i, bias=has_bias)
+        x, W, A, B = case[:4]
+        mod = lqer_amd.LinearFlexibleLqer(K, N, bias=has_bias, q_config=qc, l_config={"rank": r})
+        sd = {"weight": W, "A": A, "B": B}
+        if has_bias:
+            sd["bias"] = case[4]
+        mod.load_state_dict(sd)
+        mod = mod.to(dev).half()
+        xd = x.half().to(dev)
+        y = mod(xd)  # packs the operands (one-time, like the reference's first forward)
+        mods.append((mod, xd, K, N, cnt * layers_here, y))
+    torch.cuda.synchronize()
+
+    if args.check and rank == 0:
+        from oracle import lqer_oracle as O
+
+        mod, xd, K, N, _, y = mods[0]
+        case = make_case(M, K, N, r, seed=0, bias=has_bias)
+        ref = O.lqer_linear_forward(case[0].half().float(), case[1].half().float(), case[4].half().float() if has_bias else None,
+                                    case[2].half().float(), case[3].half().float(), qc)
+        err = float((y.float().cpu() - ref).norm() / ref.norm())
+        print(f"# parity vs CPU oracle: rel-L2 {err:.3e}", file=sys.stderr)
+        assert err <= 1e-3, err
+
+    L = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    gemm_events = []
+
+    def step(timed: bool):
+        for mod, xd, K, N, reps, y in mods:
+            desc = mod._desc()
+            p = mod._packed
+            sz = ops.linear_sizes(desc, M)
+            ws = ops.workspace(dev, sz.workspace)
+            Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
+            xq = ws.data_ptr()
+            xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256
+            for _ in range(reps):
+                # the three launches of lqer_linear_forward, issued separately so that the dominant
+                # kernel can be bracketed with HIP events on the launch stream
+                _lib.check(L.lqer_quantize_act_mxint(xd.data_ptr(), _lib.F16, M, K, K, C.byref(desc.x_fmt), xq, stream), "quantize_act")
+                _lib.check(L.lqer_lowrank_xa(C.byref(desc), xq, M, p["a_t"].data_ptr(), p["a_limbs"], xaq, stream), "lowrank_xa")
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _lib.check(L.lqer_linear_gemm(C.byref(desc), xq, M, p["w"].data_ptr(), xaq, p["b_t"].data_ptr(), p["b_limbs"],
+                                              ops._ptr(p.get("bias")), y.data_ptr(), _lib.F16, N, stream), "linear_gemm")
+                if timed:
+                    e1.record()
+                    gemm_events.append((e0, e1, K, N))
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    flops_rank = sum(flops(M, K, N, r) * reps for _, _, K, N, reps, _ in mods)
+    tokens_rank = M  # a model sweep pushes the same M tokens through every layer
+    total_flops = flops_rank * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_flops * args.steps / elapsed / 1e12
+
+    if rank == 0:
+        # dominant kernel = k_lqer_gemm; algorithmic FLOPs per launch = 2MKN + 2MrN
+        tot_ms, tot_fl, n_launch = 0.0, 0.0, 0
+        for e0, e1, K, N in gemm_events:
+            tot_ms += e0.elapsed_time(e1)
+            tot_fl += 2.0 * M * K * N + 2.0 * M * r * N
+            n_launch += 1
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_lqer_gemm",
+                    "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
+                    "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4)}
+        out = {
+            "metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv",
+            "value": round(value, 2),
+            "unit": "TFLOP/s-equiv",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": desc_txt, "tokens_per_step_per_gpu": M, "rank": r,
+                       "formats": "x MXINT8/16, W MXINT4/16, A_out,B_out MXINT8/16, y fp16",
+                       "sharding": "independent Linear units per rank, no data-path collective"},
+            "tokens_per_s": round(tokens_rank * world * args.steps / elapsed, 1),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            K0, N0, _ = shapes[0]
+            out["cpu_baseline"] = cpu_baseline(M, K0, N0, r, qc)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/*
+ * lqer_hip.h - C ABI of liblqer_hip.so: the MI355X (gfx950) implementation of the LQER quantized
+ * Linear forward      y = Q_x(x) W_q^T + b_q + Q_Bout( Q_Aout( Q_x(x) A ) B )
+ *
+ * The reference (ChengZhang-98/lqer) is pure Python and has no FFI: its boundary for this path is
+ * the nn.Module `LinearFlexibleLqer` (src/lqer/quantize/quantized_layers/linear.py:112-166).  Each
+ * entry point below replaces one step of that module's forward; the reference line it stands in
+ * for is cited on the declaration.  The Python mirror of the module (lqer_amd/linear.py) binds
+ * these with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *  - the caller owns every buffer (incl. workspace); the library never allocates, frees or
+ *    retains pointers, keeps no global mutable state, and is re-entrant;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream) and performs no host synchronisation, so calls may be captured in a hipGraph;
+ *  - return value 0 = success, <0 = error (LQER_E_*); lqer_last_error() gives the text of the
+ *    last error raised on the calling thread.
+ *  - "MXINT(w, L)" = the reference's block_fp format (quantizers/block_fp.py:7-82): blocks of L
+ *    consecutive elements along the last dim share an exponent e = ceil(log2(max|block|)); each
+ *    element is a sign and a (w-1)-bit magnitude m; value = +-m * 2^(e-(w-1)).
+ */
+#ifndef LQER_HIP_H
+#define LQER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LQER_ABI_VERSION 1
+
+/* error codes */
+#define LQER_OK 0
+#define LQER_E_INVALID (-1)     /* bad argument (null pointer, negative size, misalignment) */
+#define LQER_E_UNSUPPORTED (-2) /* format / shape outside what the kernels implement       */
+#define LQER_E_LAUNCH (-3)      /* HIP reported an error at launch                          */
+#define LQER_E_WORKSPACE (-4)   /* workspace too small                                     */
+
+/* element types of caller tensors */
+#define LQER_F32 0
+#define LQER_F16 1
+#define LQER_BF16 2
+
+/* quantizer kinds (reference quantizers/__init__.py:7-18) */
+#define LQER_Q_PASSTHROUGH 0
+#define LQER_Q_MXINT 1 /* "block_fp" */
+
+/* Geometry of the packed operands (fixed by the kernels; exported so callers can size buffers). */
+#define LQER_K_ALIGN 64     /* K is zero-padded to a multiple of this                        */
+#define LQER_M_ALIGN 256    /* activation workspaces are row-padded to a multiple of this    */
+#define LQER_N_ALIGN 128    /* packed weights are row-padded to a multiple of this           */
+#define LQER_R_ALIGN 16     /* rank is zero-padded to a multiple of this                     */
+#define LQER_PANEL_ROWS 16  /* packed W: panels of 16 rows x 64 k                            */
+#define LQER_PANEL_BYTES 576 /* 16*32 B of 4-bit codes + 16*4 B of block exponents           */
+
+/* One MXINT quantizer: `width` bits per element incl. sign; `block` elements share an exponent
+ * (block <= 0: one block per row); exponent clamped to [-exp_bias, 2^exp_width-1-exp_bias]
+ * (block_fp.py:46-51; exp_width=8, exp_bias=127 in every template config). */
+typedef struct lqer_qfmt {
+  int32_t kind;      /* LQER_Q_* */
+  int32_t width;
+  int32_t block;
+  int32_t exp_width;
+  int32_t exp_bias;
+} lqer_qfmt_t;
+
+/* Static description of one Linear.  M (tokens) is a per-call argument. */
+typedef struct lqer_linear_desc {
+  int32_t in_features;   /* K */
+  int32_t out_features;  /* N */
+  int32_t rank;          /* r; 0 = no side path (LinearFlexible, linear.py:88-109) */
+  int32_t has_bias;
+  lqer_qfmt_t x_fmt;     /* linear.py:148   x_quantizer                        */
+  lqer_qfmt_t w_fmt;     /* linear.py:150   w_quantizer (width must be <= 4)   */
+  lqer_qfmt_t b_fmt;     /* linear.py:152   b_quantizer                        */
+  lqer_qfmt_t a_out_fmt; /* linear.py:154   A_out_quantizer                    */
+  lqer_qfmt_t b_out_fmt; /* linear.py:155   B_out_quantizer                    */
+} lqer_linear_desc_t;
+
+/* Sizes (bytes) of the derived, caller-allocated device buffers of one Linear. */
+typedef struct lqer_linear_sizes {
+  size_t w_packed;   /* 4-bit codes + block exponents, panel layout            */
+  size_t a_t;        /* A^T as bf16 limbs [3][rp][Kp]                          */
+  size_t b_t;        /* B^T as bf16 limbs [3][Np][rp]                          */
+  size_t bias_q;     /* quantized bias, fp32 [Np]                              */
+  size_t workspace;  /* per-call scratch for `m_max` tokens                    */
+} lqer_linear_sizes_t;
+
+int lqer_version(void);
+const char* lqer_last_error(void);
+
+/* Padded extents used by the packed buffers. */
+int64_t lqer_padded_k(int64_t K);
+int64_t lqer_padded_n(int64_t N);
+int64_t lqer_padded_m(int64_t M);
+int64_t lqer_padded_r(int64_t r);
+
+/* ---- quantizers -------------------------------------------------------------------------- */
+
+/* MXINT quantizer over the rows of a [rows, cols] matrix (row stride `ld` elements), blocks along
+ * the last dim.  Replaces x_quantizer / A_out_quantizer / B_out_quantizer / b_quantizer calls of
+ * linear.py:148,152,154,155 -> block_fp.py:111.  Any of the outputs may be NULL:
+ *   deq_f32 [rows, cols]   dequantized values (|x| <= 1e-8 kept as is, block_fp.py:79-80)
+ *   codes   [rows, cols]   signed mantissas, int8 (needs width <= 8); |x| <= 1e-8 -> 0
+ *   exps    [rows, ceil(cols/L)]  shared exponents, int8 (0 for an all-zero block)          */
+int lqer_quantize_mxint(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld,
+                        const lqer_qfmt_t* fmt, float* deq_f32, int8_t* codes, int8_t* exps,
+                        void* stream);
+
+/* Activation quantizer of the fast path (linear.py:148): x [M,K] -> exact bf16 image
+ * xq [lqer_padded_m(M), lqer_padded_k(K)] (K padding zeroed; |x| <= 1e-8 flushed to 0).
+ * Needs fmt->width <= 9 so that every value m*2^(e-w+1) is exactly representable in bf16.   */
+int lqer_quantize_act_mxint(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx,
+                            const lqer_qfmt_t* fmt, void* xq_bf16, void* stream);
+
+/* ---- one-time packing (replaces the in-place first-forward quantization, linear.py:149-153) */
+
+int lqer_linear_sizes(const lqer_linear_desc_t* desc, int64_t m_max, lqer_linear_sizes_t* out);
+
+/* W [N,K] (row stride ldw) -> packed panels: w_quantizer(W) as 4-bit two's-complement mantissas
+ * + int8 block exponents.  Panel (n/16, k/64) = 16 rows x 32 B codes (element 2j in the low
+ * nibble of byte j) followed by 16 x 4 exponents (one per 16 k; a coarser block repeats its
+ * exponent).  |w| <= 1e-8 is flushed to code 0.  `scratch` needs N*ceil(K/16) bytes.          */
+int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64_t ldw,
+                           const lqer_qfmt_t* fmt, void* w_packed, void* scratch, void* stream);
+
+/* Test hook: packed panels -> dequantized fp32 [N,K]. */
+int lqer_unpack_weight_mxint(const void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* fmt,
+                             float* w_f32, void* stream);
+
+/* A [K,r] and B [r,N] (linear.py:142-143; values as stored in the state dict) -> transposed bf16
+ * limb images a_t [3][rp][Kp], b_t [3][Np][rp]; v = limb0 + limb1 + limb2 exactly (an 8-bit
+ * MXINT value needs one limb, fp16 two, fp32 three).  limb_flags[0..1] (device int32[2]) receive
+ * the number of non-zero limbs of A and of B.                                                */
+int lqer_pack_lowrank(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r,
+                      void* a_t, void* b_t, int32_t* limb_flags, void* stream);
+
+/* bias [N] -> b_quantizer(bias) as fp32 [Np] (linear.py:151-152). fmt->kind may be passthrough. */
+int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fmt, float* bias_q,
+                   void* stream);
+
+/* ---- the forward (linear.py:145-157, PTQ branch) ------------------------------------------- */
+
+/* y[M,N] (row stride ldy, same dtype as x) from x[M,K] (row stride ldx).  a_limbs / b_limbs =
+ * the limb counts reported by lqer_pack_lowrank.  workspace >= lqer_linear_sizes(...).workspace
+ * for m_max >= M.  Three stream-ordered launches: activation quantize, rank-r side GEMM with
+ * A_out re-quantization, fused W4 x A8 GEMM with the B side GEMM, B_out re-quantization, bias and
+ * add in its prologue.                                                                       */
+int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype, int64_t M,
+                        int64_t ldx, const void* w_packed, const void* a_t, const void* b_t,
+                        int a_limbs, int b_limbs, const float* bias_q, void* y, int64_t ldy,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same, split for callers that share one quantized activation between several Linears
+ * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */
+int lqer_lowrank_xa(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
+                    const void* a_t, int a_limbs, void* xaq_bf16, void* stream);
+int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
+                     const void* w_packed, const void* xaq_bf16, const void* b_t, int b_limbs,
+                     const float* bias_q, void* y, int dtype, int64_t ldy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LQER_HIP_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of liblqer_hip.so (include/lqer_hip.h).  No CPU fallback: if the shared library
+is missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
+BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
+
+ABI_VERSION = 1
+F32, F16, BF16 = 0, 1, 2
+Q_PASSTHROUGH, Q_MXINT = 0, 1
+K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 128, 16
+
+
+class QFmt(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("block", C.c_int32), ("exp_width", C.c_int32), ("exp_bias", C.c_int32)]
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [
+        ("in_features", C.c_int32),
+        ("out_features", C.c_int32),
+        ("rank", C.c_int32),
+        ("has_bias", C.c_int32),
+        ("x_fmt", QFmt),
+        ("w_fmt", QFmt),
+        ("b_fmt", QFmt),
+        ("a_out_fmt", QFmt),
+        ("b_out_fmt", QFmt),
+    ]
+
+
+class LinearSizes(C.Structure):
+    _fields_ = [("w_packed", C.c_size_t), ("a_t", C.c_size_t), ("b_t", C.c_size_t), ("bias_q", C.c_size_t), ("workspace", C.c_size_t)]
+
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_qp, _dp = C.POINTER(QFmt), C.POINTER(LinearDesc)
+
+# name -> (restype, argtypes); must list every symbol declared in include/lqer_hip.h
+SIGNATURES = {
+    "lqer_version": (_i, []),
+    "lqer_last_error": (C.c_char_p, []),
+    "lqer_padded_k": (_i64, [_i64]),
+    "lqer_padded_n": (_i64, [_i64]),
+    "lqer_padded_m": (_i64, [_i64]),
+    "lqer_padded_r": (_i64, [_i64]),
+    "lqer_quantize_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp, _vp, _vp]),
+    "lqer_quantize_act_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp]),
+    "lqer_linear_sizes": (_i, [_dp, _i64, C.POINTER(LinearSizes)]),
+    "lqer_pack_weight_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp, _vp]),
+    "lqer_unpack_weight_mxint": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),
+    "lqer_pack_lowrank": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "lqer_pack_bias": (_i, [_vp, _i, _i64, _qp, _vp, _vp]),
+    "lqer_linear_forward": (_i, [_dp, _vp, _i, _i64, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "lqer_lowrank_xa": (_i, [_dp, _vp, _i64, _vp, _i, _vp, _vp]),
+    "lqer_linear_gemm": (_i, [_dp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class LqerHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["bash", BUILD_SCRIPT], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise LqerHipError("hipcc build of liblqer_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout.strip())
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it has not been built (there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LqerHipError(
+                f"{LIB_PATH} not found: build it with `bash {BUILD_SCRIPT}` (or __graft_entry__.build()). "
+                "lqer_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.lqer_version() != ABI_VERSION:
+            raise LqerHipError(f"ABI mismatch: library {L.lqer_version()} vs binding {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise LqerHipError(f"{what} failed (code {rc}): {lib().lqer_last_error().decode()}")

@@ -1,0 +1,254 @@
+// C ABI of liblqer_hip.so (include/lqer_hip.h): argument checking, buffer carving, kernel dispatch.
+// No allocation, no synchronisation, no global mutable state besides the thread-local error text.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace lqer {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return LQER_E_LAUNCH;
+  }
+  return LQER_OK;
+}
+
+static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
+  if (!f) {
+    set_error("%s: null format", name);
+    return false;
+  }
+  if (f->kind == LQER_Q_PASSTHROUGH) return true;
+  if (f->kind != LQER_Q_MXINT) {
+    set_error("%s: quantizer kind %d is not implemented on the HIP path", name, f->kind);
+    return false;
+  }
+  if (f->width < 2 || f->width > max_width) {
+    set_error("%s: width %d outside [2,%d]", name, f->width, max_width);
+    return false;
+  }
+  if (f->exp_width < 1 || f->exp_width > 8) {
+    set_error("%s: exponent_width %d outside [1,8]", name, f->exp_width);
+    return false;
+  }
+  return true;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace lqer
+
+using namespace lqer;
+
+extern "C" {
+
+int lqer_version(void) { return LQER_ABI_VERSION; }
+const char* lqer_last_error(void) { return g_err; }
+
+int64_t lqer_padded_k(int64_t K) { return (K + LQER_K_ALIGN - 1) / LQER_K_ALIGN * LQER_K_ALIGN; }
+int64_t lqer_padded_n(int64_t N) { return (N + LQER_N_ALIGN - 1) / LQER_N_ALIGN * LQER_N_ALIGN; }
+int64_t lqer_padded_m(int64_t M) { return (M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN; }
+int64_t lqer_padded_r(int64_t r) { return (r + LQER_R_ALIGN - 1) / LQER_R_ALIGN * LQER_R_ALIGN; }
+
+int lqer_quantize_mxint(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const lqer_qfmt_t* fmt,
+                        float* deq_f32, int8_t* codes, int8_t* exps, void* stream) {
+  if (!x && rows * cols > 0) {
+    set_error("quantize_mxint: null input");
+    return LQER_E_INVALID;
+  }
+  if (rows < 0 || cols < 0 || ld < cols) {
+    set_error("quantize_mxint: bad shape rows=%lld cols=%lld ld=%lld", (long long)rows, (long long)cols, (long long)ld);
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(fmt, "quantize_mxint", 24)) return LQER_E_UNSUPPORTED;
+  if (fmt->kind != LQER_Q_MXINT) {
+    set_error("quantize_mxint: format is not MXINT");
+    return LQER_E_INVALID;
+  }
+  if (codes && fmt->width > 8) {
+    set_error("quantize_mxint: int8 codes need width <= 8");
+    return LQER_E_UNSUPPORTED;
+  }
+  QP q = make_qp(*fmt);
+  QuantOut o{deq_f32, codes, exps, nullptr, 0, 0};
+  const int64_t L = (q.block <= 0 || q.block >= cols) ? cols : q.block;
+  o.nblk = L > 0 ? (cols + L - 1) / L : 0;
+  return quantize_dispatch(x, dtype, rows, cols, ld, q, o, (hipStream_t)stream);
+}
+
+int lqer_quantize_act_mxint(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const lqer_qfmt_t* fmt,
+                            void* xq_bf16, void* stream) {
+  if ((!x || !xq_bf16) && M * K > 0) {
+    set_error("quantize_act: null pointer");
+    return LQER_E_INVALID;
+  }
+  if (M < 0 || K < 0 || ldx < K) {
+    set_error("quantize_act: bad shape M=%lld K=%lld ldx=%lld", (long long)M, (long long)K, (long long)ldx);
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(fmt, "x_quantizer", 9)) return LQER_E_UNSUPPORTED;
+  if (fmt->kind != LQER_Q_MXINT) {
+    set_error("x_quantizer: only block_fp activations are implemented on the HIP path");
+    return LQER_E_UNSUPPORTED;
+  }
+  QP q = make_qp(*fmt);
+  QuantOut o{nullptr, nullptr, nullptr, (bf16_t*)xq_bf16, lqer_padded_k(K), 0};
+  return quantize_dispatch(x, dtype, M, K, ldx, q, o, (hipStream_t)stream);
+}
+
+int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_sizes_t* out) {
+  if (!d || !out || d->in_features <= 0 || d->out_features <= 0 || d->rank < 0 || m_max < 0) {
+    set_error("linear_sizes: bad descriptor");
+    return LQER_E_INVALID;
+  }
+  const size_t Kp = lqer_padded_k(d->in_features), Np = lqer_padded_n(d->out_features);
+  const size_t rp = lqer_padded_r(d->rank), Mp = lqer_padded_m(m_max);
+  out->w_packed = (Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES;
+  out->a_t = 3 * rp * Kp * 2;
+  out->b_t = 3 * Np * rp * 2;
+  out->bias_q = Np * 4;
+  out->workspace = align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256);
+  return LQER_OK;
+}
+
+int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64_t ldw, const lqer_qfmt_t* fmt,
+                           void* w_packed, void* scratch, void* stream) {
+  if (!W || !w_packed || !scratch || N <= 0 || K <= 0 || ldw < K) {
+    set_error("pack_weight: bad argument");
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
+  if (fmt->kind != LQER_Q_MXINT) {
+    set_error("w_quantizer: only block_fp weights can be packed");
+    return LQER_E_UNSUPPORTED;
+  }
+  return pack_weight_dispatch(W, dtype, N, K, ldw, make_qp(*fmt), w_packed, scratch, (hipStream_t)stream);
+}
+
+int lqer_unpack_weight_mxint(const void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* fmt, float* w_f32,
+                             void* stream) {
+  if (!w_packed || !w_f32 || !fmt || N <= 0 || K <= 0) {
+    set_error("unpack_weight: bad argument");
+    return LQER_E_INVALID;
+  }
+  return unpack_weight_dispatch(w_packed, N, K, fmt->width - 1, w_f32, (hipStream_t)stream);
+}
+
+int lqer_pack_lowrank(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r, void* a_t, void* b_t,
+                      int32_t* limb_flags, void* stream) {
+  if (!A || !B || !a_t || !b_t || !limb_flags || K <= 0 || N <= 0 || r <= 0) {
+    set_error("pack_lowrank: bad argument");
+    return LQER_E_INVALID;
+  }
+  return pack_lowrank_dispatch(A, B, dtype, K, N, r, a_t, b_t, limb_flags, (hipStream_t)stream);
+}
+
+int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fmt, float* bias_q, void* stream) {
+  if (!bias || !bias_q || N <= 0) {
+    set_error("pack_bias: bad argument");
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(fmt, "b_quantizer", 24)) return LQER_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (fmt->kind == LQER_Q_PASSTHROUGH) return bias_passthrough_dispatch(bias, dtype, N, bias_q, st);
+  (void)hipMemsetAsync(bias_q, 0, lqer_padded_n(N) * sizeof(float), st);
+  QP q = make_qp(*fmt);
+  QuantOut o{bias_q, nullptr, nullptr, nullptr, 0, 0};
+  return quantize_dispatch(bias, dtype, 1, N, N, q, o, st);
+}
+
+int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* a_t, int a_limbs, void* xaq,
+                    void* stream) {
+  if (!d || !xq || !a_t || !xaq || M < 0 || d->rank <= 0) {
+    set_error("lowrank_xa: bad argument");
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(&d->a_out_fmt, "A_out_quantizer", 9)) return LQER_E_UNSUPPORTED;
+  if (a_limbs < 0 || a_limbs > 3) {
+    set_error("lowrank_xa: a_limbs %d outside [0,3]", a_limbs);
+    return LQER_E_INVALID;
+  }
+  return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, (const bf16_t*)a_t, a_limbs, d->rank,
+                             make_qp(d->a_out_fmt), (bf16_t*)xaq, (hipStream_t)stream);
+}
+
+int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
+                     const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy, void* stream) {
+  if (!d || !xq || !w_packed || !y || M < 0 || ldy < d->out_features) {
+    set_error("linear_gemm: bad argument");
+    return LQER_E_INVALID;
+  }
+  const bool lowrank = d->rank > 0;
+  if (lowrank && (!xaq || !b_t)) {
+    set_error("linear_gemm: rank %d but no side-path operands", d->rank);
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(&d->w_fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
+  if (lowrank && !fmt_ok(&d->b_out_fmt, "B_out_quantizer", 24)) return LQER_E_UNSUPPORTED;
+  if (b_limbs < 0 || b_limbs > 3) {
+    set_error("linear_gemm: b_limbs %d outside [0,3]", b_limbs);
+    return LQER_E_INVALID;
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.xq = (const bf16_t*)xq;
+  g.wp = (const uint8_t*)w_packed;
+  g.xaq = (const bf16_t*)xaq;
+  g.bt = (const bf16_t*)b_t;
+  g.bias = d->has_bias ? bias_q : nullptr;
+  g.y = y;
+  g.ldy = ldy;
+  g.M = (int)M;
+  g.N = d->out_features;
+  g.Np = (int)lqer_padded_n(d->out_features);
+  g.Kp = (int)lqer_padded_k(d->in_features);
+  g.rp = (int)lqer_padded_r(d->rank);
+  g.b_limbs = b_limbs;
+  g.w_mbits = d->w_fmt.width - 1;
+  if (lowrank) g.bout = make_qp(d->b_out_fmt);
+  return gemm_dispatch(g, dtype, lowrank, (hipStream_t)stream);
+}
+
+int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx,
+                        const void* w_packed, const void* a_t, const void* b_t, int a_limbs, int b_limbs,
+                        const float* bias_q, void* y, int64_t ldy, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (!d) {
+    set_error("linear_forward: null descriptor");
+    return LQER_E_INVALID;
+  }
+  lqer_linear_sizes_t sz;
+  int rc = lqer_linear_sizes(d, M, &sz);
+  if (rc) return rc;
+  if (workspace_bytes < sz.workspace || (!workspace && sz.workspace)) {
+    set_error("linear_forward: workspace %zu B < %zu B needed for M=%lld", workspace_bytes, sz.workspace, (long long)M);
+    return LQER_E_WORKSPACE;
+  }
+  if (M == 0) return LQER_OK;
+  const size_t Kp = lqer_padded_k(d->in_features), Mp = lqer_padded_m(M);
+  unsigned char* ws = (unsigned char*)workspace;
+  void* xq = ws;
+  void* xaq = ws + align_up(Mp * Kp * 2, 256);
+  rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
+  if (rc) return rc;
+  if (d->rank > 0) {
+    rc = lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, stream);
+    if (rc) return rc;
+  }
+  return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+// Shared device helpers for the LQER HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lqer_hip.h"
+
+namespace lqer {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 accumulator
+
+// Resolved MXINT parameters handed to kernels by value.
+struct QP {
+  int kind;   // LQER_Q_*
+  int mbits;  // width - 1
+  int block;  // elements per shared exponent; <=0 = whole row
+  int emin, emax;
+  float mmax;  // 2^mbits - 1
+};
+
+__host__ inline QP make_qp(const lqer_qfmt_t& f) {
+  QP q;
+  q.kind = f.kind;
+  q.mbits = f.width - 1;
+  q.block = f.block;
+  q.emin = -f.exp_bias;
+  q.emax = (1 << f.exp_width) - 1 - f.exp_bias;
+  q.mmax = (float)((1 << (f.width - 1)) - 1);
+  return q;
+}
+
+// ---- element loads of the three caller dtypes -------------------------------------------------
+template <int DT>
+__device__ __forceinline__ float load_elem(const void* p, int64_t i);
+template <>
+__device__ __forceinline__ float load_elem<LQER_F32>(const void* p, int64_t i) {
+  return ((const float*)p)[i];
+}
+template <>
+__device__ __forceinline__ float load_elem<LQER_F16>(const void* p, int64_t i) {
+  return (float)((const _Float16*)p)[i];
+}
+template <>
+__device__ __forceinline__ float load_elem<LQER_BF16>(const void* p, int64_t i) {
+  return __uint_as_float(((uint32_t)((const bf16_t*)p)[i]) << 16);
+}
+
+template <int DT>
+__device__ __forceinline__ void store_elem(void* p, int64_t i, float v);
+template <>
+__device__ __forceinline__ void store_elem<LQER_F32>(void* p, int64_t i, float v) {
+  ((float*)p)[i] = v;
+}
+template <>
+__device__ __forceinline__ void store_elem<LQER_F16>(void* p, int64_t i, float v) {
+  ((_Float16*)p)[i] = (_Float16)v;  // v_cvt_f16_f32: round to nearest even
+}
+__device__ __forceinline__ bf16_t f32_to_bf16_rne(float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <>
+__device__ __forceinline__ void store_elem<LQER_BF16>(void* p, int64_t i, float v) {
+  ((bf16_t*)p)[i] = f32_to_bf16_rne(v);
+}
+
+// ---- the reference's exponent rule --------------------------------------------------------------
+// e = torch.ceil(torch.log2(amax)) evaluated in fp32 (reference block_fp.py:58).  torch's log2 is
+// correctly rounded, so for amax = 2^k (1 + j 2^-23) the sum k + log2(1 + j 2^-23) rounds back to k
+// while j <= J(k), J = floor(2^(p-1) ln 2) with p the binade of the reals just above k
+// (oracle/lqer_oracle.py::ceil_log2_f32; table pinned by tests/golden "log2_rule").
+__device__ __forceinline__ int ceil_log2_rule(float amax) {
+  const uint32_t bits = __float_as_uint(amax);
+  const int k = (int)((bits >> 23) & 0xff) - 127;
+  const int mant = (int)(bits & 0x7fffffu);
+  const int ak = k < 0 ? -k : k;
+  int slack = 0;
+  if (ak >= 4) {
+    int p = 31 - __clz(ak);
+    if (k < 0 && (ak & (ak - 1)) == 0) p -= 1;
+    slack = p <= 1 ? 0 : p == 2 ? 1 : p == 3 ? 2 : p == 4 ? 5 : p == 5 ? 11 : 22;
+  }
+  return mant > slack ? k + 1 : k;
+}
+
+__device__ __forceinline__ int block_exponent(float amax, const QP& q) {
+  int e = ceil_log2_rule(amax);
+  return e < q.emin ? q.emin : (e > q.emax ? q.emax : e);
+}
+
+// Signed mantissa of one element given its block exponent (block_fp.py:55-65):
+//   m = min(rne((|x| + 1e-9) / 2^e * 2^mbits), 2^mbits - 1), sign from x.
+// |x| <= 1e-8 is the reference's pass-through (block_fp.py:79-80); packed images flush it to 0.
+__device__ __forceinline__ float mxint_mantissa(float x, int e, const QP& q) {
+  const float v = fabsf(x) + 1e-9f;
+  const float t = ldexpf(v, q.mbits - e);
+  const float m = fminf(rintf(t), q.mmax);
+  return fabsf(x) <= 1e-8f ? 0.0f : copysignf(m, x);
+}
+
+// bf16 bits of an exactly representable fp32 value (low 16 bits are zero by construction).
+__device__ __forceinline__ uint32_t exact_bf16_bits(float v) { return __float_as_uint(v) >> 16; }
+
+// max over the 16 lanes of a DPP row (lanes 16g..16g+15); every lane of the row gets the result.
+__device__ __forceinline__ float row16_max(float v) {
+  int t;
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+  v = fmaxf(v, __int_as_float(t));
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true);  // quad_perm [2,3,0,1]
+  v = fmaxf(v, __int_as_float(t));
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true);  // row_half_mirror
+  v = fmaxf(v, __int_as_float(t));
+  t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true);  // row_mirror
+  v = fmaxf(v, __int_as_float(t));
+  return v;
+}
+
+
+// ---- cross-file declarations ----------------------------------------------------------------------
+struct QuantOut {
+  float* deq;      // [rows, cols] or null
+  int8_t* codes;   // [rows, cols] or null
+  int8_t* exps;    // [rows, nblk] or null
+  bf16_t* xq;      // [rows_p, cols_p] exact bf16 image or null
+  int64_t cols_p;  // row stride of xq (zero-filled beyond cols)
+  int64_t nblk;    // blocks per row (exps row stride)
+};
+
+struct GemmArgs {
+  const bf16_t* xq;    // [Mp][Kp]
+  const uint8_t* wp;   // packed panels
+  const bf16_t* xaq;   // [Mp][rp] or null
+  const bf16_t* bt;    // [limbs][Np][rp]
+  const float* bias;   // [Np] or null
+  void* y;
+  int64_t ldy;
+  int M, N, Np, Kp, rp, b_limbs;
+  int w_mbits;
+  QP bout;
+  int tiles_m, tiles_n;
+};
+
+int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
+                      const QuantOut& o, hipStream_t st);
+int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, void* out,
+                         void* scratch, hipStream_t st);
+int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, float* out, hipStream_t st);
+int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r, void* a_t,
+                          void* b_t, int32_t* flags, hipStream_t st);
+int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, hipStream_t st);
+int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,
+                        const QP& q, bf16_t* xaq, hipStream_t st);
+int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, hipStream_t st);
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+}  // namespace lqer

@@ -1,0 +1,195 @@
+// One-time operand packing: replaces the reference's lazy in-place weight/bias quantization on the
+// first forward (quantized_layers/linear.py:149-153 -> quantizers/block_fp.py:111, blocking by
+// quantizers/utils.py:161-208) with a packed 4-bit image the GEMM kernel streams.
+//
+// Packed W layout (DESIGN.md "Data layout"): panels of 16 rows x 64 k, panel (pn, pk) at byte
+// ((pn * Kp/64) + pk) * 576:   [16 rows][32 B]  4-bit two's-complement mantissas, k even = low nibble
+//                              [16 rows][4]     int8 exponent of each 16-k segment
+// A coarser weight block (32, 128, whole row) repeats its exponent per segment, so the GEMM kernel
+// handles every block length with one code path.
+#include "common.h"
+
+namespace lqer {
+
+// pass 1: exponent of every (row, block) -> scratch[N][nblk]
+template <int DT>
+__global__ __launch_bounds__(256) void k_w_exps(const void* __restrict__ W, int64_t N, int64_t K, int64_t ld, QP q,
+                                                int64_t L, int64_t nblk, int8_t* __restrict__ scratch) {
+  const int64_t total = N * nblk;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / nblk, b = idx - row * nblk;
+    const int64_t k1 = (b + 1) * L < K ? (b + 1) * L : K;
+    float amax = 0.0f;
+    for (int64_t k = b * L; k < k1; ++k) amax = fmaxf(amax, fabsf(load_elem<DT>(W, row * ld + k)));
+    int e = amax > 0.0f ? block_exponent(amax, q) : -128;  // -128 marks an all-zero block
+    scratch[idx] = (int8_t)(e > 127 ? 127 : e);
+  }
+}
+
+// pass 2: one lane per (padded row, 16-k segment)
+template <int DT>
+__global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int64_t N, int64_t K, int64_t ld, QP q,
+                                                int64_t L, int64_t nblk, const int8_t* __restrict__ scratch,
+                                                int64_t Np, int64_t Kp, uint8_t* __restrict__ out) {
+  const int64_t segs = Kp / 16;
+  const int64_t total = Np * segs;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / segs, seg = idx - row * segs, k0 = seg * 16;
+    uint32_t lo = 0, hi = 0;
+    int e = 0;
+    if (row < N && k0 < K) {
+      const int es = scratch[row * nblk + k0 / L];
+      if (es != -128) {
+        e = es;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float w = (k0 + i < K) ? load_elem<DT>(W, row * ld + k0 + i) : 0.0f;
+          const uint32_t c = ((uint32_t)(int)mxint_mantissa(w, e, q)) & 0xfu;
+          if (i < 8)
+            lo |= c << (4 * i);
+          else
+            hi |= c << (4 * (i - 8));
+        }
+      }
+    }
+    uint8_t* panel = out + ((row / 16) * (Kp / 64) + seg / 4) * LQER_PANEL_BYTES;
+    *(uint2*)(panel + (row % 16) * 32 + (seg % 4) * 8) = make_uint2(lo, hi);
+    panel[512 + (row % 16) * 4 + (seg % 4)] = (uint8_t)(int8_t)e;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_w_unpack(const uint8_t* __restrict__ in, int64_t N, int64_t K, int64_t Kp,
+                                                  int mbits, float* __restrict__ out) {
+  const int64_t segs = Kp / 16;
+  const int64_t total = N * segs;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / segs, seg = idx - row * segs, k0 = seg * 16;
+    const uint8_t* panel = in + ((row / 16) * (Kp / 64) + seg / 4) * LQER_PANEL_BYTES;
+    const uint2 c = *(const uint2*)(panel + (row % 16) * 32 + (seg % 4) * 8);
+    const int e = (int8_t)panel[512 + (row % 16) * 4 + (seg % 4)];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t word = i < 8 ? c.x : c.y;
+      const int v = ((int)(word << (28 - 4 * (i & 7)))) >> 28;  // sign-extended nibble
+      if (k0 + i < K) out[row * K + k0 + i] = ldexpf((float)v, e - mbits);
+    }
+  }
+}
+
+// A [K,r] -> a_t [3][rp][Kp] ; B [r,N] -> b_t [3][Np][rp]  (bf16 limbs, transposed, zero padded).
+template <int DT>
+__global__ __launch_bounds__(256) void k_pack_lowrank(const void* __restrict__ src, int64_t rows, int64_t cols,
+                                                      int64_t rows_p, int64_t cols_p, bf16_t* __restrict__ dst,
+                                                      int32_t* __restrict__ nlimbs) {
+  // dst[l][c][r] = limb l of src[r][c]   (dst is [3][cols_p][rows_p])
+  const int64_t total = rows_p * cols_p;
+  int used = 0;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t c = idx / rows_p, r = idx - c * rows_p;
+    float v = (r < rows && c < cols) ? load_elem<DT>(src, r * cols + c) : 0.0f;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      const bf16_t b = f32_to_bf16_rne(v);
+      dst[(l * cols_p + c) * rows_p + r] = b;
+      if (b & 0x7fff) used = l + 1;
+      v -= __uint_as_float((uint32_t)b << 16);  // exact: the residual has fewer significant bits
+    }
+  }
+  if (used) atomicMax(nlimbs, used);
+}
+
+template <int DT>
+__global__ void k_bias_passthrough(const void* __restrict__ b, int64_t N, int64_t Np, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < Np) out[i] = i < N ? load_elem<DT>(b, i) : 0.0f;
+}
+
+template <int DT>
+static int pack_w(const void* W, int64_t N, int64_t K, int64_t ld, const QP& q, uint8_t* out, int8_t* scratch,
+                  hipStream_t st) {
+  const int64_t Np = lqer_padded_n(N), Kp = lqer_padded_k(K);
+  const int64_t L = (q.block <= 0 || q.block >= K) ? Kp : q.block;
+  const int64_t nblk = (K + L - 1) / L;
+  {
+    const int64_t total = N * nblk;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    k_w_exps<DT><<<grid, 256, 0, st>>>(W, N, K, ld, q, L, nblk, scratch);
+  }
+  {
+    const int64_t total = Np * (Kp / 16);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    k_w_pack<DT><<<grid, 256, 0, st>>>(W, N, K, ld, q, L, nblk, scratch, Np, Kp, out);
+  }
+  return check_launch("pack_weight");
+}
+
+int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, void* out,
+                         void* scratch, hipStream_t st) {
+  if (q.mbits < 1 || q.mbits > 3) {
+    set_error("packed weights hold 4-bit codes: w_quantizer width must be 2..4, got %d", q.mbits + 1);
+    return LQER_E_UNSUPPORTED;
+  }
+  if (!(q.block <= 0 || q.block >= K || q.block % 16 == 0)) {
+    set_error("w_quantizer block %d: must be a multiple of 16 or cover the row", q.block);
+    return LQER_E_UNSUPPORTED;
+  }
+  switch (dtype) {
+    case LQER_F32: return pack_w<LQER_F32>(W, N, K, ld, q, (uint8_t*)out, (int8_t*)scratch, st);
+    case LQER_F16: return pack_w<LQER_F16>(W, N, K, ld, q, (uint8_t*)out, (int8_t*)scratch, st);
+    case LQER_BF16: return pack_w<LQER_BF16>(W, N, K, ld, q, (uint8_t*)out, (int8_t*)scratch, st);
+  }
+  set_error("unknown dtype %d", dtype);
+  return LQER_E_INVALID;
+}
+
+int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, float* out, hipStream_t st) {
+  const int64_t Kp = lqer_padded_k(K);
+  const int64_t total = N * (Kp / 16);
+  if (total == 0) return LQER_OK;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  k_w_unpack<<<grid, 256, 0, st>>>((const uint8_t*)in, N, K, Kp, mbits, out);
+  return check_launch("unpack_weight");
+}
+
+template <int DT>
+static int pack_lr(const void* A, const void* B, int64_t K, int64_t N, int64_t r, bf16_t* a_t, bf16_t* b_t,
+                   int32_t* flags, hipStream_t st) {
+  const int64_t Kp = lqer_padded_k(K), Np = lqer_padded_n(N), rp = lqer_padded_r(r);
+  (void)hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st);
+  {  // A [K, r] -> a_t [3][rp][Kp]
+    const int64_t total = Kp * rp;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    k_pack_lowrank<DT><<<grid, 256, 0, st>>>(A, K, r, Kp, rp, a_t, flags);
+  }
+  {  // B [r, N] -> b_t [3][Np][rp]
+    const int64_t total = rp * Np;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    k_pack_lowrank<DT><<<grid, 256, 0, st>>>(B, r, N, rp, Np, b_t, flags + 1);
+  }
+  return check_launch("pack_lowrank");
+}
+
+int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r, void* a_t,
+                          void* b_t, int32_t* flags, hipStream_t st) {
+  switch (dtype) {
+    case LQER_F32: return pack_lr<LQER_F32>(A, B, K, N, r, (bf16_t*)a_t, (bf16_t*)b_t, flags, st);
+    case LQER_F16: return pack_lr<LQER_F16>(A, B, K, N, r, (bf16_t*)a_t, (bf16_t*)b_t, flags, st);
+    case LQER_BF16: return pack_lr<LQER_BF16>(A, B, K, N, r, (bf16_t*)a_t, (bf16_t*)b_t, flags, st);
+  }
+  set_error("unknown dtype %d", dtype);
+  return LQER_E_INVALID;
+}
+
+int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, hipStream_t st) {
+  const int64_t Np = lqer_padded_n(N);
+  const unsigned grid = (unsigned)((Np + 255) / 256);
+  switch (dtype) {
+    case LQER_F32: k_bias_passthrough<LQER_F32><<<grid, 256, 0, st>>>(b, N, Np, out); break;
+    case LQER_F16: k_bias_passthrough<LQER_F16><<<grid, 256, 0, st>>>(b, N, Np, out); break;
+    case LQER_BF16: k_bias_passthrough<LQER_BF16><<<grid, 256, 0, st>>>(b, N, Np, out); break;
+    default: set_error("unknown dtype %d", dtype); return LQER_E_INVALID;
+  }
+  return check_launch("pack_bias");
+}
+
+}  // namespace lqer

@@ -1,0 +1,192 @@
+// MXINT (block floating point) quantizers over matrix rows - the HBM-bound kernels of the path.
+//
+//  k_quant_seg16 : one lane per 16-element block (the x_quantizer / A_out / B_out default,
+//                  reference llama-7b.toml:82-88).  128-bit loads and stores, no cross-lane work.
+//  k_quant_row   : one workgroup per row, one shared exponent per row (block_size [1,-1]).
+//  k_quant_blk   : one lane per block of any length, serial (cold paths: L = 32, 128, ragged).
+//
+// Replaces reference quantizers/block_fp.py:7-82 together with the pad/unfold/fold blocking of
+// quantizers/utils.py:127-158 and :211-258 (an activation's blocks are runs of L consecutive
+// elements of one row, for 2-D and 3-D inputs alike - SURVEY.md §4).
+#include "common.h"
+
+namespace lqer {
+
+template <int DT, bool VEC>
+__device__ __forceinline__ void load16(const void* x, int64_t base, int64_t k0, int64_t cols, float (&v)[16]) {
+  if constexpr (VEC) {
+    if constexpr (DT == LQER_F32) {
+      const float4* p = (const float4*)((const float*)x + base + k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 t = p[i];
+        v[4 * i] = t.x, v[4 * i + 1] = t.y, v[4 * i + 2] = t.z, v[4 * i + 3] = t.w;
+      }
+    } else {
+      const uint4* p = (const uint4*)((const bf16_t*)x + base + k0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint4 t = p[i];
+        uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (DT == LQER_F16) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            h2 h = __builtin_bit_cast(h2, w[j]);
+            v[8 * i + 2 * j] = (float)h[0];
+            v[8 * i + 2 * j + 1] = (float)h[1];
+          } else {
+            v[8 * i + 2 * j] = __uint_as_float(w[j] << 16);
+            v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (k0 + i < cols) ? load_elem<DT>(x, base + k0 + i) : 0.0f;
+  }
+}
+
+// Quantize 16 values that share exponent e (or are all zero when !any) and emit every requested image.
+__device__ __forceinline__ void emit16(const float (&v)[16], bool any, int e, const QP& q, const QuantOut& o,
+                                       int64_t row, int64_t k0, int64_t cols) {
+  float m[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m[i] = any ? mxint_mantissa(v[i], e, q) : 0.0f;
+  if (o.xq) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t lo = exact_bf16_bits(ldexpf(m[2 * i], e - q.mbits));
+      const uint32_t hi = exact_bf16_bits(ldexpf(m[2 * i + 1], e - q.mbits));
+      w[i] = lo | (hi << 16);
+    }
+    uint4* dst = (uint4*)(o.xq + row * o.cols_p + k0);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+  if (o.deq || o.codes) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (k0 + i < cols) {
+        if (o.deq) o.deq[row * cols + k0 + i] = fabsf(v[i]) <= 1e-8f ? v[i] : ldexpf(m[i], e - q.mbits);
+        if (o.codes) o.codes[row * cols + k0 + i] = (int8_t)(int)m[i];
+      }
+    }
+  }
+}
+
+template <int DT, bool VEC>
+__global__ __launch_bounds__(256) void k_quant_seg16(const void* __restrict__ x, int64_t rows, int64_t cols,
+                                                     int64_t ld, QP q, QuantOut o) {
+  const int64_t segs = o.xq ? o.cols_p / 16 : (cols + 15) / 16;
+  const int64_t total = rows * segs;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / segs;
+    const int64_t k0 = (idx - row * segs) * 16;
+    float v[16];
+    if (k0 + 16 <= cols) {
+      load16<DT, VEC>(x, row * ld, k0, cols, v);
+    } else {
+      load16<DT, false>(x, row * ld, k0, cols, v);
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    const bool any = amax > 0.0f;
+    const int e = any ? block_exponent(amax, q) : 0;
+    emit16(v, any, e, q, o, row, k0, cols);
+    if (o.exps && k0 < cols) o.exps[row * o.nblk + k0 / 16] = (int8_t)(e > 127 ? 127 : e);
+  }
+}
+
+// One workgroup per row, one exponent per row.
+template <int DT>
+__global__ __launch_bounds__(256) void k_quant_row(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                   QP q, QuantOut o) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int64_t segs = o.xq ? o.cols_p / 16 : (cols + 15) / 16;
+  float amax = 0.0f;
+  for (int64_t k = threadIdx.x; k < cols; k += 256) amax = fmaxf(amax, fabsf(load_elem<DT>(x, row * ld + k)));
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const bool any = amax > 0.0f;
+  const int e = any ? block_exponent(amax, q) : 0;
+  for (int64_t s = threadIdx.x; s < segs; s += 256) {
+    float v[16];
+    load16<DT, false>(x, row * ld, s * 16, cols, v);
+    emit16(v, any, e, q, o, row, s * 16, cols);
+  }
+  if (o.exps && threadIdx.x == 0) o.exps[row * o.nblk] = (int8_t)(e > 127 ? 127 : e);
+}
+
+// One lane per block of L elements (L a multiple of 16), serial.
+template <int DT>
+__global__ __launch_bounds__(256) void k_quant_blk(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                   QP q, QuantOut o) {
+  const int64_t L = q.block;
+  const int64_t width = o.xq ? o.cols_p : cols;
+  const int64_t nb = (width + L - 1) / L;
+  const int64_t total = rows * nb;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / nb;
+    const int64_t b0 = (idx - row * nb) * L;
+    const int64_t b1 = b0 + L < width ? b0 + L : width;
+    float amax = 0.0f;
+    for (int64_t k = b0; k < b1 && k < cols; ++k) amax = fmaxf(amax, fabsf(load_elem<DT>(x, row * ld + k)));
+    const bool any = amax > 0.0f;
+    const int e = any ? block_exponent(amax, q) : 0;
+    for (int64_t k0 = b0; k0 < b1; k0 += 16) {
+      float v[16];
+      load16<DT, false>(x, row * ld, k0, cols, v);
+      emit16(v, any, e, q, o, row, k0, cols);
+    }
+    if (o.exps && b0 < cols) o.exps[row * o.nblk + b0 / L] = (int8_t)(e > 127 ? 127 : e);
+  }
+}
+
+template <int DT>
+static int launch_quant(const void* x, int64_t rows, int64_t cols, int64_t ld, const QP& q, const QuantOut& o,
+                        hipStream_t st) {
+  if (rows == 0 || cols == 0) return LQER_OK;
+  const int64_t width = o.xq ? o.cols_p : cols;
+  const bool whole = q.block <= 0 || q.block >= cols;
+  if (whole) {
+    k_quant_row<DT><<<dim3((unsigned)rows), 256, 0, st>>>(x, rows, cols, ld, q, o);
+  } else if (q.block == 16) {
+    const int64_t total = rows * ((width + 15) / 16);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 1 << 20 ? (total + 255) / 256 : 1 << 20);
+    const int esz = DT == LQER_F32 ? 4 : 2;
+    const bool vec = ((uintptr_t)x % 16 == 0) && ((ld * esz) % 16 == 0);
+    if (vec)
+      k_quant_seg16<DT, true><<<grid, 256, 0, st>>>(x, rows, cols, ld, q, o);
+    else
+      k_quant_seg16<DT, false><<<grid, 256, 0, st>>>(x, rows, cols, ld, q, o);
+  } else if (q.block % 16 == 0) {
+    const int64_t total = rows * ((width + q.block - 1) / q.block);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 1 << 20 ? (total + 255) / 256 : 1 << 20);
+    k_quant_blk<DT><<<grid, 256, 0, st>>>(x, rows, cols, ld, q, o);
+  } else {
+    set_error("MXINT block %d: block must be 16*n or cover the whole row", q.block);
+    return LQER_E_UNSUPPORTED;
+  }
+  return check_launch("quantize_mxint");
+}
+
+int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
+                      const QuantOut& o, hipStream_t st) {
+  switch (dtype) {
+    case LQER_F32: return launch_quant<LQER_F32>(x, rows, cols, ld, q, o, st);
+    case LQER_F16: return launch_quant<LQER_F16>(x, rows, cols, ld, q, o, st);
+    case LQER_BF16: return launch_quant<LQER_BF16>(x, rows, cols, ld, q, o, st);
+  }
+  set_error("unknown dtype %d", dtype);
+  return LQER_E_INVALID;
+}
+
+}  // namespace lqer

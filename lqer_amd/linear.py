@@ -1,0 +1,172 @@
+"""Drop-in mirror of the reference's quantized Linear modules, running on the HIP library.
+
+Mirrors the reference file src/lqer/quantize/quantized_layers/linear.py:
+  _LinearBase        :12-85    constructor signature, q_config / l_config attributes, repr
+  LinearFlexible     :88-109   x / w / b quantizers, forward = F.linear(Q_x(x), Q_w(W), Q_b(b))
+  LinearFlexibleLqer :112-166  + A [in, rank], B [rank, out], A_out / B_out quantizers defaulting
+                               to the x quantizer's config (:115-124)
+and the registry of quantized_layers/__init__.py:3-16 (`get_quantized_layer_cls`).
+
+Same parameter names and shapes (weight, bias, A, B), so a stock HF checkpoint and the reference's
+`low_rank_dict.pt` load unchanged with `load_state_dict(..., strict=False)` (reference
+models/llama_decoder.py:507, runners.py:220-222).  The packed 4-bit weight image, the transposed
+bf16 limb images of A and B and the quantized bias are derived, non-persistent buffers built on the
+first forward - the counterpart of the reference's in-place first-forward quantization
+(linear.py:149-153) - and rebuilt after load_state_dict / .to().
+
+Only the PTQ inference branch exists here (is_ptq=True in every template config); the training
+branch (linear.py:158-166) raises.  There is no CPU path: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import LinearDesc, QFmt, check
+
+
+class _LinearBase(nn.Linear):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 q_config: dict = None, l_config: dict = None) -> None:
+        super().__init__(in_features, out_features, bias, device, dtype)
+        self.q_config = q_config
+        self.l_config = l_config
+        self.is_ptq = q_config.get("is_ptq", False)
+        self.w_is_quantized = False if self.is_ptq else None
+        self._fmt = {}
+        self._packed = None
+        self._setup_quantizers(q_config)
+        self._setup_lqer(l_config)
+
+    # -- configuration -------------------------------------------------------------------------
+    def _setup_quantizers(self, q_config: dict):
+        raise NotImplementedError
+
+    def _setup_lqer(self, l_config: dict):
+        raise NotImplementedError
+
+    @property
+    def rank(self) -> int:
+        return 0
+
+    def _desc(self) -> LinearDesc:
+        f = self._fmt
+        none = QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+        return LinearDesc(self.in_features, self.out_features, self.rank, int(self.bias is not None),
+                          f["x"], f["w"], f.get("b", none), f.get("A_out", none), f.get("B_out", none))
+
+    # -- derived buffers -------------------------------------------------------------------------
+    def invalidate_packed(self) -> None:
+        """Drop the packed images (called after weights change); the next forward re-packs."""
+        self._packed = None
+        if self.is_ptq:
+            self.w_is_quantized = False
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self.invalidate_packed()
+        return out
+
+    @torch.no_grad()
+    def _pack(self) -> None:
+        """One-time operand preparation = linear.py:149-153 (weight.copy_(w_quantizer(weight)), same for
+        bias) plus the build's packed images.  Like the reference, the weight/bias parameters hold the
+        quantized values afterwards."""
+        W = self.weight.data
+        ops._need_gpu(W)
+        f = self._fmt
+        p = {"w": ops.pack_weight(W, f["w"])}
+        if self.bias is not None:
+            p["bias"] = ops.pack_bias(self.bias.data, f["b"])
+            self.bias.data.copy_(p["bias"][: self.out_features].to(self.bias.dtype))
+        if self.rank > 0:
+            p["a_t"], p["b_t"], p["a_limbs"], p["b_limbs"] = ops.pack_lowrank(self.A.data, self.B.data)
+        # the parameter now carries w_quantizer(W) (|w| <= 1e-8 kept as is, block_fp.py:79-80)
+        wq = ops.quantize_mxint(W, f["w"], want=("deq",))["deq"]
+        self.weight.data.copy_(wq.to(W.dtype))
+        self._packed = p
+        self.w_is_quantized = True
+
+    # -- forward -------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.is_ptq:
+            raise NotImplementedError("lqer_amd implements the PTQ inference branch only (q_config['is_ptq'] = True)")
+        ops._need_gpu(x)
+        with torch.no_grad():
+            if self._packed is None or self.w_is_quantized is False:
+                self._pack()
+            K, N = self.in_features, self.out_features
+            if x.shape[-1] != K:
+                raise RuntimeError(f"expected last dim {K}, got {tuple(x.shape)}")
+            x2 = x.reshape(-1, K)
+            if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < K):
+                x2 = x2.contiguous()
+            M = x2.shape[0]
+            y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+            if M > 0:
+                desc = self._desc()
+                sz = ops.linear_sizes(desc, M)
+                ws = ops.workspace(x.device, sz.workspace)
+                p = self._packed
+                check(
+                    _lib.lib().lqer_linear_forward(
+                        C.byref(desc), x2.data_ptr(), ops.dtype_code(x2), M, x2.stride(0) if M > 1 else K,
+                        p["w"].data_ptr(), ops._ptr(p.get("a_t")), ops._ptr(p.get("b_t")),
+                        p.get("a_limbs", 0), p.get("b_limbs", 0), ops._ptr(p.get("bias")),
+                        y.data_ptr(), N, ws.data_ptr(), ws.numel(), ops._stream(x.device)),
+                    "lqer_linear_forward",
+                )
+            return y.reshape(*x.shape[:-1], N)
+
+    def __repr__(self):
+        return "{}(in_features={}, out_features={}, bias={}, is_ptq={}, rank={}, backend=hip/gfx950)".format(
+            self.__class__.__name__, self.in_features, self.out_features, self.bias is not None, self.is_ptq, self.rank)
+
+
+class LinearFlexible(_LinearBase):
+    def _setup_quantizers(self, q_config: dict):
+        # q_config["default"] is evaluated eagerly, as in the reference (linear.py:90-91): a config
+        # without a "default" key raises KeyError there and here.
+        x_cfg = deepcopy(q_config.get("x_quantizer", q_config["default"]))
+        w_cfg = deepcopy(q_config.get("w_quantizer", q_config["default"]))
+        self._fmt["x"] = ops.make_qfmt(x_cfg)
+        self._fmt["w"] = ops.make_qfmt(w_cfg)
+        if self.bias is not None:
+            self._fmt["b"] = ops.make_qfmt(deepcopy(q_config.get("b_quantizer", q_config["default"])))
+
+    def _setup_lqer(self, l_config: dict):
+        pass
+
+
+class LinearFlexibleLqer(LinearFlexible):
+    def _setup_quantizers(self, q_config: dict):
+        LinearFlexible._setup_quantizers(self, q_config)
+        fall = q_config.get("x_quantizer", q_config["default"])
+        self._fmt["B_out"] = ops.make_qfmt(deepcopy(q_config.get("B_out_quantizer", fall)))
+        self._fmt["A_out"] = ops.make_qfmt(deepcopy(q_config.get("A_out_quantizer", fall)))
+
+    def _setup_lqer(self, l_config: dict):
+        # y = x_q W_q^T + (x_q A) B ;  A [in, rank], B [rank, out], zeros until loaded (linear.py:134-143)
+        self.A = nn.Parameter(torch.zeros(self.weight.shape[1], l_config["rank"]))
+        self.B = nn.Parameter(torch.zeros(l_config["rank"], self.weight.shape[0]))
+
+    @property
+    def rank(self) -> int:
+        return int(self.A.shape[1])
+
+
+QUANTIZED_MODULE_MAP = {"linear": {"flexible": LinearFlexible, "flexible_lqer": LinearFlexibleLqer}}
+
+
+def get_quantized_layer_cls(op: str, q_config: dict):
+    assert op in QUANTIZED_MODULE_MAP, f"Unsupported quantized op: {op}"
+    assert q_config["name"] in QUANTIZED_MODULE_MAP[op], f"Unsupported quantized config: {q_config}"
+    return QUANTIZED_MODULE_MAP[op][q_config["name"]]

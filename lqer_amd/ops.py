@@ -1,0 +1,170 @@
+"""Torch-tensor wrappers over the C ABI (device pointers + the current HIP stream).  Host logic
+only: shape checks, buffer allocation, format descriptors.  All arithmetic happens in the HIP
+kernels; a CPU tensor is an error, not a fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import LinearDesc, LinearSizes, QFmt, check
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"lqer_amd: unsupported dtype {t.dtype} (float32 / float16 / bfloat16)") from None
+
+
+def _need_gpu(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("lqer_amd runs on the HIP device only: got a CPU tensor (there is no CPU fallback)")
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def make_qfmt(cfg: Optional[dict], last_dim_only: bool = True) -> QFmt:
+    """One q_config entry (reference quantize/__init__.py:1-40 schema) -> lqer_qfmt_t.
+    Blocks must run along the last dim: block_size [1, L], [L] or [-1] (every template config)."""
+    if cfg is None:
+        raise KeyError("quantizer config missing")
+    name = cfg["name"]
+    if name == "passthrough":
+        return QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+    if name != "block_fp":
+        raise NotImplementedError(f"quantizer '{name}' is not implemented on the HIP path (block_fp, passthrough)")
+    bs = cfg.get("block_size", [16])
+    bs = [bs] if isinstance(bs, int) else list(bs)
+    if any(b not in (1,) for b in bs[:-1]):
+        raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path")
+    ew = int(cfg.get("exponent_width", 8))
+    eb = cfg.get("exponent_bias", None)
+    eb = 2 ** (ew - 1) - 1 if eb in (None, "none", "None", "NA") else int(eb)
+    return QFmt(_lib.Q_MXINT, int(cfg.get("width", 12)), int(bs[-1]), ew, eb)
+
+
+def quantize_mxint(x: torch.Tensor, fmt: QFmt, want=("deq", "codes", "exps")) -> Dict[str, torch.Tensor]:
+    """MXINT quantizer over the last dim of x (any leading dims).  Returns the requested images."""
+    _need_gpu(x)
+    cols = x.shape[-1]
+    x2 = x.reshape(-1, cols)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    L = cols if fmt.block <= 0 or fmt.block >= cols else fmt.block
+    out: Dict[str, torch.Tensor] = {}
+    if "deq" in want:
+        out["deq"] = torch.empty(rows, cols, dtype=torch.float32, device=x.device)
+    if "codes" in want:
+        out["codes"] = torch.empty(rows, cols, dtype=torch.int8, device=x.device)
+    if "exps" in want:
+        out["exps"] = torch.zeros(rows, -(-cols // L) if L else 0, dtype=torch.int8, device=x.device)
+    check(
+        _lib.lib().lqer_quantize_mxint(
+            x2.data_ptr(), dtype_code(x2), rows, cols, x2.stride(0) if rows > 1 else cols, C.byref(fmt),
+            _ptr(out.get("deq")), _ptr(out.get("codes")), _ptr(out.get("exps")), _stream(x.device)),
+        "lqer_quantize_mxint",
+    )
+    for k in ("deq", "codes"):
+        if k in out:
+            out[k] = out[k].reshape(x.shape)
+    return out
+
+
+def quantize_act(x2: torch.Tensor, fmt: QFmt, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M,K] -> exact bf16 image [Mp,Kp] of x_quantizer(x)."""
+    _need_gpu(x2)
+    M, K = x2.shape
+    L = _lib.lib()
+    Mp, Kp = L.lqer_padded_m(M), L.lqer_padded_k(K)
+    if out is None:
+        out = torch.empty(Mp, Kp, dtype=torch.bfloat16, device=x2.device)
+    check(
+        L.lqer_quantize_act_mxint(x2.data_ptr(), dtype_code(x2), M, K, x2.stride(0) if M > 1 else K, C.byref(fmt), out.data_ptr(), _stream(x2.device)),
+        "lqer_quantize_act_mxint",
+    )
+    return out
+
+
+def linear_sizes(desc: LinearDesc, m_max: int) -> LinearSizes:
+    sz = LinearSizes()
+    check(_lib.lib().lqer_linear_sizes(C.byref(desc), m_max, C.byref(sz)), "lqer_linear_sizes")
+    return sz
+
+
+def pack_weight(W: torch.Tensor, fmt: QFmt) -> torch.Tensor:
+    _need_gpu(W)
+    N, K = W.shape
+    if W.stride(-1) != 1:
+        W = W.contiguous()
+    L = _lib.lib()
+    Np, Kp = L.lqer_padded_n(N), L.lqer_padded_k(K)
+    packed = torch.empty((Np // 16) * (Kp // 64) * 576, dtype=torch.uint8, device=W.device)
+    scratch = torch.empty(N * (-(-K // 16)), dtype=torch.int8, device=W.device)
+    check(
+        L.lqer_pack_weight_mxint(W.data_ptr(), dtype_code(W), N, K, W.stride(0), C.byref(fmt), packed.data_ptr(), scratch.data_ptr(), _stream(W.device)),
+        "lqer_pack_weight_mxint",
+    )
+    return packed
+
+
+def unpack_weight(packed: torch.Tensor, N: int, K: int, fmt: QFmt) -> torch.Tensor:
+    _need_gpu(packed)
+    out = torch.empty(N, K, dtype=torch.float32, device=packed.device)
+    check(_lib.lib().lqer_unpack_weight_mxint(packed.data_ptr(), N, K, C.byref(fmt), out.data_ptr(), _stream(packed.device)), "lqer_unpack_weight_mxint")
+    return out
+
+
+def pack_lowrank(A: torch.Tensor, B: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, int, int]:
+    """A [K,r], B [r,N] -> (a_t, b_t, a_limbs, b_limbs).  Synchronises once to read the limb counts."""
+    _need_gpu(A, B)
+    K, r = A.shape
+    r2, N = B.shape
+    if r != r2 or A.dtype != B.dtype:
+        raise ValueError(f"A {tuple(A.shape)} {A.dtype} and B {tuple(B.shape)} {B.dtype} do not match")
+    L = _lib.lib()
+    Kp, Np, rp = L.lqer_padded_k(K), L.lqer_padded_n(N), L.lqer_padded_r(r)
+    a_t = torch.empty(3 * rp * Kp, dtype=torch.bfloat16, device=A.device)
+    b_t = torch.empty(3 * Np * rp, dtype=torch.bfloat16, device=A.device)
+    flags = torch.zeros(2, dtype=torch.int32, device=A.device)
+    A, B = A.contiguous(), B.contiguous()
+    check(
+        L.lqer_pack_lowrank(A.data_ptr(), B.data_ptr(), dtype_code(A), K, N, r, a_t.data_ptr(), b_t.data_ptr(), flags.data_ptr(), _stream(A.device)),
+        "lqer_pack_lowrank",
+    )
+    fl = flags.tolist()
+    return a_t, b_t, int(fl[0]), int(fl[1])
+
+
+def pack_bias(bias: torch.Tensor, fmt: QFmt) -> torch.Tensor:
+    _need_gpu(bias)
+    N = bias.shape[0]
+    out = torch.empty(_lib.lib().lqer_padded_n(N), dtype=torch.float32, device=bias.device)
+    bias = bias.contiguous()
+    check(_lib.lib().lqer_pack_bias(bias.data_ptr(), dtype_code(bias), N, C.byref(fmt), out.data_ptr(), _stream(bias.device)), "lqer_pack_bias")
+    return out
+
+
+# grow-only per-(device, stream) scratch shared by every Linear (stream-ordered reuse is safe)
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws

@@ -1,0 +1,275 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lqer_oracle as O  # the checker (tests may import it; the product never does)
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from lqer_amd import ops as _ops
+
+    return _ops
+
+
+def _fmt(ops, width, block):
+    return ops.make_qfmt(dict(name="block_fp", width=width, exponent_width=8, exponent_bias=None, block_size=[1, block]))
+
+
+def _q_cases(golden_q):
+    """(name, x, y_ref, width, block along last dim) for every golden case the HIP path covers."""
+    out = []
+    for name in sorted({k.split("/")[1] for k in golden_q.files if k.startswith("q/")}):
+        x = torch.from_numpy(golden_q[f"q/{name}/x"])
+        y = torch.from_numpy(golden_q[f"q/{name}/y"])
+        meta = golden_q[f"q/{name}/meta"].tolist()
+        width, block = meta[0], meta[2:]
+        if width > 8:
+            continue
+        if x.ndim == 2 and len(block) == 2 and block[0] == 16 and block[1] == 1:
+            out.append((name + "^T", x.t().contiguous(), y.t().contiguous(), width, 16))  # column blocks = row blocks of x^T
+            continue
+        if any(b != 1 for b in block[:-1]):
+            continue  # 2-D tiles: not on the path
+        out.append((name, x, y, width, block[-1]))
+    return out
+
+
+def test_quantizer_bit_exact_vs_reference_vectors(ops, golden_q):
+    cases = _q_cases(golden_q)
+    assert len(cases) >= 18
+    for name, x, y, width, block in cases:
+        got = ops.quantize_mxint(x.to(DEV), _fmt(ops, width, block), want=("deq",))["deq"].cpu()
+        assert torch.equal(got.view(torch.int32), y.view(torch.int32)) or torch.equal(got, y), name
+
+
+def test_quantizer_codes_and_exponents_bit_exact(ops, golden_q):
+    for name, x, y, width, block in _q_cases(golden_q):
+        x2 = x.reshape(-1, x.shape[-1])
+        _, codes, exps = O.mxint_quantize(x2, width=width, block_size=[1, block], skip_first_dim=True, decompose=True)
+        got = ops.quantize_mxint(x2.to(DEV), _fmt(ops, width, block))
+        assert torch.equal(got["codes"].cpu().to(torch.int32), codes), name
+        assert torch.equal(got["exps"].cpu().to(torch.int32), exps.reshape(x2.shape[0], -1).clamp(-128, 127)), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_quantizer_half_inputs(ops, dtype):
+    torch.manual_seed(3)
+    x = (torch.randn(33, 200) * 3).to(dtype)
+    x[:, 7] *= 30
+    for block in (16, 32, -1):
+        ref, codes, exps = O.mxint_quantize(x.float(), width=8, block_size=[1, block], skip_first_dim=True, decompose=True)
+        got = ops.quantize_mxint(x.to(DEV), _fmt(ops, 8, block))
+        assert torch.equal(got["deq"].cpu(), ref)
+        assert torch.equal(got["codes"].cpu().to(torch.int32), codes)
+
+
+def test_quantize_act_bf16_image_exact(ops):
+    torch.manual_seed(4)
+    for (M, K) in ((5, 176), (300, 4096), (1, 50)):
+        x = torch.randn(M, K, dtype=torch.float16)
+        x[:, 3] *= 30
+        ref = O.mxint_quantize(x.float(), width=8, block_size=[1, 16], skip_first_dim=True)
+        xq = ops.quantize_act(x.to(DEV), _fmt(ops, 8, 16)).cpu()
+        assert xq.shape[0] % 256 == 0 and xq.shape[1] % 64 == 0
+        assert torch.equal(xq[:M, :K].float(), ref)
+        assert not xq[:M, K:].any()
+
+
+def _panels_from_rowmajor(codes, exps, L, Kp):
+    """oracle layout ([Np,Kp/2] codes, [Np,nblk] exps) -> the library's panel layout (bytes)."""
+    Np = codes.shape[0]
+    e16 = exps.repeat_interleave(max(L // 16, 1), dim=1)[:, : Kp // 16] if L < Kp else exps[:, :1].expand(Np, Kp // 16)
+    c = codes.reshape(Np // 16, 16, Kp // 64, 32).permute(0, 2, 1, 3)  # [pn, pk, 16, 32]
+    e = e16.reshape(Np // 16, 16, Kp // 64, 4).permute(0, 2, 1, 3).contiguous().view(torch.uint8)
+    return torch.cat([c.reshape(Np // 16, Kp // 64, 512), e.reshape(Np // 16, Kp // 64, 64)], dim=2).reshape(-1)
+
+
+def test_pack_unpack_weight_bit_exact(ops, golden_q):
+    for name, block in (("w4_b16", 16), ("w4_b128", 128), ("w4_row", -1), ("w4_ragged", 16), ("w2_b32", 32)):
+        x = torch.from_numpy(golden_q[f"q/{name}/x"])
+        y = torch.from_numpy(golden_q[f"q/{name}/y"])
+        width = int(golden_q[f"q/{name}/meta"][0])
+        fmt = _fmt(ops, width, block)
+        packed = ops.pack_weight(x.to(DEV), fmt)
+        w = ops.unpack_weight(packed, x.shape[0], x.shape[1], fmt).cpu()
+        ref = torch.where(x.abs() <= 1e-8, torch.zeros_like(y), y)  # declared flush (block_fp.py:79-80)
+        assert torch.equal(w, ref), name
+        if width == 4:
+            codes, exps = O.pack_weight_mxint4(x, block, n_pad=128, k_pad=64)
+            Kp = codes.shape[1] * 2
+            L = Kp if block <= 0 or block >= x.shape[1] else block
+            want = _panels_from_rowmajor(codes, exps, L, Kp)
+            assert torch.equal(packed.cpu(), want), name
+
+
+def test_pack_lowrank_limbs(ops):
+    torch.manual_seed(5)
+    K, N, r = 100, 70, 24
+    A8 = O.mxint_quantize(0.05 * torch.randn(K, r), width=8, block_size=[16, 1], skip_first_dim=False)
+    B8 = O.mxint_quantize(0.05 * torch.randn(r, N), width=8, block_size=[16, 1], skip_first_dim=False)
+    for A, B, want in ((A8, B8, 1), (A8.half(), B8.half(), 1), (torch.randn(K, r).half(), torch.randn(r, N).half(), 2),
+                       (torch.randn(K, r), torch.randn(r, N), 3)):
+        a_t, b_t, la, lb = ops.pack_lowrank(A.to(DEV), B.to(DEV))
+        assert (la, lb) == (want, want)
+        Kp, Np, rp = 128, 128, 32
+        a3 = a_t.cpu().float().reshape(3, rp, Kp)
+        b3 = b_t.cpu().float().reshape(3, Np, rp)
+        assert torch.equal(a3.sum(0)[:r, :K].t().double(), A.double()) or torch.equal((a3[0].double() + a3[1].double() + a3[2].double())[:r, :K].t(), A.double())
+        assert torch.equal((b3[0].double() + b3[1].double() + b3[2].double())[:N, :r].t(), B.double())
+        assert not a3[:, r:].any() and not a3[:, :, K:].any() and not b3[:, N:].any() and not b3[:, :, r:].any()
+
+
+def _module_from_case(g, cfgs, name, dtype=torch.float32):
+    import lqer_amd
+
+    t = lambda k: torch.from_numpy(g[f"{name}/{k}"])
+    qc = cfgs[name]
+    W = t("W")
+    N, K = W.shape
+    has_b = f"{name}/bias" in g.files
+    r = int(g[f"{name}/rank"][0])
+    mod = lqer_amd.get_quantized_layer_cls("linear", qc)(K, N, bias=has_b, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": t("A"), "B": t("B")}
+    if has_b:
+        sd["bias"] = t("bias")
+    mod.load_state_dict(sd)  # same keys as the reference module
+    return mod.to(DEV).to(dtype), t
+
+
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged"]
+
+
+@pytest.mark.parametrize("name", FWD_CASES)
+def test_forward_vs_reference_vectors(ops, golden_fwd, name):
+    g, cfgs = golden_fwd
+    mod, t = _module_from_case(g, cfgs, name)
+    y = mod(t("x").to(DEV)).cpu()
+    ref = t("y")
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    err = (y - ref).norm() / ref.norm()
+    assert err <= 1e-5, float(err)  # fp32 in/out: only accumulation order differs
+    # like the reference after its first forward, the parameters now hold the quantized values
+    assert torch.equal(mod.weight.detach().cpu(), t("wq"))
+    if mod.bias is not None:
+        assert torch.equal(mod.bias.detach().cpu(), t("bq"))
+
+
+def test_forward_stages_vs_reference_vectors(ops, golden_fwd):
+    """xq and xAq (the two quantized intermediates that are materialised) against the vectors."""
+    import ctypes as C
+
+    from lqer_amd import _lib
+
+    g, cfgs = golden_fwd
+    for name in ("m7", "m64", "r128"):
+        mod, t = _module_from_case(g, cfgs, name)
+        x = t("x").to(DEV)
+        mod(x)
+        M, K = x.reshape(-1, x.shape[-1]).shape
+        xq = ops.quantize_act(x.reshape(M, K), mod._fmt["x"])
+        assert torch.equal(xq[:M, :K].float().cpu(), t("xq").reshape(M, K))
+        rp = _lib.lib().lqer_padded_r(mod.rank)
+        xaq = torch.empty(xq.shape[0], rp, dtype=torch.bfloat16, device=DEV)
+        desc = mod._desc()
+        p = mod._packed
+        _lib.check(_lib.lib().lqer_lowrank_xa(C.byref(desc), xq.data_ptr(), M, p["a_t"].data_ptr(), p["a_limbs"], xaq.data_ptr(), None), "xa")
+        torch.cuda.synchronize()
+        got = xaq[:M, : mod.rank].float().cpu()
+        ref = t("xAq").reshape(M, -1)
+        # a re-quantizer amplifies fp32 summation-order noise into (rare) one-step differences
+        step = (got - ref).abs().max() / ref.abs().max()
+        assert (got != ref).float().mean() <= 0.02 and step <= 2.0 ** -6, name
+
+
+def test_forward_no_side_path(ops, golden_fwd):
+    import lqer_amd
+
+    g, cfgs = golden_fwd
+    t = lambda k: torch.from_numpy(g[f"flex/{k}"])
+    qc = cfgs["flex"]
+    mod = lqer_amd.get_quantized_layer_cls("linear", qc)(96, 48, bias=True, q_config=qc, l_config=None)
+    mod.load_state_dict({"weight": t("W"), "bias": t("bias")})
+    y = mod.to(DEV)(t("x").to(DEV)).cpu()
+    assert (y - t("y")).norm() / t("y").norm() <= 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 5e-3), (torch.float32, 1e-5)])
+def test_forward_llama_shape_vs_oracle(ops, dtype, tol):
+    """4096 -> 4096, rank 32, W4A8 MXINT (BASELINE config 2) against the CPU oracle; tolerance is the
+    north star's 1e-3 relative L2 for fp16 output (bf16 output rounding alone is 2^-9)."""
+    import lqer_amd
+    from bench import make_case, MXINT_Q
+
+    K = N = 4096
+    M, r = 384, 32
+    x, W, A, B = make_case(M, K, N, r, seed=0)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).to(dtype)
+    xin = x.to(dtype)
+    y = mod(xin.to(DEV)).float().cpu()
+    ref = O.lqer_linear_forward(xin.float(), W.to(dtype).float(), None, A.to(dtype).float(), B.to(dtype).float(), MXINT_Q)
+    err = (y - ref).norm() / ref.norm()
+    assert err <= tol, float(err)
+
+
+def test_size_independent_properties_full_size(ops):
+    """At BASELINE's full size (M=2048, 4096x4096, r=32): rows and output columns are independent,
+    so a row permutation, a row split and a column split must reproduce the same bits."""
+    import lqer_amd
+    from bench import make_case, MXINT_Q
+
+    K = N = 4096
+    M, r = 2048, 32
+    x, W, A, B = make_case(M, K, N, r, seed=1)
+    x = x.half().to(DEV)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).half()
+    y = mod(x)
+    assert torch.isfinite(y).all()
+    perm = torch.randperm(M, device=DEV)
+    assert torch.equal(mod(x[perm]), y[perm])
+    assert torch.equal(mod(x[:1000]), y[:1000])
+    assert torch.equal(mod(x[1000:1001]), y[1000:1001])
+    half = lqer_amd.LinearFlexibleLqer(K, N // 2, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    half.load_state_dict({"weight": W[: N // 2], "A": A, "B": B[:, : N // 2]})
+    assert torch.equal(half.to(DEV).half()(x), y[:, : N // 2])
+    # 3-D input = flattened 2-D input (reference blocks both the same way)
+    assert torch.equal(mod(x.reshape(2, M // 2, K)).reshape(M, N), y)
+    # zero A,B: the side path contributes nothing -> LinearFlexible
+    z = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    z.load_state_dict({"weight": W}, strict=False)
+    f = lqer_amd.LinearFlexible(K, N, bias=False, q_config=dict(MXINT_Q, name="flexible"), l_config=None)
+    f.load_state_dict({"weight": W})
+    assert torch.equal(z.to(DEV).half()(x), f.to(DEV).half()(x))
+
+
+def test_edge_shapes_and_errors(ops):
+    import lqer_amd
+    from bench import MXINT_Q
+
+    mod = lqer_amd.LinearFlexibleLqer(64, 48, bias=True, q_config=MXINT_Q, l_config={"rank": 16}).to(DEV)
+    assert mod(torch.zeros(0, 64, device=DEV)).shape == (0, 48)
+    assert mod(torch.zeros(2, 0, 64, device=DEV)).shape == (2, 0, 48)
+    y0 = mod(torch.zeros(3, 64, device=DEV))
+    assert torch.equal(y0, mod.bias.detach().expand(3, 48))  # all-zero activations: y = b_q
+    with pytest.raises(RuntimeError):
+        mod(torch.zeros(3, 65, device=DEV))
+    with pytest.raises(RuntimeError):
+        mod(torch.zeros(3, 64))  # CPU tensor: no fallback
+    bad = dict(MXINT_Q, x_quantizer=dict(name="minifloat", width=8))
+    with pytest.raises(NotImplementedError):
+        lqer_amd.LinearFlexibleLqer(64, 48, q_config=bad, l_config={"rank": 16})
+    # non-contiguous rows
+    xb = torch.randn(5, 128, device=DEV)
+    assert torch.equal(mod(xb[:, :64]), mod(xb[:, :64].contiguous()))
