@@ -84,10 +84,13 @@ def test_quantize_act_bf16_image_exact(ops):
         assert not xq[:M, K:].any()
 
 
-def _panels_from_rowmajor(codes, exps, L, Kp):
-    """oracle layout ([Np,Kp/2] codes, [Np,nblk] exps) -> the library's panel layout (bytes)."""
+def _panels_from_rowmajor(codes, exps, L, Kp, K):
+    """oracle layout ([Np,Kp/2] codes, [Np,nblk] exps) -> the library's panel layout (bytes).
+    Segments that lie entirely in the K padding carry exponent 0."""
     Np = codes.shape[0]
     e16 = exps.repeat_interleave(max(L // 16, 1), dim=1)[:, : Kp // 16] if L < Kp else exps[:, :1].expand(Np, Kp // 16)
+    e16 = e16.clone()
+    e16[:, -(-K // 16):] = 0
     c = codes.reshape(Np // 16, 16, Kp // 64, 32).permute(0, 2, 1, 3)  # [pn, pk, 16, 32]
     e = e16.reshape(Np // 16, 16, Kp // 64, 4).permute(0, 2, 1, 3).contiguous().view(torch.uint8)
     return torch.cat([c.reshape(Np // 16, Kp // 64, 512), e.reshape(Np // 16, Kp // 64, 64)], dim=2).reshape(-1)
@@ -107,7 +110,7 @@ def test_pack_unpack_weight_bit_exact(ops, golden_q):
             codes, exps = O.pack_weight_mxint4(x, block, n_pad=128, k_pad=64)
             Kp = codes.shape[1] * 2
             L = Kp if block <= 0 or block >= x.shape[1] else block
-            want = _panels_from_rowmajor(codes, exps, L, Kp)
+            want = _panels_from_rowmajor(codes, exps, L, Kp, x.shape[1])
             assert torch.equal(packed.cpu(), want), name
 
 
