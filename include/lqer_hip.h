@@ -51,7 +51,7 @@ extern "C" {
 /* Geometry of the packed operands (fixed by the kernels; exported so callers can size buffers). */
 #define LQER_K_ALIGN 64     /* K is zero-padded to a multiple of this                        */
 #define LQER_M_ALIGN 256    /* activation workspaces are row-padded to a multiple of this    */
-#define LQER_N_ALIGN 128    /* packed weights are row-padded to a multiple of this           */
+#define LQER_N_ALIGN 256    /* packed weights are row-padded to a multiple of this           */
 #define LQER_R_ALIGN 16     /* rank is zero-padded to a multiple of this                     */
 #define LQER_PANEL_ROWS 16  /* packed W: panels of 16 rows x 64 k                            */
 #define LQER_PANEL_BYTES 576 /* 16*32 B of 4-bit codes + 16*4 B of block exponents           */
@@ -120,10 +120,11 @@ int lqer_quantize_act_mxint(const void* x, int dtype, int64_t M, int64_t K, int6
 
 int lqer_linear_sizes(const lqer_linear_desc_t* desc, int64_t m_max, lqer_linear_sizes_t* out);
 
-/* W [N,K] (row stride ldw) -> packed panels: w_quantizer(W) as 4-bit two's-complement mantissas
- * + int8 block exponents.  Panel (n/16, k/64) = 16 rows x 32 B codes (element 2j in the low
- * nibble of byte j) followed by 16 x 4 exponents (one per 16 k; a coarser block repeats its
- * exponent).  |w| <= 1e-8 is flushed to code 0.  `scratch` needs N*ceil(K/16) bytes.          */
+/* W [N,K] (row stride ldw) -> packed panels: w_quantizer(W) as 4-bit sign-magnitude mantissas
+ * (bit 3 = sign) + int8 block exponents.  Panel (n/16, k/64) = 16 rows x 32 B codes followed by
+ * 16 x 4 exponents (one per 16 k; a coarser block repeats its exponent).  Within each 32-bit
+ * word of codes (8 consecutive k) nibble p holds k = p/2 (p even) or 4 + p/2 (p odd).
+ * |w| <= 1e-8 is flushed to code 0.  `scratch` needs N*ceil(K/16) bytes.                      */
 int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64_t ldw,
                            const lqer_qfmt_t* fmt, void* w_packed, void* scratch, void* stream);
 

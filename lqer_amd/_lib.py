@@ -14,7 +14,7 @@ BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 ABI_VERSION = 1
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT = 0, 1
-K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 128, 16
+K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
 
 
 class QFmt(C.Structure):

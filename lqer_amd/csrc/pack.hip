@@ -3,8 +3,10 @@
 // quantizers/utils.py:161-208) with a packed 4-bit image the GEMM kernel streams.
 //
 // Packed W layout (DESIGN.md "Data layout"): panels of 16 rows x 64 k, panel (pn, pk) at byte
-// ((pn * Kp/64) + pk) * 576:   [16 rows][32 B]  4-bit two's-complement mantissas, k even = low nibble
+// ((pn * Kp/64) + pk) * 576:   [16 rows][32 B]  4-bit sign-magnitude mantissas (bit 3 = sign)
 //                              [16 rows][4]     int8 exponent of each 16-k segment
+// Within each 32-bit word (8 consecutive k) nibble p holds k = p/2 for even p and 4 + p/2 for odd p,
+// so that the GEMM kernel's byte-wise expand (even nibbles, then odd nibbles) emits k in order.
 // A coarser weight block (32, 128, whole row) repeats its exponent per segment, so the GEMM kernel
 // handles every block length with one code path.
 #include "common.h"
@@ -44,11 +46,13 @@ __global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int6
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float w = (k0 + i < K) ? load_elem<DT>(W, row * ld + k0 + i) : 0.0f;
-          const uint32_t c = ((uint32_t)(int)mxint_mantissa(w, e, q)) & 0xfu;
+          const int mi = (int)mxint_mantissa(w, e, q);
+          const uint32_t c = (uint32_t)(mi < 0 ? (8 - mi) : mi);  // sign-magnitude, +0 canonical
+          const int j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
           if (i < 8)
-            lo |= c << (4 * i);
+            lo |= c << (4 * pos);
           else
-            hi |= c << (4 * (i - 8));
+            hi |= c << (4 * pos);
         }
       }
     }
@@ -70,7 +74,9 @@ __global__ __launch_bounds__(256) void k_w_unpack(const uint8_t* __restrict__ in
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const uint32_t word = i < 8 ? c.x : c.y;
-      const int v = ((int)(word << (28 - 4 * (i & 7)))) >> 28;  // sign-extended nibble
+      const int j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
+      const uint32_t nib = (word >> (4 * pos)) & 0xfu;
+      const int v = (nib & 8u) ? -(int)(nib & 7u) : (int)nib;
       if (k0 + i < K) out[row * K + k0 + i] = ldexpf((float)v, e - mbits);
     }
   }

@@ -306,10 +306,15 @@ def lqer_linear_forward(
 # the build's packed weight format (no counterpart in the reference; restated here so the GPU
 # pack kernel can be checked bit-for-bit).  See DESIGN.md "Data layout".
 # ----------------------------------------------------------------------------------------------
+_NIB_POS = [0, 2, 4, 6, 1, 3, 5, 7]  # nibble position (within a 32-bit word) of k = 0..7
+
+
 def pack_weight_mxint4(weight: torch.Tensor, block: int, n_pad: int = 1, k_pad: int = 64):
     """W[N,K] -> (codes uint8 [Np, Kp/2], exps int8 [Np, Kp/block_eff]) with
-    code = two's-complement 4-bit signed mantissa (-7..7), element 2j in the low nibble of byte j;
-    exps = shared exponent e of each `block` consecutive k (value = code * 2^(e-3)).
+    code = 4-bit sign-magnitude mantissa (bit 3 = sign, magnitude 0..7, +0 canonical);
+    within each group of 8 consecutive k (one little-endian 32-bit word) nibble p holds
+    k = p/2 (p even) or 4 + p/2 (p odd);
+    exps = shared exponent e of each `block` consecutive k (value = +-magnitude * 2^(e-3)).
     block <= 0 means one block per row.  Rows/cols are zero-padded to multiples of n_pad / k_pad.
     Elements with |w| <= 1e-8 are flushed to code 0 (reference keeps them unquantized)."""
     N, K = weight.shape
@@ -322,7 +327,12 @@ def pack_weight_mxint4(weight: torch.Tensor, block: int, n_pad: int = 1, k_pad: 
     cpad[:N, :K] = codes
     epad = torch.zeros(Np, nblk, dtype=torch.int32)
     epad[:N, : exps.reshape(N, -1).shape[1]] = exps.reshape(N, -1)
-    nib = (cpad & 0xF).to(torch.uint8)
+    sm = torch.where(cpad < 0, 8 - cpad, cpad).to(torch.uint8)  # sign-magnitude nibble
+    grp = sm.reshape(Np, Kp // 8, 8)
+    nib = torch.zeros_like(grp)
+    for k, pos in enumerate(_NIB_POS):
+        nib[:, :, pos] = grp[:, :, k]
+    nib = nib.reshape(Np, Kp)
     packed = nib[:, 0::2] | (nib[:, 1::2] << 4)
     return packed.contiguous(), epad.clamp(-128, 127).to(torch.int8).contiguous()
 
@@ -331,8 +341,9 @@ def unpack_weight_mxint4(packed: torch.Tensor, exps: torch.Tensor, N: int, K: in
     L = K if block <= 0 or block > K else block
     lo = (packed & 0xF).to(torch.int32)
     hi = (packed >> 4).to(torch.int32)
-    nib = torch.stack([lo, hi], dim=-1).reshape(packed.shape[0], -1)
-    c = torch.where(nib >= 8, nib - 16, nib).to(torch.float32)
+    nib = torch.stack([lo, hi], dim=-1).reshape(packed.shape[0], -1, 8)
+    grp = torch.stack([nib[:, :, pos] for pos in _NIB_POS], dim=-1).reshape(packed.shape[0], -1)
+    c = torch.where(grp >= 8, -(grp - 8), grp).to(torch.float32)
     e = exps.to(torch.float32).repeat_interleave(L, dim=1)[:, : c.shape[1]]
     return (c * torch.pow(2.0, e - 3))[:N, :K]
 

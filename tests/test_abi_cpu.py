@@ -46,7 +46,7 @@ def test_abi_constants_and_padding(lib):
     assert (int(consts["LQER_K_ALIGN"]), int(consts["LQER_M_ALIGN"]), int(consts["LQER_N_ALIGN"]), int(consts["LQER_R_ALIGN"])) == (
         _lib.K_ALIGN, _lib.M_ALIGN, _lib.N_ALIGN, _lib.R_ALIGN)
     assert lib.lqer_padded_k(4096) == 4096 and lib.lqer_padded_k(4097) == 4160 and lib.lqer_padded_k(1) == 64
-    assert lib.lqer_padded_n(11008) == 11008 and lib.lqer_padded_n(50) == 128
+    assert lib.lqer_padded_n(11008) == 11008 and lib.lqer_padded_n(50) == 256
     assert lib.lqer_padded_m(1) == 256 and lib.lqer_padded_r(32) == 32 and lib.lqer_padded_r(33) == 48
     assert C.sizeof(_lib.QFmt) == 20 and C.sizeof(_lib.LinearDesc) == 16 + 5 * 20
 

@@ -107,7 +107,7 @@ def test_pack_unpack_weight_bit_exact(ops, golden_q):
         ref = torch.where(x.abs() <= 1e-8, torch.zeros_like(y), y)  # declared flush (block_fp.py:79-80)
         assert torch.equal(w, ref), name
         if width == 4:
-            codes, exps = O.pack_weight_mxint4(x, block, n_pad=128, k_pad=64)
+            codes, exps = O.pack_weight_mxint4(x, block, n_pad=256, k_pad=64)
             Kp = codes.shape[1] * 2
             L = Kp if block <= 0 or block >= x.shape[1] else block
             want = _panels_from_rowmajor(codes, exps, L, Kp, x.shape[1])
@@ -123,7 +123,7 @@ def test_pack_lowrank_limbs(ops):
                        (torch.randn(K, r), torch.randn(r, N), 3)):
         a_t, b_t, la, lb = ops.pack_lowrank(A.to(DEV), B.to(DEV))
         assert (la, lb) == (want, want)
-        Kp, Np, rp = 128, 128, 32
+        Kp, Np, rp = 128, 256, 32
         a3 = a_t.cpu().float().reshape(3, rp, Kp)
         b3 = b_t.cpu().float().reshape(3, Np, rp)
         assert torch.equal(a3.sum(0)[:r, :K].t().double(), A.double()) or torch.equal((a3[0].double() + a3[1].double() + a3[2].double())[:r, :K].t(), A.double())

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""A/B timing of lqer_linear_gemm across several builds of the library in ONE process, interleaved
+rounds (cdna_hip_programming.md rule 24).  Usage on the GPU box:
+    python tools/ab_gemm.py [--M 2048 --K 4096 --N 4096 --r 32] lib_a.so lib_b.so ...
+Operands are random (random 4-bit codes, gaussian bf16 activations); results are not checked here."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lqer_amd import _lib  # noqa: E402
+
+
+def load(path):
+    L = C.CDLL(os.path.abspath(path))
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--M", type=int, default=2048)
+    ap.add_argument("--K", type=int, default=4096)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--r", type=int, default=32)
+    ap.add_argument("--rounds", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--bout", type=int, default=1, help="1: B_out MXINT8/16, 0: passthrough")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    M, K, N, r = a.M, a.K, a.N, a.r
+    Kp, Np, Mp, rp = (K + 63) // 64 * 64, (N + 255) // 256 * 256, (M + 255) // 256 * 256, (r + 15) // 16 * 16
+    g = torch.Generator(device="cpu").manual_seed(0)
+    xq = torch.randn(Mp, Kp, generator=g).to(torch.bfloat16).to(dev)
+    wp = torch.randint(0, 256, ((Np // 16) * (Kp // 64) * 576,), generator=g, dtype=torch.uint8)
+    wv = wp.view(-1, 576)
+    wv[:, 512:] = torch.randint(0, 3, (wv.shape[0], 64), generator=g, dtype=torch.uint8) + 250  # exponents -6..-4
+    wp = wp.to(dev)
+    xaq = (0.1 * torch.randn(Mp, max(rp, 16), generator=g)).to(torch.bfloat16).to(dev)
+    bt = (0.1 * torch.randn(3 * Np * max(rp, 16), generator=g)).to(torch.bfloat16).to(dev)
+    y = torch.empty(M, N, dtype=torch.float16, device=dev)
+    f8 = _lib.QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
+    f4 = _lib.QFmt(_lib.Q_MXINT, 4, 16, 8, 127)
+    fb = f8 if a.bout else _lib.QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+    desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, fb)
+    libs = [(p, load(p)) for p in a.libs]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(L):
+        rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr() if r else None,
+                                bt.data_ptr() if r else None, 1, None, y.data_ptr(), _lib.F16, N, st)
+        assert rc == 0, L.lqer_last_error()
+
+    times = {p: [] for p, _ in libs}
+    for p, L in libs:
+        for _ in range(5):
+            run(L)
+    torch.cuda.synchronize()
+    for _ in range(a.rounds):
+        for p, L in libs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run(L)
+            e1.record()
+            torch.cuda.synchronize()
+            times[p].append(e0.elapsed_time(e1) / a.iters * 1e3)
+    fl = 2.0 * M * K * N + 2.0 * M * r * N
+    for p, _ in libs:
+        t = sorted(times[p])
+        med, mn = t[len(t) // 2], t[0]
+        print(f"{os.path.basename(p):40s} median {med:8.2f} us  min {mn:8.2f} us   {fl / med / 1e6:8.1f} TFLOP/s (median)")
+
+
+if __name__ == "__main__":
+    main()
