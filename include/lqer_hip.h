@@ -121,10 +121,11 @@ int lqer_quantize_act_mxint(const void* x, int dtype, int64_t M, int64_t K, int6
 int lqer_linear_sizes(const lqer_linear_desc_t* desc, int64_t m_max, lqer_linear_sizes_t* out);
 
 /* W [N,K] (row stride ldw) -> packed panels: w_quantizer(W) as 4-bit sign-magnitude mantissas
- * (bit 3 = sign) + int8 block exponents.  Panel (n/16, k/64) = 16 rows x 32 B codes followed by
- * 16 x 4 exponents (one per 16 k; a coarser block repeats its exponent).  Within each 32-bit
- * word of codes (8 consecutive k) nibble p holds k = p/2 (p even) or 4 + p/2 (p odd).
- * |w| <= 1e-8 is flushed to code 0.  `scratch` needs N*ceil(K/16) bytes.                      */
+ * (bit 3 = sign) + block exponents.  Panel (n/16, k/64) = 16 rows x 32 B codes followed by
+ * 16 x 4 exponent bytes (one per 16 k; a coarser block repeats its exponent), stored biased:
+ * byte = clamp(e - (width-1) + 127, 1, 254).  Within each 32-bit word of codes (8 consecutive k)
+ * nibble p holds k = p/2 (p even) or 4 + p/2 (p odd); a row's 8 words are stored in the order
+ * {0,2,4,6,1,3,5,7}.  |w| <= 1e-8 is flushed to code 0.  `scratch` needs N*ceil(K/16) bytes.   */
 int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64_t ldw,
                            const lqer_qfmt_t* fmt, void* w_packed, void* scratch, void* stream);
 

@@ -17,11 +17,12 @@
 //  * prologue: the rank-r product xAq @ B runs on the MFMA straight from global memory, is
 //    re-quantized in registers, the bias is added, and the result is the INITIAL accumulator of the
 //    main loop - there is no epilogue pass over the tile.
-//  * main loop, BK = 64, one barrier per k-step, every global access a global_load_lds (16 B/lane)
-//    so that loads stay in flight across barriers behind a COUNTED s_waitcnt vmcnt:
-//      - activation tile: 3-slot LDS ring, loaded two k-steps ahead (XOR swizzle on the source address)
-//      - packed weight panel (4-bit codes + block exponents, 576 B per wave): 3-slot ring, three steps
-//        ahead; one step ahead of its use the owning wave expands it to bf16 (VALU) into a 2-slot tile.
+//  * main loop, BK = 64: every global access is an LDS-DMA (buffer_load ... lds, 16 B/lane) into a
+//    4-slot ring, three k-steps ahead, retired with a COUNTED s_waitcnt vmcnt so that loads stay in
+//    flight across barriers.  The activation tile is staged as bf16 (XOR swizzle on the source
+//    address); the weights stay PACKED in LDS (4-bit codes + block exponents, 0.56 B per weight) and
+//    each wave expands the fragments it needs in registers, in the shadow of its MFMAs.
+//  * the two waves of a SIMD run half a k-step apart (LOAD / COMPUTE ping-pong, see the main loop).
 //  * tiles are numbered so that each of the 8 XCDs works on a contiguous run of tiles (same token
 //    rows -> the activation slab stays in that XCD's L2).
 #include "common.h"
@@ -29,13 +30,13 @@
 namespace lqer {
 
 constexpr int BM = 128, BN = 256, BK = 64;
-constexpr int A_SLOT = BM * BK * 2;                   // 16 KiB
-constexpr int W_SLOT = BN * BK * 2;                   // 32 KiB (expanded bf16)
-constexpr int R_SLOT = (BN / 16) * LQER_PANEL_BYTES;  // 9216 B (raw panels)
+constexpr int DEPTH = 3;                              // k-steps of prefetch in flight
+constexpr int NSLOT = DEPTH + 1;                      // LDS ring slots
+constexpr int A_SLOT = BM * BK * 2;                   // 16 KiB  activation tile, bf16
+constexpr int R_SLOT = (BN / 16) * LQER_PANEL_BYTES;  // 9216 B  packed weight panels (4-bit codes + exponents)
 constexpr int OFF_A = 0;
-constexpr int OFF_W = 3 * A_SLOT;
-constexpr int OFF_R = OFF_W + 2 * W_SLOT;
-constexpr int GEMM_LDS = OFF_R + 3 * R_SLOT;  // 142336 B
+constexpr int OFF_R = NSLOT * A_SLOT;
+constexpr int GEMM_LDS = OFF_R + NSLOT * R_SLOT;  // 102400 B
 
 // byte offset of 16-byte chunk `c` (8 bf16 along k) of tile row `r`; rows are 128 B.
 // chunk ^ ((row >> 1) & 7): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots.
@@ -44,29 +45,28 @@ __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >>
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-// Expand 16 sign-magnitude 4-bit codes (lo = k 0..7, hi = k 8..15; nibble order see pack.hip) times
-// 2^(e - mbits) to bf16: magnitude -> fp8 (e4m3) byte through a v_perm_b32 table, sign bit OR-ed in,
-// then v_cvt_scalef32_pk_bf16_fp8 converts two elements per instruction and applies the block scale.
-// ~1.5 VALU ops per weight; every step is exact (integers 0..7 and powers of two).
+// Expand 8 sign-magnitude 4-bit codes (one 32-bit word = 8 consecutive k of one weight row; nibble p
+// holds k = p/2 for even p, 4 + p/2 for odd p) times the block scale into one MFMA operand fragment:
+// magnitude -> fp8 (e4m3) byte through a v_perm_b32 table, sign bit OR-ed in, then
+// v_cvt_scalef32_pk_bf16_fp8 converts two elements per instruction and applies the scale.
+// 14 VALU ops per 8 weights; every step is exact (integers 0..7 and powers of two).
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ void expand16(uint32_t lo, uint32_t hi, int e, int mbits, uint32_t (&w)[8]) {
-  int ef = e - mbits + 127;
-  ef = ef < 1 ? 1 : ef;  // codes of such a block are all zero (|w| <= 1e-8 is flushed)
-  const float scale = __uint_as_float((uint32_t)ef << 23);
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+__device__ __forceinline__ bf16x8 expand_frag(uint32_t word, uint32_t scale_bits) {
+  const float scale = __uint_as_float(scale_bits);
   constexpr uint32_t LUT_LO = 0x44403800u, LUT_HI = 0x4E4C4A48u;  // e4m3 bytes of 0,1,2,3 | 4,5,6,7
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const uint32_t word = h ? hi : lo;
-    const uint32_t me = word & 0x07070707u, mo = (word >> 4) & 0x07070707u;   // k 0..3 | k 4..7
-    uint32_t fe = __builtin_amdgcn_perm(LUT_HI, LUT_LO, me);
-    uint32_t fo = __builtin_amdgcn_perm(LUT_HI, LUT_LO, mo);
-    fe |= (word << 4) & 0x80808080u;
-    fo |= word & 0x80808080u;
-    w[4 * h + 0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, false));
-    w[4 * h + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, true));
-    w[4 * h + 2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, false));
-    w[4 * h + 3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, true));
-  }
+  const uint32_t t = word >> 4;
+  uint32_t fe = __builtin_amdgcn_perm(LUT_HI, LUT_LO, word & 0x07070707u);  // k 0..3
+  uint32_t fo = __builtin_amdgcn_perm(LUT_HI, LUT_LO, t & 0x07070707u);     // k 4..7
+  fe |= (word << 4) & 0x80808080u;
+  fo |= word & 0x80808080u;
+  u32x4 r;
+  r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, false));
+  r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, true));
+  r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, false));
+  r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, true));
+  return __builtin_bit_cast(bf16x8, r);
 }
 
 // max over lanes l and l^32
@@ -82,13 +82,20 @@ __device__ __forceinline__ float pair32_max(float v) {
 // k-step.  Inside the main loop all LDS reads/writes are therefore asm statements the pass cannot
 // see; completion is waited for explicitly (cdna_hip_programming.md §5.7 form (ii): the wait
 // statement names every destination register "+v", so no consumer can be scheduled above it).
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read128(uint32_t addr) {
   bf16x8 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+__device__ __forceinline__ u32x4 lds_read128u(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_read32_512(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(v) : "v"(addr));
   return v;
 }
 __device__ __forceinline__ u32x2 lds_read64(uint32_t addr) {
@@ -159,72 +166,48 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_voff[i] = (row * g.Kp + chunk * 8) * 2;
   }
-  auto issue_a = [&](int kt, int slot) {
-#ifdef LQER_ABL_NO_A_LOAD
-    return;
-#endif
+  // weights: wave w stages panels 2w, 2w+1 of the tile (a panel = 16 rows x 64 k = 576 B = lanes 0..35 x 16 B)
+  const uint8_t* w_base = g.wp + ((int64_t)(n0 / 16 + 2 * wave) * nk) * LQER_PANEL_BYTES;
+  const auto w_rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(w_base + (int64_t)nk * LQER_PANEL_BYTES), 0, 0x7fffffff, 0x00020000);
+  const int w_voff = (lane < 36 ? lane : 35) * 16;
+  auto issue_loads = [&](int kt, int slot) {  // 4 LDS-DMA instructions per wave
+#ifndef LQER_ABL_NO_A_LOAD
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       unsigned char* dst = smem + OFF_A + slot * A_SLOT + (wave * 16 + i * 8) * 128;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)dst, 16, a_voff[i], kt * (BK * 2), 0, 0);
     }
-  };
-  // weights: wave w owns panels 2w, 2w+1 of the tile (rows [32w, 32w+32); a panel = 16 rows x 64 k =
-  // 576 B = lanes 0..35 x 16 B): it fetches them, expands them to bf16 and publishes them for all waves.
-  const uint8_t* w_base = g.wp + ((int64_t)(n0 / 16 + 2 * wave) * nk) * LQER_PANEL_BYTES;
-  const auto w_rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
-  const auto w_rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(w_base + (int64_t)nk * LQER_PANEL_BYTES), 0, 0x7fffffff, 0x00020000);
-  const int w_voff = (lane < 36 ? lane : 35) * 16;
-  auto issue_w = [&](int kt, int slot) {
-#ifdef LQER_ABL_NO_W_LOAD
-    return;
 #endif
+#ifndef LQER_ABL_NO_W_LOAD
     unsigned char* dst = smem + OFF_R + slot * R_SLOT + 2 * wave * LQER_PANEL_BYTES;
     if (lane < 36) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc0, (lds_void*)dst, 16, w_voff, kt * LQER_PANEL_BYTES, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc1, (lds_void*)(dst + LQER_PANEL_BYTES), 16, w_voff, kt * LQER_PANEL_BYTES, 0, 0);
     }
-  };
-  // raw panel j of this wave in ring slot rs: lane -> 16 codes (8 B) + the exponent of their 16-k block
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  const uint32_t raw_addr = lds0 + OFF_R + 2 * wave * LQER_PANEL_BYTES + lane * 8;  // + j * 576 + rs * R_SLOT
-  const uint32_t rawe_addr = lds0 + OFF_R + 2 * wave * LQER_PANEL_BYTES + lane;     // + 512 + ...
-  // expanded tile rows [32w + 16j, +16): lane -> (row = lane / 4, 16-k segment = lane % 4) = chunks 2seg, 2seg+1
-  uint32_t wexp_addr[2][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    wexp_addr[j][0] = lds0 + OFF_W + swz(wave * 32 + j * 16 + (lane >> 2), 2 * (lane & 3));  // + ws * W_SLOT
-    wexp_addr[j][1] = lds0 + OFF_W + swz(wave * 32 + j * 16 + (lane >> 2), 2 * (lane & 3) + 1);
-  }
-  auto expand_regs = [&](u32x2 codes, int e, u32x4& lo, u32x4& hi) {
-    uint32_t w[8];
-#ifdef LQER_ABL_NO_EXPAND
-    for (int i = 0; i < 8; ++i) w[i] = codes[i & 1] + i + e;
-#else
-    expand16(codes[0], codes[1], e, g.w_mbits, w);
 #endif
-    lo = (u32x4){w[0], w[1], w[2], w[3]};
-    hi = (u32x4){w[4], w[5], w[6], w[7]};
   };
-  auto store_expanded = [&](const u32x4& lo, const u32x4& hi, int j, int ws) {
-    lds_write128(wexp_addr[j][0] + ws * W_SLOT, lo);
-    lds_write128(wexp_addr[j][1] + ws * W_SLOT, hi);
-  };
-  // fragment read addresses (slot 0): row = wave tile row + lane & 31; chunk 2 ks + (lane >> 5), swizzled
-  uint32_t fa_addr[4], fw_addr[4];
+  // fragment read addresses (slot 0).  Activation: row = wave tile row + lane & 31, chunk 2 ks + (lane >> 5),
+  // swizzled; the second m tile is +32 rows = +4096 B (row + 32 keeps (row >> 1) & 7).
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+  uint32_t fa_addr[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    fa_addr[ks] = lds0 + OFF_A + swz(wm * 64 + l31, 2 * ks + lh);  // second m tile: +32 rows = +4096 B
-    fw_addr[ks] = lds0 + OFF_W + swz(wn * 64 + l31, 2 * ks + lh);  // (row + 32 keeps (row >> 1) & 7)
+  for (int ks = 0; ks < 4; ++ks) fa_addr[ks] = lds0 + OFF_A + swz(wm * 64 + l31, 2 * ks + lh);
+  // Packed weights: weight row n = wave tile column + lane & 31 lives in panel n / 16 at row n % 16; its
+  // 32 B of codes hold the words of chunks {0,2,4,6} then {1,3,5,7}, so the lane's 4 words (chunk
+  // 2 ks + (lane >> 5), ks = 0..3) are one 16-byte read; its 4 biased block exponents are one 4-byte read.
+  uint32_t fw_addr[2], fe_addr[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = wn * 64 + i * 32 + l31;
+    fw_addr[i] = lds0 + OFF_R + (n >> 4) * LQER_PANEL_BYTES + (n & 15) * 32 + lh * 16;
+    fe_addr[i] = lds0 + OFF_R + (n >> 4) * LQER_PANEL_BYTES + (n & 15) * 4;  // + 512
   }
 
-  // prologue loads: A(0), A(1) and raw W(0..2), every wave its own rows / panel
-  const bool late = wave >= 4;  // waves 4-7 run one barrier behind waves 0-3 (see main loop)
-  issue_a(0, 0);
-  if (nk > 1) issue_a(1, 1);
-  issue_w(0, 0);
-  if (nk > 1) issue_w(1, 1);
-  if (nk > 2) issue_w(2, 2);
+  // prologue loads: steps 0 .. DEPTH-1
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < nk) issue_loads(d, d);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -285,124 +268,118 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       }
   }
 
-  // W(0) -> expanded slot 0 (own panels: only this wave's vmcnt matters), publish; W(1) expanded into
-  // registers for the first LOAD section
-  u32x4 wx[2][2] = {{{0, 0, 0, 0}, {0, 0, 0, 0}}, {{0, 0, 0, 0}, {0, 0, 0, 0}}};
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    u32x2 c0 = lds_read64(raw_addr + j * LQER_PANEL_BYTES), c1 = lds_read64(raw_addr + j * LQER_PANEL_BYTES + R_SLOT);
-    int e0 = lds_read_i8_512(rawe_addr + j * LQER_PANEL_BYTES), e1 = lds_read_i8_512(rawe_addr + j * LQER_PANEL_BYTES + R_SLOT);
-    lds_wait(c0, e0);
-    lds_wait(c1, e1);
-    expand_regs(c0, e0, wx[j][0], wx[j][1]);
-    store_expanded(wx[j][0], wx[j][1], j, 0);
-    if (nk > 1) expand_regs(c1, e1, wx[j][0], wx[j][1]);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
   // ---- main loop ------------------------------------------------------------------------------
-  // Ping-pong: the two waves that share a SIMD (w and w+4) run one barrier apart.  A k-step is a LOAD
-  // section and a COMPUTE section, each closed by a barrier; while waves 0-3 compute, waves 4-7 load,
-  // and vice versa, so the matrix pipe always has a wave feeding it.
+  // Ping-pong: the two waves that share a SIMD (w and w+4) run one barrier apart.  A k-step is
+  //   LOAD(kt):    read this wave's operands of step kt from ring slot kt % 4 into registers (8 x 16 B of
+  //                activation fragments, 2 x 16 B of weight codes, 2 x 4 B of block exponents), issue the
+  //                loads of step kt+3 into slot (kt+3) % 4, wait, barrier;
+  //   COMPUTE(kt): per 16-deep k slice expand two weight fragments (VALU) and issue 4 MFMAs; barrier.
+  // While waves 0-3 compute, waves 4-7 load, and vice versa:
   //   barrier index      2kt-1        2kt          2kt+1         2kt+2
   //   waves 0-3:    ... | LOAD(kt)  | COMPUTE(kt) | LOAD(kt+1)  | ...
   //   waves 4-7:    ... | COMP(kt-1)| LOAD(kt)    | COMPUTE(kt) | ...
-  // LOAD(kt):    write the expanded panel W(kt+1) held in registers (4 ds_write_b128, first, so that their
-  //              latency hides under what follows), read the 16 operand fragments of step kt, issue the
-  //              prefetch A(kt+2) x2 + raw W(kt+3) x2, wait: LDS done, all but these 4 loads done; barrier.
-  // COMPUTE(kt): read the raw panel W(kt+2), 16 MFMAs, the expand of W(kt+2) (12 VALU + 8 converts) in
-  //              their shadow, result kept in 8 registers for LOAD(kt+1); barrier.
-  // Hazards: the slot of expanded W(kt+1) was last read in LOAD(kt-1) (both groups are past it: two
-  // barriers earlier for the other group) and is first read in LOAD(kt+1), after barrier 2kt+1 which
-  // every writer reaches with lgkmcnt(0).  A(kt+2) / raw W(kt+3) go to the ring slots of A(kt-1) /
-  // W(kt), last read by this wave's own group in LOAD(kt-1) / by this wave in COMPUTE(kt-2).  The counted
-  // vmcnt at the end of LOAD(kt) retires what LOAD(kt-1) issued: A(kt+1) for LOAD(kt+1) (activation rows
-  // never cross the two groups, and the group passes a barrier first) and raw W(kt+2) for COMPUTE(kt).
+  // RAW: every wave ends LOAD(kt-1) with a counted vmcnt that retires its own loads of step kt (the
+  // DEPTH-1 younger batches of 4 stay in flight) and then passes a barrier (2kt-2 or 2kt-1) before
+  // anyone starts LOAD(kt).  WAR: slot (kt+3) % 4 held step kt-1, last read in LOAD(kt-1) of waves 4-7,
+  // which ends (lgkmcnt(0)) before barrier 2kt-1; the overwriting loads are issued after it.
+  const bool late = wave >= 4;
+  {
+    const int issued = nk < DEPTH ? nk : DEPTH;
+    if (issued >= 3)
+      asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if (issued == 2)
+      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
   if (late) asm volatile("s_barrier" ::: "memory");
-  int sa = 0, sr = 2, sw = 0;  // A(kt) in ring slot sa, raw W(kt+2) in slot sr, expanded W(kt) in slot sw
+  int slot = 0;
 #ifdef LQER_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-  for (int kt = 0; kt < nk; ++kt) {
-    const int sa2 = sa == 0 ? 2 : sa - 1;  // (sa + 2) % 3: slot of A(kt+2)
-    const int sr1 = sr == 2 ? 0 : sr + 1;  // slot of raw W(kt+3)
-    const bool full = kt + 3 < nk;
-    const uint32_t oa = sa * A_SLOT, ow = sw * W_SLOT;
+  // One k-step.  The operand registers are passed in: consecutive steps use two different register sets,
+  // because the last MFMAs of COMPUTE(kt) may still be queued (and read their sources late) when the LDS
+  // reads of LOAD(kt+1) return - a read landing in a register an in-flight MFMA has not consumed yet
+  // corrupts one 16-lane group of that operand (seen as run-to-run differences before this was fixed).
+  auto step = [&](int kt, bf16x8(&xa)[4][2], u32x4(&wr)[2], uint32_t(&we)[2]) {
+    const uint32_t oa = slot * A_SLOT, orw = slot * R_SLOT;
+    const int slot_new = slot == 0 ? NSLOT - 1 : slot - 1;  // (slot + DEPTH) % NSLOT
     STAMP(7);
-    // ---- LOAD(kt)
-#ifndef LQER_ABL_DMA_ONLY
-    if (kt + 1 < nk) {
-      store_expanded(wx[0][0], wx[0][1], 0, sw ^ 1);
-      store_expanded(wx[1][0], wx[1][1], 1, sw ^ 1);
-    }
-#endif
-    bf16x8 xa[4][2], wb[4][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    // ---- LOAD(kt): prefetch issue, then ONE asm statement with the 12 LDS reads, the waits and the barrier.
+    // (Reads and their wait must not be separate statements: hipcc treats an asm output as valid when the
+    // statement ends and was seen to copy such registers to others BEFORE the separate wait - stale data.)
+    if (kt + DEPTH < nk) issue_loads(kt + DEPTH, slot_new);
 #ifdef LQER_ABL_DMA_ONLY
-      xa[ks][0] = xa[ks][1] = wb[ks][0] = wb[ks][1] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+    for (int ks = 0; ks < 4; ++ks) xa[ks][0] = xa[ks][1] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+    wr[0] = wr[1] = (u32x4){1, 2, 3, 4};
+    we[0] = we[1] = 0x7c7c7c7cu;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-      xa[ks][0] = lds_read128<0>(fa_addr[ks] + oa), xa[ks][1] = lds_read128<4096>(fa_addr[ks] + oa);
-      wb[ks][0] = lds_read128<0>(fw_addr[ks] + ow), wb[ks][1] = lds_read128<4096>(fw_addr[ks] + ow);
-#endif
+    {
+      const uint32_t aw0 = fw_addr[0] + orw, aw1 = fw_addr[1] + orw, ae0 = fe_addr[0] + orw, ae1 = fe_addr[1] + orw;
+      const uint32_t aa0 = fa_addr[0] + oa, aa1 = fa_addr[1] + oa, aa2 = fa_addr[2] + oa, aa3 = fa_addr[3] + oa;
+      const int younger = nk - 2 - kt;  // batches issued for steps beyond kt+1: they may stay in flight
+#define LQER_LOAD_ASM(VM)                                                                                    \
+  asm volatile(                                                                                              \
+      "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b32 %2, %14 offset:512\n\t"                    \
+      "ds_read_b32 %3, %15 offset:512\n\t"                                                                    \
+      "ds_read_b128 %4, %16\n\tds_read_b128 %5, %16 offset:4096\n\t"                                          \
+      "ds_read_b128 %6, %17\n\tds_read_b128 %7, %17 offset:4096\n\t"                                          \
+      "ds_read_b128 %8, %18\n\tds_read_b128 %9, %18 offset:4096\n\t"                                          \
+      "ds_read_b128 %10, %19\n\tds_read_b128 %11, %19 offset:4096\n\t"                                        \
+      "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                                      \
+      : "=&v"(wr[0]), "=&v"(wr[1]), "=&v"(we[0]), "=&v"(we[1]), "=&v"(xa[0][0]), "=&v"(xa[0][1]),            \
+        "=&v"(xa[1][0]), "=&v"(xa[1][1]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[3][0]), "=&v"(xa[3][1])  \
+      : "v"(aw0), "v"(aw1), "v"(ae0), "v"(ae1), "v"(aa0), "v"(aa1), "v"(aa2), "v"(aa3)                       \
+      : "memory")
+      if (younger >= 2)
+        LQER_LOAD_ASM(8);
+      else if (younger == 1)
+        LQER_LOAD_ASM(4);
+      else
+        LQER_LOAD_ASM(0);
+#undef LQER_LOAD_ASM
     }
-    if (kt + 2 < nk) issue_a(kt + 2, sa2);
-    if (full) issue_w(kt + 3, sr1);
-#define LQER_FRAGS                                                                                          \
-  "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1]), "+v"(xa[2][0]), "+v"(xa[2][1]), "+v"(xa[3][0]), \
-      "+v"(xa[3][1]), "+v"(wb[0][0]), "+v"(wb[0][1]), "+v"(wb[1][0]), "+v"(wb[1][1]), "+v"(wb[2][0]), "+v"(wb[2][1]), \
-      "+v"(wb[3][0]), "+v"(wb[3][1])
-    STAMP(0);  // LOAD section issue (stamped builds also wait for the LDS traffic here)
-    if (full)
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" : LQER_FRAGS::"memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : LQER_FRAGS::"memory");
-#undef LQER_FRAGS
+#endif
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4);  // waits + barrier after LOAD
     // ---- COMPUTE(kt)
-    u32x2 wc0, wc1;
-    int we0, we1;
-#ifdef LQER_ABL_DMA_ONLY
-    const bool do_expand = false;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // biased exponent byte ks -> fp32 bits of the block scale 2^(e - mbits)
+      const uint32_t s0 = ks < 3 ? (we[0] << (23 - 8 * ks)) & 0x7f800000u : (we[0] >> 1) & 0x7f800000u;
+      const uint32_t s1 = ks < 3 ? (we[1] << (23 - 8 * ks)) & 0x7f800000u : (we[1] >> 1) & 0x7f800000u;
+#ifdef LQER_ABL_NO_EXPAND
+      const bf16x8 wb0 = __builtin_bit_cast(bf16x8, wr[0] + s0), wb1 = __builtin_bit_cast(bf16x8, wr[1] + s1);
 #else
-    const bool do_expand = kt + 2 < nk;
+      const bf16x8 wb0 = expand_frag(wr[0][ks], s0), wb1 = expand_frag(wr[1][ks], s1);
 #endif
-    if (do_expand) {
-      wc0 = lds_read64(raw_addr + sr * R_SLOT), wc1 = lds_read64(raw_addr + LQER_PANEL_BYTES + sr * R_SLOT);
-      we0 = lds_read_i8_512(rawe_addr + sr * R_SLOT), we1 = lds_read_i8_512(rawe_addr + LQER_PANEL_BYTES + sr * R_SLOT);
-    }
 #if defined(LQER_ABL_NO_MFMA) || defined(LQER_ABL_DMA_ONLY)
-#define LQER_MFMA4(ks) asm volatile("" ::"v"(wb[ks][0]), "v"(wb[ks][1]), "v"(xa[ks][0]), "v"(xa[ks][1]))
+      asm volatile("" ::"v"(wb0), "v"(wb1), "v"(xa[ks][0]), "v"(xa[ks][1]));
 #else
-#define LQER_MFMA4(ks)                                                                                   \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks][0], xa[ks][0], acc[0][0], 0, 0, 0);        \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks][1], xa[ks][0], acc[0][1], 0, 0, 0);        \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks][0], xa[ks][1], acc[1][0], 0, 0, 0);        \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks][1], xa[ks][1], acc[1][1], 0, 0, 0)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb0, xa[ks][0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, xa[ks][0], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb0, xa[ks][1], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, xa[ks][1], acc[1][1], 0, 0, 0);
 #endif
-    LQER_MFMA4(0);
-    if (do_expand) {
-      lds_wait(wc0, we0);
-      lds_wait(wc1, we1);
-      expand_regs(wc0, we0, wx[0][0], wx[0][1]);
     }
-    LQER_MFMA4(1);
-    LQER_MFMA4(2);
-    if (do_expand) expand_regs(wc1, we1, wx[1][0], wx[1][1]);
-    LQER_MFMA4(3);
-#undef LQER_MFMA4
     __builtin_amdgcn_sched_barrier(0);
     STAMP(5);  // COMPUTE section issue
-    asm volatile("s_barrier" : "+v"(wx[0][0]), "+v"(wx[0][1]), "+v"(wx[1][0]), "+v"(wx[1][1])::"memory");
+    asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     STAMP(6);  // barrier after COMPUTE
-    sa = sa == 2 ? 0 : sa + 1;
-    sr = sr == 2 ? 0 : sr + 1;
-    sw ^= 1;
+    slot = slot == NSLOT - 1 ? 0 : slot + 1;
+  };
+  bf16x8 xa0[4][2], xa1[4][2];
+  u32x4 wr0[2], wr1[2];
+  uint32_t we0[2], we1[2];
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    step(kt, xa0, wr0, we0);
+    step(kt + 1, xa1, wr1, we1);
   }
+  if (kt < nk) step(kt, xa0, wr0, we0);
   if (!late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_STAMPS
   if (g_stamp_buf && lane == 0)

@@ -7,6 +7,9 @@
 //                              [16 rows][4]     int8 exponent of each 16-k segment
 // Within each 32-bit word (8 consecutive k) nibble p holds k = p/2 for even p and 4 + p/2 for odd p,
 // so that the GEMM kernel's byte-wise expand (even nibbles, then odd nibbles) emits k in order.
+// A row's 8 words (64 k) are stored as words {0,2,4,6} then {1,3,5,7}: the MFMA lane that needs the
+// words of chunks 2 ks + h (ks = 0..3) reads them with one 16-byte LDS access.  Exponents are stored
+// biased, ready to be shifted into an fp32 exponent field: byte = clamp(e - mbits + 127, 1, 254).
 // A coarser weight block (32, 128, whole row) repeats its exponent per segment, so the GEMM kernel
 // handles every block length with one code path.
 #include "common.h"
@@ -57,8 +60,11 @@ __global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int6
       }
     }
     uint8_t* panel = out + ((row / 16) * (Kp / 64) + seg / 4) * LQER_PANEL_BYTES;
-    *(uint2*)(panel + (row % 16) * 32 + (seg % 4) * 8) = make_uint2(lo, hi);
-    panel[512 + (row % 16) * 4 + (seg % 4)] = (uint8_t)(int8_t)e;
+    *(uint32_t*)(panel + (row % 16) * 32 + (seg % 4) * 4) = lo;        // chunk 2 * (seg % 4)
+    *(uint32_t*)(panel + (row % 16) * 32 + 16 + (seg % 4) * 4) = hi;   // chunk 2 * (seg % 4) + 1
+    int eb = e - q.mbits + 127;
+    eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+    panel[512 + (row % 16) * 4 + (seg % 4)] = (uint8_t)eb;
   }
 }
 
@@ -69,8 +75,10 @@ __global__ __launch_bounds__(256) void k_w_unpack(const uint8_t* __restrict__ in
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t row = idx / segs, seg = idx - row * segs, k0 = seg * 16;
     const uint8_t* panel = in + ((row / 16) * (Kp / 64) + seg / 4) * LQER_PANEL_BYTES;
-    const uint2 c = *(const uint2*)(panel + (row % 16) * 32 + (seg % 4) * 8);
-    const int e = (int8_t)panel[512 + (row % 16) * 4 + (seg % 4)];
+    uint2 c;
+    c.x = *(const uint32_t*)(panel + (row % 16) * 32 + (seg % 4) * 4);
+    c.y = *(const uint32_t*)(panel + (row % 16) * 32 + 16 + (seg % 4) * 4);
+    const int e = (int)panel[512 + (row % 16) * 4 + (seg % 4)] - 127 + mbits;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const uint32_t word = i < 8 ? c.x : c.y;

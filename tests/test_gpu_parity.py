@@ -89,10 +89,13 @@ def _panels_from_rowmajor(codes, exps, L, Kp, K):
     Segments that lie entirely in the K padding carry exponent 0."""
     Np = codes.shape[0]
     e16 = exps.repeat_interleave(max(L // 16, 1), dim=1)[:, : Kp // 16] if L < Kp else exps[:, :1].expand(Np, Kp // 16)
-    e16 = e16.clone()
+    e16 = e16.clone().to(torch.int32)
     e16[:, -(-K // 16):] = 0
-    c = codes.reshape(Np // 16, 16, Kp // 64, 32).permute(0, 2, 1, 3)  # [pn, pk, 16, 32]
-    e = e16.reshape(Np // 16, 16, Kp // 64, 4).permute(0, 2, 1, 3).contiguous().view(torch.uint8)
+    e16 = (e16 - 3 + 127).clamp(1, 254).to(torch.uint8)  # stored biased for mbits = 3
+    # a row's 8 words (4 B = 8 k each) of a 64-k group are stored in the order {0,2,4,6,1,3,5,7}
+    words = codes.reshape(Np, Kp // 64, 8, 4)[:, :, [0, 2, 4, 6, 1, 3, 5, 7], :].reshape(Np, Kp // 2)
+    c = words.reshape(Np // 16, 16, Kp // 64, 32).permute(0, 2, 1, 3)  # [pn, pk, 16, 32]
+    e = e16.reshape(Np // 16, 16, Kp // 64, 4).permute(0, 2, 1, 3).contiguous()
     return torch.cat([c.reshape(Np // 16, Kp // 64, 512), e.reshape(Np // 16, Kp // 64, 64)], dim=2).reshape(-1)
 
 
@@ -255,6 +258,24 @@ def test_size_independent_properties_full_size(ops):
     f = lqer_amd.LinearFlexible(K, N, bias=False, q_config=dict(MXINT_Q, name="flexible"), l_config=None)
     f.load_state_dict({"weight": W})
     assert torch.equal(z.to(DEV).half()(x), f.to(DEV).half()(x))
+
+
+def test_run_to_run_bit_stability(ops):
+    """Race screen: the kernel keeps loads in flight across barriers and hand-counts its waits, so the
+    same launch must give the same bits every time (a too-early LDS read shows up as rare differences).
+    Several shapes, 20 launches each, every output element compared."""
+    import lqer_amd
+    from bench import make_case, MXINT_Q
+
+    for (M, K, N, r) in ((2048, 4096, 4096, 32), (300, 1024, 768, 32), (2048, 11008, 4096, 32)):
+        x, W, A, B = make_case(M, K, N, r, seed=3)
+        mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+        mod.load_state_dict({"weight": W, "A": A, "B": B})
+        mod = mod.to(DEV).half()
+        xd = x.half().to(DEV)
+        y0 = mod(xd).clone()
+        for _ in range(20):
+            assert torch.equal(mod(xd), y0), (M, K, N)
 
 
 def test_edge_shapes_and_errors(ops):
