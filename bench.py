@@ -85,7 +85,7 @@ def cpu_baseline(M, K, N, r, q_config, reps=3):
     one-time weight quantization (reference linear.py:149-153) is done before the clock starts."""
     from oracle import lqer_oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, int(os.environ.get("LQER_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     x, W, A, B = make_case(M, K, N, r, seed=0)
     x = x.half().float()
@@ -132,7 +132,7 @@ def main():
     import ctypes as C
 
     import lqer_amd
-    from lqer_amd import _lib, ops
+    from lqer_amd import _lib, ops, sweep
 
     desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS[args.workload]
     # this rank's units: one module per distinct projection shape (weights differ per rank by seed);
@@ -140,7 +140,7 @@ def main():
     layers_here = layers  # weak scaling: every rank runs a full unit list of its own
     mods = []
     for i, (K, N, cnt) in enumerate(shapes):
-        case = make_case(M, K, N, r, seed=1000 * rank + i, bias=has_bias)
+        case = make_case(M, K, N, r, seed=sweep.unit_seed(rank, i), bias=has_bias)
         x, W, A, B = case[:4]
         mod = lqer_amd.LinearFlexibleLqer(K, N, bias=has_bias, q_config=qc, l_config={"rank": r})
         sd = {"weight": W, "A": A, "B": B}
@@ -153,20 +153,11 @@ def main():
         mods.append((mod, xd, K, N, cnt * layers_here, y))
     torch.cuda.synchronize()
 
-    if args.check and rank == 0:
-        from oracle import lqer_oracle as O
-
-        mod, xd, K, N, _, y = mods[0]
-        case = make_case(M, K, N, r, seed=0, bias=has_bias)
-        ref = O.lqer_linear_forward(case[0].half().float(), case[1].half().float(), case[4].half().float() if has_bias else None,
-                                    case[2].half().float(), case[3].half().float(), qc)
-        err = float((y.float().cpu() - ref).norm() / ref.norm())
-        print(f"# parity vs CPU oracle: rel-L2 {err:.3e}", file=sys.stderr)
-        assert err <= 1e-3, err
-
     L = _lib.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
     gemm_events = []
+    launch_no = [0]
+    EV_EVERY = 5  # bracket every 5th launch of the dominant kernel with HIP events (each pair costs ~12 us of gaps)
 
     def step(timed: bool):
         for mod, xd, K, N, reps, y in mods:
@@ -182,12 +173,14 @@ def main():
                 # kernel can be bracketed with HIP events on the launch stream
                 _lib.check(L.lqer_quantize_act_mxint(xd.data_ptr(), _lib.F16, M, K, K, C.byref(desc.x_fmt), xq, stream), "quantize_act")
                 _lib.check(L.lqer_lowrank_xa(C.byref(desc), xq, M, p["a_t"].data_ptr(), p["a_limbs"], xaq, stream), "lowrank_xa")
-                if timed:
+                ev = timed and launch_no[0] % EV_EVERY == 0
+                launch_no[0] += 1
+                if ev:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 _lib.check(L.lqer_linear_gemm(C.byref(desc), xq, M, p["w"].data_ptr(), xaq, p["b_t"].data_ptr(), p["b_limbs"],
                                               ops._ptr(p.get("bias")), y.data_ptr(), _lib.F16, N, stream), "linear_gemm")
-                if timed:
+                if ev:
                     e1.record()
                     gemm_events.append((e0, e1, K, N))
 
@@ -205,16 +198,25 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sweep.max_over_ranks(elapsed, dev)
+    checksums = sweep.gather_checksums(float(mods[0][5].float().sum().item()), dev)
 
     flops_rank = sum(flops(M, K, N, r) * reps for _, _, K, N, reps, _ in mods)
     tokens_rank = M  # a model sweep pushes the same M tokens through every layer
     total_flops = flops_rank * world
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_flops * args.steps / elapsed / 1e12
+    value = sweep.aggregate_throughput(flops_rank, args.steps, world, elapsed)
+
+    if args.check and rank == 0:
+        from oracle import lqer_oracle as O
+
+        mod, xd, K, N, _, y = mods[0]
+        case = make_case(M, K, N, r, seed=0, bias=has_bias)
+        ref = O.lqer_linear_forward(case[0].half().float(), case[1].half().float(), case[4].half().float() if has_bias else None,
+                                    case[2].half().float(), case[3].half().float(), qc)
+        err = float((y.float().cpu() - ref).norm() / ref.norm())
+        print(f"# parity vs CPU oracle: rel-L2 {err:.3e}", file=sys.stderr)
+        assert err <= 1e-3, err
 
     if rank == 0:
         # dominant kernel = k_lqer_gemm; algorithmic FLOPs per launch = 2MKN + 2MrN
@@ -246,6 +248,7 @@ def main():
                        "sharding": "independent Linear units per rank, no data-path collective"},
             "tokens_per_s": round(tokens_rank * world * args.steps / elapsed, 1),
             "roofline": roofline,
+            "rank_checksums": [round(c, 3) for c in checksums],
         }
         if world == 1 and not args.no_cpu_baseline:
             K0, N0, _ = shapes[0]

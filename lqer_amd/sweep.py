@@ -1,0 +1,62 @@
+"""Host-side helpers for running the hot path over many independent Linear units on several GPUs.
+
+The path shards into independent units (every Linear forward on a given input is independent of every
+other - SURVEY.md §8e), so there is no collective on the data path: each rank owns a list of units,
+builds them from a seed and runs them; torch.distributed (RCCL on GPUs, gloo in the CPU tests) is
+used only for the timing barrier, the max-over-ranks of the elapsed time and a checksum gather.
+
+`layer_partition` is the reference's only multi-GPU rule - ceil(L / G) consecutive decoder layers per
+device (experiments/infer_device_map.py:29-37) - restated for a fixed model split over ranks.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+def layer_partition(n_layers: int, world: int) -> List[range]:
+    """Consecutive layers per rank: rank g gets [g*ceil(L/G), min(L, (g+1)*ceil(L/G)))."""
+    if n_layers < 0 or world <= 0:
+        raise ValueError("n_layers >= 0 and world > 0 required")
+    per = math.ceil(n_layers / world) if n_layers else 0
+    return [range(min(n_layers, g * per), min(n_layers, (g + 1) * per)) for g in range(world)]
+
+
+def projection_units(shapes: Sequence[Tuple[int, int, int]], layers: Sequence[int]) -> List[Tuple[int, int, int, int]]:
+    """(layer, K, N, copy) for every projection of the given layers; `shapes` = [(K, N, count per layer)]."""
+    return [(l, K, N, c) for l in layers for (K, N, cnt) in shapes for c in range(cnt)]
+
+
+def unit_seed(rank: int, unit_index: int) -> int:
+    """Seed of the synthetic weights of one unit: distinct per rank and unit, reproducible."""
+    return 1000 * rank + unit_index
+
+
+def max_over_ranks(seconds: float, device: torch.device) -> float:
+    """Whole-job elapsed time = max over ranks (all-reduce MAX; identity without a process group)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_checksums(value: float, device: torch.device) -> List[float]:
+    """One checksum per rank, gathered on every rank (outside any timed region)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def aggregate_throughput(flops_per_rank_step: float, steps: int, world: int, elapsed_max: float) -> float:
+    """Weak scaling: every rank does `flops_per_rank_step` per step; TFLOP/s of the whole job."""
+    return flops_per_rank_step * world * steps / elapsed_max / 1e12

@@ -1,0 +1,61 @@
+"""The N > 1 host logic on CPU: two gloo ranks exercise the timing reduction, the checksum gather and
+the aggregate computed from them; plus the reference's layer -> device partition rule."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lqer_amd import sweep
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        elapsed = sweep.max_over_ranks(1.0 + rank, dev)  # rank 1 is the slow one
+        sums = sweep.gather_checksums(10.0 * (rank + 1), dev)
+        dist.barrier()
+        q.put((rank, elapsed, sums, sweep.aggregate_throughput(2e12, 5, world, elapsed)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, elapsed, sums, agg in res:
+        assert elapsed == 2.0  # max over ranks
+        assert sums == [10.0, 20.0]
+        assert agg == pytest.approx(2e12 * 2 * 5 / 2.0 / 1e12)
+
+
+def test_single_process_is_identity():
+    assert sweep.max_over_ranks(0.25, torch.device("cpu")) == 0.25
+    assert sweep.gather_checksums(3.0, torch.device("cpu")) == [3.0]
+
+
+def test_layer_partition_matches_reference_rule():
+    # reference experiments/infer_device_map.py:29-37: ceil(L / G) consecutive layers per device
+    assert [list(r) for r in sweep.layer_partition(32, 8)] == [list(range(4 * g, 4 * g + 4)) for g in range(8)]
+    parts = sweep.layer_partition(40, 8)  # Llama-13B on 8 GPUs: 5 layers per rank
+    assert [len(r) for r in parts] == [5] * 8
+    parts = sweep.layer_partition(10, 4)  # ceil -> 3,3,3,1
+    assert [len(r) for r in parts] == [3, 3, 3, 1] and sum(len(r) for r in parts) == 10
+    assert [len(r) for r in sweep.layer_partition(2, 4)] == [1, 1, 0, 0]
+    with pytest.raises(ValueError):
+        sweep.layer_partition(4, 0)
+    units = sweep.projection_units([(4096, 4096, 4), (4096, 11008, 2), (11008, 4096, 1)], parts[0] if False else range(2))
+    assert len(units) == 14 and units[0] == (0, 4096, 4096, 0)
+    assert sweep.unit_seed(0, 1) != sweep.unit_seed(1, 1) != sweep.unit_seed(1, 0)
