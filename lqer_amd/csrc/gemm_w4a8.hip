@@ -4,8 +4,8 @@
 //
 // replaces reference quantized_layers/linear.py:155-156 (torch.matmul(xA, B), B_out_quantizer,
 // F.linear, add).  One workgroup = one 128(m) x 256(n) output tile (wide in n: a weight costs 0.56 B
-// of L2->LDS traffic per element, an activation 2 B), 8 waves as 2(m) x 4(n), each
-// wave 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 (bf16 holds every MXINT value
+// of L2->LDS traffic per element, an activation 2 B), 8 waves side by side along n, each
+// wave 128 x 32 = 4 x 1 tiles of v_mfma_f32_32x32x16_bf16 (bf16 holds every MXINT value
 // m * 2^e, |m| < 256, exactly; fp32 accumulation - SURVEY.md §7 H1 strategy S1).
 //
 // The MFMA is issued "transposed" (A operand = weight rows, B operand = token rows), so a lane owns
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wn = wave;  // 8 waves side by side along n: each owns all 128 token rows x 32 output columns
   const int l31 = lane & 31, lh = lane >> 5;
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous tile range.
@@ -192,80 +192,65 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
   uint32_t fa_addr[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) fa_addr[ks] = lds0 + OFF_A + swz(wm * 64 + l31, 2 * ks + lh);
+  for (int ks = 0; ks < 4; ++ks) fa_addr[ks] = lds0 + OFF_A + swz(l31, 2 * ks + lh);  // m tile i: + i * 4096
   // Packed weights: weight row n = wave tile column + lane & 31 lives in panel n / 16 at row n % 16; its
   // 32 B of codes hold the words of chunks {0,2,4,6} then {1,3,5,7}, so the lane's 4 words (chunk
   // 2 ks + (lane >> 5), ks = 0..3) are one 16-byte read; its 4 biased block exponents are one 4-byte read.
-  uint32_t fw_addr[2], fe_addr[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int n = wn * 64 + i * 32 + l31;
-    fw_addr[i] = lds0 + OFF_R + (n >> 4) * LQER_PANEL_BYTES + (n & 15) * 32 + lh * 16;
-    fe_addr[i] = lds0 + OFF_R + (n >> 4) * LQER_PANEL_BYTES + (n & 15) * 4;  // + 512
-  }
+  const int nw = wn * 32 + l31;
+  const uint32_t fw_addr = lds0 + OFF_R + (nw >> 4) * LQER_PANEL_BYTES + (nw & 15) * 32 + lh * 16;
+  const uint32_t fe_addr = lds0 + OFF_R + (nw >> 4) * LQER_PANEL_BYTES + (nw & 15) * 4;  // + 512
 
   // prologue loads: steps 0 .. DEPTH-1
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (d < nk) issue_loads(d, d);
 
-  f32x16 acc[2][2];
+  f32x16 acc[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+    for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
 
   // ---- low-rank prologue: acc = Q_Bout(xAq @ B) + bias ----------------------------------------
   if constexpr (LOWRANK) {
     for (int l = 0; l < g.b_limbs; ++l) {
       for (int ks = 0; ks < g.rp / 16; ++ks) {
-        bf16x8 xa[2], bb[2];
+        const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          xa[i] = *(const bf16x8*)(g.xaq + (int64_t)(m0 + wm * 64 + i * 32 + l31) * g.rp + ks * 16 + 8 * lh);
-          bb[i] = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 64 + i * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa, acc[i], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[j], xa[i], acc[i][j], 0, 0, 0);
       }
     }
     if constexpr (BOUT16) {
       const int mb = g.bout.mbits;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int b = 0; b < 2; ++b) {
+          float amax = 0.f;
 #pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            float amax = 0.f;
+          for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[i][8 * b + k]));
+          amax = pair32_max(amax);
+          const int e = block_exponent(amax, g.bout);  // amax = 0: every element takes the pass-through
 #pragma unroll
-            for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[i][j][8 * b + k]));
-            amax = pair32_max(amax);
-            const int e = block_exponent(amax, g.bout);  // amax = 0: every element takes the pass-through
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const float t = acc[i][j][8 * b + k];
-              const float m = fminf(rintf(ldexpf(fabsf(t) + 1e-9f, mb - e)), g.bout.mmax);
-              const float q = copysignf(ldexpf(m, e - mb), t);
-              acc[i][j][8 * b + k] = fabsf(t) <= 1e-8f ? t : q;
-            }
+          for (int k = 0; k < 8; ++k) {
+            const float t = acc[i][8 * b + k];
+            const float m = fminf(rintf(ldexpf(fabsf(t) + 1e-9f, mb - e)), g.bout.mmax);
+            const float q = copysignf(ldexpf(m, e - mb), t);
+            acc[i][8 * b + k] = fabsf(t) <= 1e-8f ? t : q;
           }
+        }
     }
   }
   if (g.bias) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int k = 0; k < 16; ++k) {
+      const float bv = g.bias[n0 + wn * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const float bv = g.bias[n0 + wn * 64 + j * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][j][k] += bv;
-      }
+      for (int i = 0; i < 4; ++i) acc[i][k] += bv;
+    }
   }
 
   // ---- main loop ------------------------------------------------------------------------------
@@ -302,36 +287,44 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // because the last MFMAs of COMPUTE(kt) may still be queued (and read their sources late) when the LDS
   // reads of LOAD(kt+1) return - a read landing in a register an in-flight MFMA has not consumed yet
   // corrupts one 16-lane group of that operand (seen as run-to-run differences before this was fixed).
-  auto step = [&](int kt, bf16x8(&xa)[4][2], u32x4(&wr)[2], uint32_t(&we)[2]) {
+  auto step = [&](int kt) {
     const uint32_t oa = slot * A_SLOT, orw = slot * R_SLOT;
     const int slot_new = slot == 0 ? NSLOT - 1 : slot - 1;  // (slot + DEPTH) % NSLOT
     STAMP(7);
-    // ---- LOAD(kt): prefetch issue, then ONE asm statement with the 12 LDS reads, the waits and the barrier.
+    // ---- LOAD(kt): prefetch issue, then ONE asm statement with the 18 LDS reads, the waits and the barrier.
     // (Reads and their wait must not be separate statements: hipcc treats an asm output as valid when the
     // statement ends and was seen to copy such registers to others BEFORE the separate wait - stale data.)
     if (kt + DEPTH < nk) issue_loads(kt + DEPTH, slot_new);
+    bf16x8 xa[4][4];  // [ks][m tile]
+    u32x4 wr;
+    uint32_t we;
 #ifdef LQER_ABL_DMA_ONLY
-    for (int ks = 0; ks < 4; ++ks) xa[ks][0] = xa[ks][1] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
-    wr[0] = wr[1] = (u32x4){1, 2, 3, 4};
-    we[0] = we[1] = 0x7c7c7c7cu;
+    for (int ks = 0; ks < 4; ++ks)
+      for (int i = 0; i < 4; ++i) xa[ks][i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+    wr = (u32x4){1, 2, 3, 4};
+    we = 0x7c7c7c7cu;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #else
     {
-      const uint32_t aw0 = fw_addr[0] + orw, aw1 = fw_addr[1] + orw, ae0 = fe_addr[0] + orw, ae1 = fe_addr[1] + orw;
+      const uint32_t aw = fw_addr + orw, ae = fe_addr + orw;
       const uint32_t aa0 = fa_addr[0] + oa, aa1 = fa_addr[1] + oa, aa2 = fa_addr[2] + oa, aa3 = fa_addr[3] + oa;
       const int younger = nk - 2 - kt;  // batches issued for steps beyond kt+1: they may stay in flight
-#define LQER_LOAD_ASM(VM)                                                                                    \
-  asm volatile(                                                                                              \
-      "ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b32 %2, %14 offset:512\n\t"                    \
-      "ds_read_b32 %3, %15 offset:512\n\t"                                                                    \
-      "ds_read_b128 %4, %16\n\tds_read_b128 %5, %16 offset:4096\n\t"                                          \
-      "ds_read_b128 %6, %17\n\tds_read_b128 %7, %17 offset:4096\n\t"                                          \
-      "ds_read_b128 %8, %18\n\tds_read_b128 %9, %18 offset:4096\n\t"                                          \
-      "ds_read_b128 %10, %19\n\tds_read_b128 %11, %19 offset:4096\n\t"                                        \
-      "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                                      \
-      : "=&v"(wr[0]), "=&v"(wr[1]), "=&v"(we[0]), "=&v"(we[1]), "=&v"(xa[0][0]), "=&v"(xa[0][1]),            \
-        "=&v"(xa[1][0]), "=&v"(xa[1][1]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[3][0]), "=&v"(xa[3][1])  \
-      : "v"(aw0), "v"(aw1), "v"(ae0), "v"(ae1), "v"(aa0), "v"(aa1), "v"(aa2), "v"(aa3)                       \
+#define LQER_LOAD_ASM(VM)                                                                                         \
+  asm volatile(                                                                                                   \
+      "ds_read_b128 %0, %18\n\tds_read_b32 %1, %19 offset:512\n\t"                                                 \
+      "ds_read_b128 %2, %20\n\tds_read_b128 %3, %20 offset:4096\n\tds_read_b128 %4, %20 offset:8192\n\t"           \
+      "ds_read_b128 %5, %20 offset:12288\n\t"                                                                      \
+      "ds_read_b128 %6, %21\n\tds_read_b128 %7, %21 offset:4096\n\tds_read_b128 %8, %21 offset:8192\n\t"           \
+      "ds_read_b128 %9, %21 offset:12288\n\t"                                                                      \
+      "ds_read_b128 %10, %22\n\tds_read_b128 %11, %22 offset:4096\n\tds_read_b128 %12, %22 offset:8192\n\t"        \
+      "ds_read_b128 %13, %22 offset:12288\n\t"                                                                     \
+      "ds_read_b128 %14, %23\n\tds_read_b128 %15, %23 offset:4096\n\tds_read_b128 %16, %23 offset:8192\n\t"        \
+      "ds_read_b128 %17, %23 offset:12288\n\t"                                                                     \
+      "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                                           \
+      : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]), \
+        "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),      \
+        "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])                        \
+      : "v"(aw), "v"(ae), "v"(aa0), "v"(aa1), "v"(aa2), "v"(aa3)                                                   \
       : "memory")
       if (younger >= 2)
         LQER_LOAD_ASM(8);
@@ -343,25 +336,22 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    STAMP(4);  // waits + barrier after LOAD
+    STAMP(4);  // LOAD: issue + waits + barrier
     // ---- COMPUTE(kt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       // biased exponent byte ks -> fp32 bits of the block scale 2^(e - mbits)
-      const uint32_t s0 = ks < 3 ? (we[0] << (23 - 8 * ks)) & 0x7f800000u : (we[0] >> 1) & 0x7f800000u;
-      const uint32_t s1 = ks < 3 ? (we[1] << (23 - 8 * ks)) & 0x7f800000u : (we[1] >> 1) & 0x7f800000u;
+      const uint32_t sc = ((we >> (8 * ks)) & 0xffu) << 23;
 #ifdef LQER_ABL_NO_EXPAND
-      const bf16x8 wb0 = __builtin_bit_cast(bf16x8, wr[0] + s0), wb1 = __builtin_bit_cast(bf16x8, wr[1] + s1);
+      const bf16x8 wb = __builtin_bit_cast(bf16x8, wr + sc);
 #else
-      const bf16x8 wb0 = expand_frag(wr[0][ks], s0), wb1 = expand_frag(wr[1][ks], s1);
+      const bf16x8 wb = expand_frag(wr[ks], sc);
 #endif
 #if defined(LQER_ABL_NO_MFMA) || defined(LQER_ABL_DMA_ONLY)
-      asm volatile("" ::"v"(wb0), "v"(wb1), "v"(xa[ks][0]), "v"(xa[ks][1]));
+      asm volatile("" ::"v"(wb), "v"(xa[ks][0]), "v"(xa[ks][1]), "v"(xa[ks][2]), "v"(xa[ks][3]));
 #else
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb0, xa[ks][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, xa[ks][0], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb0, xa[ks][1], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, xa[ks][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, xa[ks][i], acc[i], 0, 0, 0);
 #endif
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -371,15 +361,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     STAMP(6);  // barrier after COMPUTE
     slot = slot == NSLOT - 1 ? 0 : slot + 1;
   };
-  bf16x8 xa0[4][2], xa1[4][2];
-  u32x4 wr0[2], wr1[2];
-  uint32_t we0[2], we1[2];
-  int kt = 0;
-  for (; kt + 1 < nk; kt += 2) {
-    step(kt, xa0, wr0, we0);
-    step(kt + 1, xa1, wr1, we1);
-  }
-  if (kt < nk) step(kt, xa0, wr0, we0);
+  for (int kt = 0; kt < nk; ++kt) step(kt);
   if (!late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_STAMPS
   if (g_stamp_buf && lane == 0)
@@ -389,67 +371,64 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // ---- store ----------------------------------------------------------------------------------
   // per 32x32 tile and quad q: regs 4q..4q+3 = columns n = nb + 8q + 4 lh + (0..3) of token row m
   const bool aligned16 = (((uintptr_t)g.y) & 15) == 0;
+  const int nb = n0 + wn * 32;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + l31;
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + i * 32 + l31;
+    if constexpr (DT == LQER_F32) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nb = n0 + wn * 64 + j * 32;
-      if constexpr (DT == LQER_F32) {
+      for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q + 4 * lh;
+        if (m < g.M) {
+          float* dst = (float*)g.y + (int64_t)m * g.ldy + n;
+          if (n + 3 < g.N && (g.ldy & 3) == 0 && aligned16) {
+            *(float4*)dst = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+          } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = nb + 8 * q + 4 * lh;
-          if (m < g.M) {
-            float* dst = (float*)g.y + (int64_t)m * g.ldy + n;
-            if (n + 3 < g.N && (g.ldy & 3) == 0 && aligned16) {
-              *(float4*)dst = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            } else {
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                if (n + t < g.N) dst[t] = acc[i][j][4 * q + t];
-            }
+            for (int t = 0; t < 4; ++t)
+              if (n + t < g.N) dst[t] = acc[i][4 * q + t];
           }
         }
-      } else {
-        // 16-bit outputs: pack 4 columns into 8 B, then merge quads (q, q+1) of lanes l / l^32 into one
-        // 16-B store: lanes 0-31 get columns 16p .. 16p+7, lanes 32-63 columns 16p+8 .. 16p+15
-        uint32_t pk[4][2];
+      }
+    } else {
+      // 16-bit outputs: pack 4 columns into 8 B, then merge quads (q, q+1) of lanes l / l^32 into one
+      // 16-B store: lanes 0-31 get columns 16p .. 16p+7, lanes 32-63 columns 16p+8 .. 16p+15
+      uint32_t pk[4][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const float v0 = acc[i][j][4 * q + 2 * h], v1 = acc[i][j][4 * q + 2 * h + 1];
-            if constexpr (DT == LQER_F16) {
-              typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-              h2 hv = {(_Float16)v0, (_Float16)v1};
-              pk[q][h] = __builtin_bit_cast(uint32_t, hv);
-            } else {
-              pk[q][h] = (uint32_t)f32_to_bf16_rne(v0) | ((uint32_t)f32_to_bf16_rne(v1) << 16);
-            }
+        for (int h = 0; h < 2; ++h) {
+          const float v0 = acc[i][4 * q + 2 * h], v1 = acc[i][4 * q + 2 * h + 1];
+          if constexpr (DT == LQER_F16) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            h2 hv = {(_Float16)v0, (_Float16)v1};
+            pk[q][h] = __builtin_bit_cast(uint32_t, hv);
+          } else {
+            pk[q][h] = (uint32_t)f32_to_bf16_rne(v0) | ((uint32_t)f32_to_bf16_rne(v1) << 16);
           }
-        const bool wide = (g.ldy & 7) == 0 && nb + 32 <= g.N && aligned16;  // wave-uniform
+        }
+      const bool wide = (g.ldy & 7) == 0 && nb + 32 <= g.N && aligned16;  // wave-uniform
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const uint32_t a0 = pk[2 * p][0], a1 = pk[2 * p][1], b0 = pk[2 * p + 1][0], b1 = pk[2 * p + 1][1];
-          if (wide) {
-            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            // lanes 0-31: {own quad 2p, upper lane's quad 2p}; lanes 32-63: {lower lane's quad 2p+1, own quad 2p+1}
-            if (m < g.M) {
-              bf16_t* dst = (bf16_t*)g.y + (int64_t)m * g.ldy + nb + 16 * p + 8 * lh;
-              *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-            }
-          } else if (m < g.M) {
+      for (int p = 0; p < 2; ++p) {
+        const uint32_t a0 = pk[2 * p][0], a1 = pk[2 * p][1], b0 = pk[2 * p + 1][0], b1 = pk[2 * p + 1][1];
+        if (wide) {
+          auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          // lanes 0-31: {own quad 2p, upper lane's quad 2p}; lanes 32-63: {lower lane's quad 2p+1, own quad 2p+1}
+          if (m < g.M) {
+            bf16_t* dst = (bf16_t*)g.y + (int64_t)m * g.ldy + nb + 16 * p + 8 * lh;
+            *(uint4*)dst = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          }
+        } else if (m < g.M) {
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-              const int n = nb + 8 * (2 * p + qq) + 4 * lh;
-              const uint32_t lo = qq ? b0 : a0, hi = qq ? b1 : a1;
-              bf16_t* dst = (bf16_t*)g.y + (int64_t)m * g.ldy + n;
-              if (n < g.N) dst[0] = (bf16_t)(lo & 0xffff);
-              if (n + 1 < g.N) dst[1] = (bf16_t)(lo >> 16);
-              if (n + 2 < g.N) dst[2] = (bf16_t)(hi & 0xffff);
-              if (n + 3 < g.N) dst[3] = (bf16_t)(hi >> 16);
-            }
+          for (int qq = 0; qq < 2; ++qq) {
+            const int n = nb + 8 * (2 * p + qq) + 4 * lh;
+            const uint32_t lo = qq ? b0 : a0, hi = qq ? b1 : a1;
+            bf16_t* dst = (bf16_t*)g.y + (int64_t)m * g.ldy + n;
+            if (n < g.N) dst[0] = (bf16_t)(lo & 0xffff);
+            if (n + 1 < g.N) dst[1] = (bf16_t)(lo >> 16);
+            if (n + 2 < g.N) dst[2] = (bf16_t)(hi & 0xffff);
+            if (n + 3 < g.N) dst[3] = (bf16_t)(hi >> 16);
           }
         }
       }

@@ -24,7 +24,7 @@ for _ in range(3):
     assert L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(), 1, N, None) == 0
 torch.cuda.synchronize()
 b = buf.cpu().view(256, 8, 8).double()
-names = ["lds reads", "prefetch issue", "expand+write", "vmcnt wait", "barrier 1", "mfma issue", "barrier 2", "loop overhead"]
+names = ["s0", "s1", "s2", "s3", "LOAD(issue+waits+barrier)", "COMPUTE issue", "barrier after COMPUTE", "loop overhead"]
 steps = K // 64
 for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
     m = b[:, sl, :].mean(dim=(0, 1)) / steps
