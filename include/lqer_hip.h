@@ -148,9 +148,9 @@ int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fm
 
 /* y[M,N] (row stride ldy, same dtype as x) from x[M,K] (row stride ldx).  a_limbs / b_limbs =
  * the limb counts reported by lqer_pack_lowrank.  workspace >= lqer_linear_sizes(...).workspace
- * for m_max >= M.  Three stream-ordered launches: activation quantize, rank-r side GEMM with
- * A_out re-quantization, fused W4 x A8 GEMM with the B side GEMM, B_out re-quantization, bias and
- * add in its prologue.                                                                       */
+ * for m_max >= M.  Four stream-ordered launches: activation quantize, rank-r side GEMM (split-K
+ * partials, then a fixed-order reduce with the A_out re-quantization), fused W4 x A8 GEMM with the
+ * B side GEMM, B_out re-quantization, bias and add in its prologue.                            */
 int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype, int64_t M,
                         int64_t ldx, const void* w_packed, const void* a_t, const void* b_t,
                         int a_limbs, int b_limbs, const float* bias_q, void* y, int64_t ldy,
@@ -158,8 +158,10 @@ int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype
 
 /* The same, split for callers that share one quantized activation between several Linears
  * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */
+size_t lqer_lowrank_xa_scratch_bytes(int64_t m_max, int64_t rank);
 int lqer_lowrank_xa(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
-                    const void* a_t, int a_limbs, void* xaq_bf16, void* stream);
+                    const void* a_t, int a_limbs, void* xaq_bf16, void* scratch,
+                    size_t scratch_bytes, void* stream);
 int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
                      const void* w_packed, const void* xaq_bf16, const void* b_t, int b_limbs,
                      const float* bias_q, void* y, int dtype, int64_t ldy, void* stream);

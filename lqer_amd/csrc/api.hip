@@ -120,7 +120,7 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
   out->a_t = 3 * rp * Kp * 2;
   out->b_t = 3 * Np * rp * 2;
   out->bias_q = Np * 4;
-  out->workspace = align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256);
+  out->workspace = align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256) + (rp ? align_up(xa_scratch_bytes(m_max, rp), 256) : 0);
   return LQER_OK;
 }
 
@@ -170,8 +170,12 @@ int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fm
   return quantize_dispatch(bias, dtype, 1, N, N, q, o, st);
 }
 
+size_t lqer_lowrank_xa_scratch_bytes(int64_t m_max, int64_t rank) {
+  return rank > 0 ? xa_scratch_bytes(m_max, lqer_padded_r(rank)) : 0;
+}
+
 int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* a_t, int a_limbs, void* xaq,
-                    void* stream) {
+                    void* scratch, size_t scratch_bytes, void* stream) {
   if (!d || !xq || !a_t || !xaq || M < 0 || d->rank <= 0) {
     set_error("lowrank_xa: bad argument");
     return LQER_E_INVALID;
@@ -182,7 +186,7 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
     return LQER_E_INVALID;
   }
   return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, (const bf16_t*)a_t, a_limbs, d->rank,
-                             make_qp(d->a_out_fmt), (bf16_t*)xaq, (hipStream_t)stream);
+                             make_qp(d->a_out_fmt), (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
@@ -241,11 +245,13 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   const size_t Kp = lqer_padded_k(d->in_features), Mp = lqer_padded_m(M);
   unsigned char* ws = (unsigned char*)workspace;
   void* xq = ws;
+  const size_t rp = lqer_padded_r(d->rank);
   void* xaq = ws + align_up(Mp * Kp * 2, 256);
+  void* xa_scratch = ws + align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256);
   rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
   if (rc) return rc;
   if (d->rank > 0) {
-    rc = lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, stream);
+    rc = lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, xa_scratch, lqer_lowrank_xa_scratch_bytes(M, d->rank), stream);
     if (rc) return rc;
   }
   return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, stream);

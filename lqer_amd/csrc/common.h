@@ -153,7 +153,8 @@ int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, in
                           void* b_t, int32_t* flags, hipStream_t st);
 int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, hipStream_t st);
 int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,
-                        const QP& q, bf16_t* xaq, hipStream_t st);
+                        const QP& q, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st);
+size_t xa_scratch_bytes(int64_t m_max, int64_t rp);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, hipStream_t st);
 
 // ---- error plumbing (host) -------------------------------------------------------------------

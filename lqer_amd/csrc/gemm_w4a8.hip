@@ -283,10 +283,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-  // One k-step.  The operand registers are passed in: consecutive steps use two different register sets,
-  // because the last MFMAs of COMPUTE(kt) may still be queued (and read their sources late) when the LDS
-  // reads of LOAD(kt+1) return - a read landing in a register an in-flight MFMA has not consumed yet
-  // corrupts one 16-lane group of that operand (seen as run-to-run differences before this was fixed).
+  // One k-step.
   auto step = [&](int kt) {
     const uint32_t oa = slot * A_SLOT, orw = slot * R_SLOT;
     const int slot_new = slot == 0 ? NSLOT - 1 : slot - 1;  // (slot + DEPTH) % NSLOT

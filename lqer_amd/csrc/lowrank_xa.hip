@@ -1,73 +1,171 @@
 // Rank-r side path, first half:  xAq = A_out_quantizer( Q_x(x) @ A )   (reference
-// quantized_layers/linear.py:154).  [M,K] x [K,r] with r << K: a skinny GEMM that streams the
-// quantized activation once (HBM/L2 bound), so one workgroup owns 16 token rows and the whole
-// rank; its 4 waves interleave 32-deep k-steps on v_mfma_f32_16x16x32_bf16 and combine through LDS.
-// A comes as exact bf16 limbs (pack.hip), x as the exact bf16 image of the activation quantizer,
-// so every product is exact in fp32 and only the fp32 accumulation order differs from the
-// reference's torch.matmul.
+// quantized_layers/linear.py:154).  [M,K] x [K,r] with r << K: a skinny GEMM that streams the quantized
+// activation once, i.e. HBM/L2 bound - so it is cut into ~2048 independent (32-row, K-chunk) pieces, one
+// wave each, to put every CU on the stream:
+//   k_xa_partial : v_mfma_f32_32x32x16_bf16 over the wave's K chunk, fp32 partial tile -> scratch
+//   k_xa_reduce  : sums the chunks in a fixed order (bit-reproducible, no atomics), applies A_out, writes
+//                  the exact bf16 image the fused GEMM's prologue consumes.
+// A comes as exact bf16 limbs (pack.hip), x as the exact bf16 image of the activation quantizer, so every
+// product is exact in fp32; only the fp32 accumulation order differs from the reference's torch.matmul.
 #include "common.h"
 
 namespace lqer {
 
-constexpr int XA_ROWS = 16;
-constexpr int XA_MAX_TILES = 16;  // rp <= 256
+constexpr int XA_ROWS = 32;       // token rows per wave
+constexpr int XA_MAX_TILES = 8;   // rp <= 256
+constexpr int XA_TARGET_WAVES = 2048;
 
+struct XaPlan {
+  int row_groups, nchunk, kc;  // kc = k per chunk (multiple of 64)
+};
+
+__host__ __device__ inline XaPlan xa_plan(int64_t M, int64_t Kp) {
+  XaPlan p;
+  p.row_groups = (int)((M + XA_ROWS - 1) / XA_ROWS);
+  const int windows = (int)(Kp / 64);
+  int want = p.row_groups > 0 ? (XA_TARGET_WAVES + p.row_groups - 1) / p.row_groups : 1;
+  if (want < 1) want = 1;
+  if (want > windows) want = windows;
+  const int wpc = (windows + want - 1) / want;  // 64-k windows per chunk
+  p.kc = wpc * 64;
+  p.nchunk = (windows + wpc - 1) / wpc;
+  return p;
+}
+
+size_t xa_scratch_bytes(int64_t m_max, int64_t rp) {
+  // row_groups * nchunk <= XA_TARGET_WAVES + row_groups for every M <= m_max
+  const int64_t rg = (m_max + XA_ROWS - 1) / XA_ROWS;
+  return (size_t)(XA_TARGET_WAVES + rg) * XA_ROWS * rp * sizeof(float);
+}
+
+// One wave = 32 token rows x one K chunk.  Within a 64-k window lane (r = lane & 31, h = lane >> 5) owns the
+// 32 consecutive k at 32h of its row - one 64-byte load - and feeds them to 4 MFMAs in the order it holds
+// them (the k order inside a window is a free permutation as long as both operands use the same one).
 template <int NT>
-__global__ __launch_bounds__(256) void k_lowrank_xa(const bf16_t* __restrict__ xq, int64_t Kp,
-                                                    const bf16_t* __restrict__ a_t, int a_limbs, int rp, QP q,
-                                                    bf16_t* __restrict__ xaq) {
-  extern __shared__ __attribute__((aligned(16))) float part[];  // [4][16][rp]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * XA_ROWS;
-  const int fr = lane & 15, fq = lane >> 4;
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const bf16_t* xrow = xq + (m0 + fr) * Kp + 8 * fq;
-  const int steps = (int)(Kp / 32);
-  for (int s = wave; s < steps; s += 4) {
-    const bf16x8 a = *(const bf16x8*)(xrow + s * 32);
-    for (int l = 0; l < a_limbs; ++l) {
-      const bf16_t* at = a_t + ((int64_t)l * rp + fr) * Kp + s * 32 + 8 * fq;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const bf16x8 b = *(const bf16x8*)(at + (int64_t)t * 16 * Kp);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
-      }
-    }
-  }
-  // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+__global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t Kp,
+                                                    const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
+                                                    float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= plan.row_groups * plan.nchunk) return;
+  const int rg = wid / plan.nchunk, c = wid - rg * plan.nchunk;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t k_begin = (int64_t)c * plan.kc;
+  const int64_t k_end = k_begin + plan.kc < Kp ? k_begin + plan.kc : Kp;
+  f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) part[(wave * XA_ROWS + 4 * fq + j) * rp + t * 16 + fr] = acc[t][j];
-  __syncthreads();
-  for (int i = threadIdx.x; i < XA_ROWS * rp; i += 256)
-    part[i] = (part[i] + part[XA_ROWS * rp + i]) + (part[2 * XA_ROWS * rp + i] + part[3 * XA_ROWS * rp + i]);
-  __syncthreads();
-  // A_out quantizer: one lane per (row, block of L along r)
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  const bf16_t* xrow = xq + ((int64_t)rg * XA_ROWS + r) * Kp + 32 * h;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += 64) {
+    bf16x8 xf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + k0 + 8 * i);
+    for (int l = 0; l < a_limbs; ++l) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = t * 32 + r;
+        bf16x8 af[4];
+        if (n < rp) {
+          const bf16_t* arow = a_t + ((int64_t)l * rp + n) * Kp + k0 + 32 * h;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(arow + 8 * i);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], af[i], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // D layout: col n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 h.  part[c][rg*32 + m][n]
+  float* dst = part + ((int64_t)c * plan.row_groups + rg) * XA_ROWS * rp;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = t * 32 + r;
+    if (n < rp) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dst[((j & 3) + 8 * (j >> 2) + 4 * h) * rp + n] = acc[t][j];
+    }
+  }
+}
+
+// Fixed-order sum over the chunks + A_out + bf16 store.  One lane per 4 consecutive rank entries; the G = L/4
+// lanes of a block (G a power of two <= 64, lanes of one wave) share their max through xor-shuffles.
+template <int G>
+__global__ __launch_bounds__(256) void k_xa_reduce4(const float* __restrict__ part, XaPlan plan, int rp, QP q,
+                                                    bf16_t* __restrict__ xaq) {
+  const int64_t total = (int64_t)plan.row_groups * XA_ROWS * rp / 4;  // float4 items (rp/4 per row, a multiple of G)
+  const int64_t chunk_stride = (int64_t)plan.row_groups * XA_ROWS * rp;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < total;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    const float* src = part + idx * 4;
+    // chunks summed in ascending order, 8 loads in flight at a time
+    int c = 0;
+    for (; c + 8 <= plan.nchunk; c += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(src + (c + u) * chunk_stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+    }
+    for (; c < plan.nchunk; ++c) {
+      const float4 v = *(const float4*)(src + c * chunk_stride);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  }
+  float amax = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w)));
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
+  if (!live) return;
+  const bool any = amax > 0.f;
+  const int e = any ? block_exponent(amax, q) : 0;
+  const float v[4] = {s.x, s.y, s.z, s.w};
+  uint32_t w[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float m0v = any ? mxint_mantissa(v[2 * i], e, q) : 0.f;
+    const float m1v = any ? mxint_mantissa(v[2 * i + 1], e, q) : 0.f;
+    w[i] = exact_bf16_bits(ldexpf(m0v, e - q.mbits)) | (exact_bf16_bits(ldexpf(m1v, e - q.mbits)) << 16);
+  }
+  *(uint2*)(xaq + idx * 4) = make_uint2(w[0], w[1]);
+}
+
+// Generic block length (not 4 * 2^g): one lane per block, serial.
+__global__ __launch_bounds__(256) void k_xa_reduce_blk(const float* __restrict__ part, XaPlan plan, int rp, QP q,
+                                                       bf16_t* __restrict__ xaq) {
   const int L = (q.block <= 0 || q.block >= rp) ? rp : q.block;
   const int nb = rp / L;
-  for (int i = threadIdx.x; i < XA_ROWS * nb; i += 256) {
-    const int row = i / nb, b0 = (i - row * nb) * L;
+  const int64_t total = (int64_t)plan.row_groups * XA_ROWS * nb;
+  const int64_t chunk_stride = (int64_t)plan.row_groups * XA_ROWS * rp;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / nb;
+    const int b0 = (int)(idx - row * nb) * L;
     const float* src = part + row * rp + b0;
+    bf16_t* dst = xaq + row * rp + b0;
     float amax = 0.f;
-    for (int k = 0; k < L; ++k) amax = fmaxf(amax, fabsf(src[k]));
+    for (int k = 0; k < L; ++k) {
+      float sum = src[k];
+      for (int c = 1; c < plan.nchunk; ++c) sum += src[c * chunk_stride + k];
+      amax = fmaxf(amax, fabsf(sum));
+    }
     const bool any = amax > 0.f;
     const int e = any ? block_exponent(amax, q) : 0;
-    bf16_t* dst = xaq + (m0 + row) * rp + b0;
-    for (int k = 0; k < L; k += 2) {
-      const float m0v = any ? mxint_mantissa(src[k], e, q) : 0.f;
-      const float m1v = any ? mxint_mantissa(src[k + 1], e, q) : 0.f;
-      *(uint32_t*)(dst + k) =
-          exact_bf16_bits(ldexpf(m0v, e - q.mbits)) | (exact_bf16_bits(ldexpf(m1v, e - q.mbits)) << 16);
+    for (int k = 0; k < L; ++k) {
+      float sum = src[k];
+      for (int c = 1; c < plan.nchunk; ++c) sum += src[c * chunk_stride + k];
+      const float mv = any ? mxint_mantissa(sum, e, q) : 0.f;
+      dst[k] = (bf16_t)exact_bf16_bits(ldexpf(mv, e - q.mbits));
     }
   }
 }
 
 int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,
-                        const QP& q, bf16_t* xaq, hipStream_t st) {
+                        const QP& q, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st) {
   const int64_t Kp = lqer_padded_k(K);
   const int rp = (int)lqer_padded_r(r);
   if (q.kind != LQER_Q_MXINT || q.mbits > 8) {
@@ -80,22 +178,44 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_
     set_error("A_out_quantizer block %d does not tile the padded rank %d", q.block, rp);
     return LQER_E_UNSUPPORTED;
   }
-  if (rp > 16 * XA_MAX_TILES) {
-    set_error("rank %d > %d not supported", (int)r, 16 * XA_MAX_TILES);
+  if (rp > 32 * XA_MAX_TILES) {
+    set_error("rank %d > %d not supported", (int)r, 32 * XA_MAX_TILES);
     return LQER_E_UNSUPPORTED;
   }
   if (M == 0) return LQER_OK;
-  const unsigned grid = (unsigned)((M + XA_ROWS - 1) / XA_ROWS);
-  const size_t lds = (size_t)4 * XA_ROWS * rp * sizeof(float);
-#define XA_CASE(NT)                                                                         \
-  case NT:                                                                                  \
-    k_lowrank_xa<NT><<<grid, 256, lds, st>>>(xq, Kp, a_t, a_limbs, rp, q, xaq);             \
+  const XaPlan plan = xa_plan(M, Kp);
+  const size_t need = (size_t)plan.nchunk * plan.row_groups * XA_ROWS * rp * sizeof(float);
+  if (!scratch || scratch_bytes < need) {
+    set_error("lowrank_xa: scratch %zu B < %zu B", scratch_bytes, need);
+    return LQER_E_WORKSPACE;
+  }
+  const unsigned grid = (unsigned)((plan.row_groups * plan.nchunk + 3) / 4);
+#define XA_CASE(NT)                                                                   \
+  case NT:                                                                            \
+    k_xa_partial<NT><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);  \
     break;
-  switch (rp / 16) {
+  switch ((rp + 31) / 32) {
     XA_CASE(1) XA_CASE(2) XA_CASE(3) XA_CASE(4) XA_CASE(5) XA_CASE(6) XA_CASE(7) XA_CASE(8)
-    XA_CASE(9) XA_CASE(10) XA_CASE(11) XA_CASE(12) XA_CASE(13) XA_CASE(14) XA_CASE(15) XA_CASE(16)
   }
 #undef XA_CASE
+  const int G = L / 4;
+  if ((G & (G - 1)) == 0 && G <= 64) {
+    const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
+    const unsigned grid2 = (unsigned)((items + 255) / 256);
+    switch (G) {
+      case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+      case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+      case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+      case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+      case 16: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+      case 32: k_xa_reduce4<32><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+      default: k_xa_reduce4<64><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+    }
+  } else {
+    const int64_t total = (int64_t)plan.row_groups * XA_ROWS * (rp / L);
+    const unsigned grid2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    k_xa_reduce_blk<<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq);
+  }
   return check_launch("lowrank_xa");
 }
 
