@@ -39,6 +39,11 @@ MXINT_Q = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=_bf
 # opt-6.7b.toml:98-102: bias in blocks of 16
 OPT_Q = dict(MXINT_Q, b_quantizer=_bfp(8, [1, 16], False))
 
+# reference sweep_lqer_act_int.sh:83 / llama-7b-int.toml (W block 128, A/B unquantized fp16) with the 8-bit
+# per-token activation format BASELINE.json's "W4A8 L2QER-INT" pins: block_fp(8, [1,-1])
+INT_Q = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=_bfp(8, [1, -1], True),
+             w_quantizer=_bfp(4, [1, 128], False), b_quantizer=dict(name="passthrough"))
+
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 INT8_MFMA_PEAK_TOPS = 5000.0    # 2x bf16 per clock (same guide, "Matrix cores", I8 row)
 
@@ -47,6 +52,8 @@ WORKLOADS = {
     "c2": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=2048 (BASELINE configs[1])", 2048, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
     "c3": ("Llama-7B 7 projections x 32 layers rank32 W4A8-MXINT16 M=2048 (BASELINE configs[2])", 2048, 32, False, MXINT_Q,
            [(4096, 4096, 4), (4096, 11008, 2), (11008, 4096, 1)], 32),
+    "c4": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A8(per-token) M=16384 (BASELINE configs[3], per-GPU share)", 16384, 64, False,
+           INT_Q, [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)], 5),
     "c5": ("OPT-6.7B 6 projections x 32 layers rank128 W4A8-MXINT16 M=2048 (BASELINE configs[4])", 2048, 128, True, OPT_Q,
            [(4096, 4096, 4), (4096, 16384, 1), (16384, 4096, 1)], 32),
 }
@@ -57,7 +64,7 @@ def flops(M, K, N, r):
     return 2 * M * K * N + 2 * M * K * r + 2 * M * r * N
 
 
-def make_case(M, K, N, r, seed=0, bias=False):
+def make_case(M, K, N, r, seed=0, bias=False, quantize_ab=True):
     """Synthetic inputs of SURVEY.md §8d: x ~ N(0,1) with three x30 outlier channels, W ~ N(0, 0.02^2),
     A, B ~ 0.01 N(0,1) snapped to the 8-bit MXINT grid (blocks of 16 along K / rank) like the
     reference's approximator output (llama-7b.toml:60-73)."""
@@ -69,9 +76,12 @@ def make_case(M, K, N, r, seed=0, bias=False):
         if c < K:
             x[:, c] *= 30.0
     W = 0.02 * torch.randn(N, K, generator=g)
-    if r > 0:
+    if r > 0 and quantize_ab:
         A = O.mxint_quantize(0.01 * torch.randn(K, r, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
         B = O.mxint_quantize(0.01 * torch.randn(r, N, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
+    elif r > 0:  # the INT configs keep A, B unquantized (llama-7b-int.toml:61-68)
+        A = 0.01 * torch.randn(K, r, generator=g)
+        B = 0.01 * torch.randn(r, N, generator=g)
     else:
         A = B = None
     if bias:
@@ -87,9 +97,9 @@ def cpu_baseline(M, K, N, r, q_config, reps=3):
 
     cores = min(os.cpu_count() or 1, int(os.environ.get("LQER_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
-    x, W, A, B = make_case(M, K, N, r, seed=0)
+    x, W, A, B = make_case(M, K, N, r, seed=0, quantize_ab=q_config is not INT_Q)
     x = x.half().float()
-    wq = O.mxint_quantize(W, width=4, block_size=[1, 16], skip_first_dim=False)
+    wq = O.get_quantizer(q_config["w_quantizer"])(W)
     O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)  # warm-up
     best = float("inf")
     for _ in range(reps):
@@ -140,7 +150,7 @@ def main():
     layers_here = layers  # weak scaling: every rank runs a full unit list of its own
     mods = []
     for i, (K, N, cnt) in enumerate(shapes):
-        case = make_case(M, K, N, r, seed=sweep.unit_seed(rank, i), bias=has_bias)
+        case = make_case(M, K, N, r, seed=sweep.unit_seed(rank, i), bias=has_bias, quantize_ab=qc is not INT_Q)
         x, W, A, B = case[:4]
         mod = lqer_amd.LinearFlexibleLqer(K, N, bias=has_bias, q_config=qc, l_config={"rank": r})
         sd = {"weight": W, "A": A, "B": B}
@@ -182,7 +192,8 @@ def main():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 _lib.check(L.lqer_linear_gemm(C.byref(desc), xq, M, p["w"].data_ptr(), xaq, p["b_t"].data_ptr(), p["b_limbs"],
-                                              ops._ptr(p.get("bias")), y.data_ptr(), _lib.F16, N, stream), "linear_gemm")
+                                              ops._ptr(p.get("bias")), y.data_ptr(), _lib.F16, N, xscr,
+                                              L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M), stream), "linear_gemm")
                 if ev:
                     e1.record()
                     gemm_events.append((e0, e1, K, N))
@@ -214,7 +225,7 @@ def main():
         from oracle import lqer_oracle as O
 
         mod, xd, K, N, _, y = mods[0]
-        case = make_case(M, K, N, r, seed=0, bias=has_bias)
+        case = make_case(M, K, N, r, seed=sweep.unit_seed(0, 0), bias=has_bias, quantize_ab=qc is not INT_Q)
         ref = O.lqer_linear_forward(case[0].half().float(), case[1].half().float(), case[4].half().float() if has_bias else None,
                                     case[2].half().float(), case[3].half().float(), qc)
         err = float((y.float().cpu() - ref).norm() / ref.norm())
@@ -247,7 +258,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": desc_txt, "tokens_per_step_per_gpu": M, "rank": r,
-                       "formats": "x MXINT8/16, W MXINT4/16, A_out,B_out MXINT8/16, y fp16",
+                       "formats": "x MXINT8/%s, W MXINT4/%s, A_out,B_out as x, y fp16" % (qc["x_quantizer"]["block_size"][-1], qc["w_quantizer"]["block_size"][-1]),
                        "sharding": "independent Linear units per rank, no data-path collective"},
             "tokens_per_s": round(tokens_rank * world * args.steps / elapsed, 1),
             "roofline": roofline,

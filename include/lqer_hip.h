@@ -162,9 +162,13 @@ size_t lqer_lowrank_xa_scratch_bytes(int64_t m_max, int64_t rank);
 int lqer_lowrank_xa(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
                     const void* a_t, int a_limbs, void* xaq_bf16, void* scratch,
                     size_t scratch_bytes, void* stream);
+/* scratch of lqer_linear_gemm: 0 unless B_out blocks differ from 16 columns (then the kernel needs
+ * the per-row-block maxima of xAq @ B, computed by a pre-pass it launches itself). */
+size_t lqer_linear_gemm_scratch_bytes(const lqer_linear_desc_t* desc, int64_t m_max);
 int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
                      const void* w_packed, const void* xaq_bf16, const void* b_t, int b_limbs,
-                     const float* bias_q, void* y, int dtype, int64_t ldy, void* stream);
+                     const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
+                     size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,7 +120,13 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
   out->a_t = 3 * rp * Kp * 2;
   out->b_t = 3 * Np * rp * 2;
   out->bias_q = Np * 4;
-  out->workspace = align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256) + (rp ? align_up(xa_scratch_bytes(m_max, rp), 256) : 0);
+  size_t side = 0;
+  if (rp) {
+    const size_t a = xa_scratch_bytes(m_max, rp);
+    const size_t b = d->b_out_fmt.kind == LQER_Q_MXINT ? gemm_scratch_bytes(m_max, d->out_features, make_qp(d->b_out_fmt)) : 0;
+    side = align_up(a > b ? a : b, 256);  // the two scratch uses never overlap in time
+  }
+  out->workspace = align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256) + side;
   return LQER_OK;
 }
 
@@ -189,8 +195,14 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
                              make_qp(d->a_out_fmt), (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+size_t lqer_linear_gemm_scratch_bytes(const lqer_linear_desc_t* d, int64_t m_max) {
+  if (!d || d->rank <= 0 || d->b_out_fmt.kind != LQER_Q_MXINT) return 0;
+  return gemm_scratch_bytes(m_max, d->out_features, make_qp(d->b_out_fmt));
+}
+
 int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
-                     const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy, void* stream) {
+                     const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
+                     size_t scratch_bytes, void* stream) {
   if (!d || !xq || !w_packed || !y || M < 0 || ldy < d->out_features) {
     set_error("linear_gemm: bad argument");
     return LQER_E_INVALID;
@@ -223,7 +235,7 @@ int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, con
   g.b_limbs = b_limbs;
   g.w_mbits = d->w_fmt.width - 1;
   if (lowrank) g.bout = make_qp(d->b_out_fmt);
-  return gemm_dispatch(g, dtype, lowrank, (hipStream_t)stream);
+  return gemm_dispatch(g, dtype, lowrank, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx,
@@ -254,7 +266,8 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
     rc = lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, xa_scratch, lqer_lowrank_xa_scratch_bytes(M, d->rank), stream);
     if (rc) return rc;
   }
-  return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, stream);
+  return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch,
+                          lqer_linear_gemm_scratch_bytes(d, M), stream);
 }
 
 }  // extern "C"

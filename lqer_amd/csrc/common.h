@@ -142,6 +142,8 @@ struct GemmArgs {
   int w_mbits;
   QP bout;
   int tiles_m, tiles_n;
+  float* bout_amax;     // [Mp][bout_nblk] row-block maxima of xAq @ B (B_out blocks other than 16), else null
+  int bout_L, bout_nblk;
 };
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
@@ -155,7 +157,8 @@ int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, h
 int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,
                         const QP& q, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st);
 size_t xa_scratch_bytes(int64_t m_max, int64_t rp);
-int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, hipStream_t st);
+int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
+size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
 
 // ---- error plumbing (host) -------------------------------------------------------------------
 void set_error(const char* fmt, ...);

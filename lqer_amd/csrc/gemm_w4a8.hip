@@ -135,7 +135,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(i)
 #endif
 
-template <int DT, bool LOWRANK, bool BOUT16>
+template <int DT, bool LOWRANK, int BOUT>  // BOUT: 0 pass-through, 1 blocks of 16 (max in registers), 2 any block (max from the pre-pass)
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -223,16 +223,22 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         }
       }
     }
-    if constexpr (BOUT16) {
+    if constexpr (BOUT != 0) {
       const int mb = g.bout.mbits;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          float amax = 0.f;
+          float amax;
+          if constexpr (BOUT == 1) {
+            amax = 0.f;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[i][8 * b + k]));
-          amax = pair32_max(amax);
+            for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[i][8 * b + k]));
+            amax = pair32_max(amax);
+          } else {
+            // block of L columns (L a multiple of 16): its max was reduced by k_bout_amax
+            amax = g.bout_amax[(int64_t)(m0 + i * 32 + l31) * g.bout_nblk + (n0 + wn * 32 + 16 * b) / g.bout_L];
+          }
           const int e = block_exponent(amax, g.bout);  // amax = 0: every element takes the pass-through
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -433,8 +439,41 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   }
 }
 
+// Pre-pass for B_out blocks other than 16 columns: max |xAq @ B| over every (token row, block of L columns),
+// L a multiple of 16.  One wave = one 32 x 32 tile of the product (same MFMA orientation as the GEMM
+// prologue); the per-16-column maxima are folded into amax[m][n / L] with atomicMax on the fp32 bit pattern
+// (non-negative floats order like unsigned integers; max is order-independent, so the result is
+// reproducible).  The buffer is zeroed on the stream before this kernel.
+__global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t tiles_m32 = (g.M + 31) / 32;
+  if (wid >= tiles_m32 * tiles_n32) return;
+  const int tm = (int)(wid / tiles_n32), tn = (int)(wid - (int64_t)tm * tiles_n32);
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  for (int l = 0; l < g.b_limbs; ++l)
+    for (int ks = 0; ks < g.rp / 16; ++ks) {
+      const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + tn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+      const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(tm * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa, acc, 0, 0, 0);
+    }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float amax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[8 * b + k]));
+    amax = pair32_max(amax);
+    if (lh == 0)
+      atomicMax((unsigned int*)g.bout_amax + (int64_t)(tm * 32 + l31) * g.bout_nblk + (tn * 32 + 16 * b) / g.bout_L,
+                __float_as_uint(amax));
+  }
+}
+
 template <int DT>
-static int launch_gemm(const GemmArgs& g, bool lowrank, bool bout16, hipStream_t st) {
+static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st) {
   const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n);
   // raising the dynamic-LDS limit is idempotent; the flag only saves the call on later launches
 #define LQER_GEMM_LAUNCH(LR, BO)                                                                                \
@@ -447,12 +486,14 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, bool bout16, hipStream_t
     }                                                                                                           \
     k_lqer_gemm<DT, LR, BO><<<grid, 512, GEMM_LDS, st>>>(g);                                                    \
   } while (0)
-  if (lowrank && bout16)
-    LQER_GEMM_LAUNCH(true, true);
-  else if (lowrank)
-    LQER_GEMM_LAUNCH(true, false);
+  if (!lowrank)
+    LQER_GEMM_LAUNCH(false, 0);
+  else if (bout == 1)
+    LQER_GEMM_LAUNCH(true, 1);
+  else if (bout == 2)
+    LQER_GEMM_LAUNCH(true, 2);
   else
-    LQER_GEMM_LAUNCH(false, false);
+    LQER_GEMM_LAUNCH(true, 0);
 #undef LQER_GEMM_LAUNCH
   return check_launch("lqer_gemm");
 }
@@ -463,23 +504,49 @@ extern "C" int lqer_debug_set_stamp_buffer(void* p) {
 }
 #endif
 
-int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, hipStream_t st) {
+size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
+  if (bout.kind != LQER_Q_MXINT || bout.block == 16) return 0;
+  const int64_t Np = lqer_padded_n(N);
+  const int64_t L = (bout.block <= 0 || bout.block >= N) ? Np : bout.block;
+  return (size_t)lqer_padded_m(m_max) * ((Np + L - 1) / L) * sizeof(float);
+}
+
+int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st) {
   if (g.M == 0 || g.N == 0) return LQER_OK;
-  bool bout16 = false;
-  if (lowrank) {
-    if (g.bout.kind == LQER_Q_MXINT && g.bout.block == 16)
-      bout16 = true;
-    else if (g.bout.kind != LQER_Q_PASSTHROUGH) {
-      set_error("B_out_quantizer block %d: the fused kernel re-quantizes blocks of 16 output columns only", g.bout.block);
-      return LQER_E_UNSUPPORTED;
+  int bout = 0;
+  if (lowrank && g.bout.kind == LQER_Q_MXINT) {
+    if (g.bout.block == 16) {
+      bout = 1;
+    } else {
+      const int L = (g.bout.block <= 0 || g.bout.block >= g.N) ? g.Np : g.bout.block;
+      if (L % 16 != 0) {
+        set_error("B_out_quantizer block %d: must be a multiple of 16 or cover the row", g.bout.block);
+        return LQER_E_UNSUPPORTED;
+      }
+      bout = 2;
+      g.bout_L = L;
+      g.bout_nblk = (g.Np + L - 1) / L;
+      const size_t need = (size_t)lqer_padded_m(g.M) * g.bout_nblk * sizeof(float);
+      if (!scratch || scratch_bytes < need) {
+        set_error("linear_gemm: scratch %zu B < %zu B for the B_out row-block maxima", scratch_bytes, need);
+        return LQER_E_WORKSPACE;
+      }
+      g.bout_amax = (float*)scratch;
+      (void)hipMemsetAsync(scratch, 0, need, st);
+      const int tiles_n32 = g.Np / 32;
+      const int64_t waves = (int64_t)((g.M + 31) / 32) * tiles_n32;
+      k_bout_amax<<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(g, tiles_n32);
     }
+  } else if (lowrank && g.bout.kind != LQER_Q_PASSTHROUGH) {
+    set_error("B_out_quantizer kind %d not implemented", g.bout.kind);
+    return LQER_E_UNSUPPORTED;
   }
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
   switch (dtype) {
-    case LQER_F32: return launch_gemm<LQER_F32>(g, lowrank, bout16, st);
-    case LQER_F16: return launch_gemm<LQER_F16>(g, lowrank, bout16, st);
-    case LQER_BF16: return launch_gemm<LQER_BF16>(g, lowrank, bout16, st);
+    case LQER_F32: return launch_gemm<LQER_F32>(g, lowrank, bout, st);
+    case LQER_F16: return launch_gemm<LQER_F16>(g, lowrank, bout, st);
+    case LQER_BF16: return launch_gemm<LQER_BF16>(g, lowrank, bout, st);
   }
   set_error("unknown dtype %d", dtype);
   return LQER_E_INVALID;

@@ -151,7 +151,7 @@ def _module_from_case(g, cfgs, name, dtype=torch.float32):
     return mod.to(DEV).to(dtype), t
 
 
-FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged"]
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw"]
 
 
 @pytest.mark.parametrize("name", FWD_CASES)

@@ -54,7 +54,7 @@ def main():
 
     def run(L):
         rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr() if r else None,
-                                bt.data_ptr() if r else None, 1, None, y.data_ptr(), _lib.F16, N, st)
+                                bt.data_ptr() if r else None, 1, None, y.data_ptr(), _lib.F16, N, None, 0, st)
         assert rc == 0, L.lqer_last_error()
 
     times = {p: [] for p, _ in libs}

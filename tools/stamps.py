@@ -21,7 +21,7 @@ y = torch.empty(M, N, dtype=torch.float16, device=dev)
 f8 = _lib.QFmt(1, 8, 16, 8, 127); f4 = _lib.QFmt(1, 4, 16, 8, 127)
 desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
 for _ in range(3):
-    assert L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(), 1, N, None) == 0
+    assert L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(), 1, N, None, 0, None) == 0
 torch.cuda.synchronize()
 b = buf.cpu().view(256, 8, 8).double()
 names = ["s0", "s1", "s2", "s3", "LOAD(issue+waits+barrier)", "COMPUTE issue", "barrier after COMPUTE", "loop overhead"]
