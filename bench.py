@@ -180,12 +180,12 @@ def main():
             xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256
             rp = L.lqer_padded_r(r)
             xscr = xaq + ((Mp * rp * 2 + 255) // 256) * 256
-            nscr = L.lqer_lowrank_xa_scratch_bytes(M, r)
+            nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
             for _ in range(reps):
-                # the three launches of lqer_linear_forward, issued separately so that the dominant
-                # kernel can be bracketed with HIP events on the launch stream
-                _lib.check(L.lqer_quantize_act_mxint(xd.data_ptr(), _lib.F16, M, K, K, C.byref(desc.x_fmt), xq, stream), "quantize_act")
-                _lib.check(L.lqer_lowrank_xa(C.byref(desc), xq, M, p["a_t"].data_ptr(), p["a_limbs"], xaq, xscr, nscr, stream), "lowrank_xa")
+                # the two calls of lqer_linear_forward, issued separately so that the dominant kernel can be
+                # bracketed with HIP events on the launch stream
+                _lib.check(L.lqer_quantize_act_xa(C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"],
+                                                  xq, xaq, xscr, nscr, stream), "quantize_act_xa")
                 ev = timed and launch_no[0] % EV_EVERY == 0
                 launch_no[0] += 1
                 if ev:

@@ -158,7 +158,13 @@ int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype
 
 /* The same, split for callers that share one quantized activation between several Linears
  * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */
-size_t lqer_lowrank_xa_scratch_bytes(int64_t m_max, int64_t rank);
+/* x_quantizer + side path in one call: xq and (rank > 0) xaq.  Uses a fused kernel (the activation
+ * image is quantized and multiplied by A from LDS, never re-read from HBM) when x blocks are 16 and the
+ * padded rank <= 64, the two separate steps otherwise.  scratch as for lqer_lowrank_xa.            */
+int lqer_quantize_act_xa(const lqer_linear_desc_t* desc, const void* x, int dtype, int64_t M,
+                         int64_t ldx, const void* a_t, int a_limbs, void* xq_bf16, void* xaq_bf16,
+                         void* scratch, size_t scratch_bytes, void* stream);
+size_t lqer_lowrank_xa_scratch_bytes(const lqer_linear_desc_t* desc, int64_t m_max);
 int lqer_lowrank_xa(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
                     const void* a_t, int a_limbs, void* xaq_bf16, void* scratch,
                     size_t scratch_bytes, void* stream);

@@ -58,7 +58,8 @@ SIGNATURES = {
     "lqer_pack_lowrank": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "lqer_pack_bias": (_i, [_vp, _i, _i64, _qp, _vp, _vp]),
     "lqer_linear_forward": (_i, [_dp, _vp, _i, _i64, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
-    "lqer_lowrank_xa_scratch_bytes": (_sz, [_i64, _i64]),
+    "lqer_quantize_act_xa": (_i, [_dp, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "lqer_lowrank_xa_scratch_bytes": (_sz, [_dp, _i64]),
     "lqer_lowrank_xa": (_i, [_dp, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),
     "lqer_linear_gemm_scratch_bytes": (_sz, [_dp, _i64]),
     "lqer_linear_gemm": (_i, [_dp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),

@@ -122,7 +122,7 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
   out->bias_q = Np * 4;
   size_t side = 0;
   if (rp) {
-    const size_t a = xa_scratch_bytes(m_max, rp);
+    const size_t a = xa_scratch_bytes(m_max, d->in_features, rp);
     const size_t b = d->b_out_fmt.kind == LQER_Q_MXINT ? gemm_scratch_bytes(m_max, d->out_features, make_qp(d->b_out_fmt)) : 0;
     side = align_up(a > b ? a : b, 256);  // the two scratch uses never overlap in time
   }
@@ -176,8 +176,8 @@ int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fm
   return quantize_dispatch(bias, dtype, 1, N, N, q, o, st);
 }
 
-size_t lqer_lowrank_xa_scratch_bytes(int64_t m_max, int64_t rank) {
-  return rank > 0 ? xa_scratch_bytes(m_max, lqer_padded_r(rank)) : 0;
+size_t lqer_lowrank_xa_scratch_bytes(const lqer_linear_desc_t* d, int64_t m_max) {
+  return (d && d->rank > 0) ? xa_scratch_bytes(m_max, d->in_features, lqer_padded_r(d->rank)) : 0;
 }
 
 int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* a_t, int a_limbs, void* xaq,
@@ -193,6 +193,24 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
   }
   return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, (const bf16_t*)a_t, a_limbs, d->rank,
                              make_qp(d->a_out_fmt), (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
+                         int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d || (!x && M > 0) || !xq || M < 0 || ldx < d->in_features) {
+    set_error("quantize_act_xa: bad argument");
+    return LQER_E_INVALID;
+  }
+  if (d->rank > 0 && a_t && xaq) {
+    if (!fmt_ok(&d->x_fmt, "x_quantizer", 9) || !fmt_ok(&d->a_out_fmt, "A_out_quantizer", 9)) return LQER_E_UNSUPPORTED;
+    const int rc = quant_xa_fused_dispatch(x, dtype, M, d->in_features, ldx, make_qp(d->x_fmt), (bf16_t*)xq,
+                                           (const bf16_t*)a_t, a_limbs, d->rank, make_qp(d->a_out_fmt), (bf16_t*)xaq,
+                                           (float*)scratch, scratch_bytes, (hipStream_t)stream);
+    if (rc != LQER_E_UNSUPPORTED) return rc;
+  }
+  int rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
+  if (rc || d->rank <= 0) return rc;
+  return lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, scratch, scratch_bytes, stream);
 }
 
 size_t lqer_linear_gemm_scratch_bytes(const lqer_linear_desc_t* d, int64_t m_max) {
@@ -260,12 +278,9 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   const size_t rp = lqer_padded_r(d->rank);
   void* xaq = ws + align_up(Mp * Kp * 2, 256);
   void* xa_scratch = ws + align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256);
-  rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
+  rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, xa_scratch,
+                            lqer_lowrank_xa_scratch_bytes(d, M), stream);
   if (rc) return rc;
-  if (d->rank > 0) {
-    rc = lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, xa_scratch, lqer_lowrank_xa_scratch_bytes(M, d->rank), stream);
-    if (rc) return rc;
-  }
   return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch,
                           lqer_linear_gemm_scratch_bytes(d, M), stream);
 }

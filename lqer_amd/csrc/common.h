@@ -156,7 +156,10 @@ int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, in
 int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, hipStream_t st);
 int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,
                         const QP& q, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st);
-size_t xa_scratch_bytes(int64_t m_max, int64_t rp);
+size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp);
+int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, bf16_t* xq,
+                            const bf16_t* a_t, int a_limbs, int64_t r, const QP& qa, bf16_t* xaq, float* scratch,
+                            size_t scratch_bytes, hipStream_t st);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
 

@@ -373,6 +373,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 
   // ---- store ----------------------------------------------------------------------------------
   // per 32x32 tile and quad q: regs 4q..4q+3 = columns n = nb + 8q + 4 lh + (0..3) of token row m
+#ifdef LQER_ABL_NO_STORE
+  if (g.M > 0) {
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i]));
+    return;
+  }
+#endif
   const bool aligned16 = (((uintptr_t)g.y) & 15) == 0;
   const int nb = n0 + wn * 32;
 #pragma unroll

@@ -32,10 +32,13 @@ __host__ __device__ inline XaPlan xa_plan(int64_t M, int64_t Kp) {
   return p;
 }
 
-size_t xa_scratch_bytes(int64_t m_max, int64_t rp) {
-  // row_groups * nchunk <= XA_TARGET_WAVES + row_groups for every M <= m_max
+size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp) {
+  // split-K plan: row_groups * nchunk <= XA_TARGET_WAVES + row_groups for every M <= m_max;
+  // fused plan (k_quant_xa16): row_groups * ceil(Kp / 256) partial tiles
   const int64_t rg = (m_max + XA_ROWS - 1) / XA_ROWS;
-  return (size_t)(XA_TARGET_WAVES + rg) * XA_ROWS * rp * sizeof(float);
+  const int64_t split = XA_TARGET_WAVES + rg;
+  const int64_t fused = rg * ((lqer_padded_k(K) + 255) / 256);
+  return (size_t)(split > fused ? split : fused) * XA_ROWS * rp * sizeof(float);
 }
 
 // One wave = 32 token rows x one K chunk.  Within a 64-k window lane (r = lane & 31, h = lane >> 5) owns the
@@ -162,6 +165,183 @@ __global__ __launch_bounds__(256) void k_xa_reduce_blk(const float* __restrict__
       dst[k] = (bf16_t)exact_bf16_bits(ldexpf(mv, e - q.mbits));
     }
   }
+}
+
+// ---- fused: activation quantize (blocks of 16) + side-path partial GEMM --------------------------------
+// One workgroup = 32 token rows x 256 k.  Phase 1: every lane quantizes two 16-element blocks (consecutive
+// lanes = consecutive 32-byte pieces of a row: fully coalesced), writes the bf16 image to HBM and to an LDS
+// slab (XOR-swizzled 16-byte chunks).  Phase 2: the 4 waves run v_mfma_f32_32x32x16_bf16 over 64 k each,
+// A^T fragments straight from L2; their partial tiles are summed in a fixed order through LDS and written as
+// ONE partial per workgroup.  The activation image is not read back from HBM for the side path.
+constexpr int QX_K = 256;
+
+template <int DT>
+__device__ __forceinline__ void qx_load16(const void* x, int64_t base, int64_t k0, int64_t cols, bool vec, float (&v)[16]) {
+  if (vec && k0 + 16 <= cols) {
+    if constexpr (DT == LQER_F32) {
+      const float4* p = (const float4*)((const float*)x + base + k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 t = p[i];
+        v[4 * i] = t.x, v[4 * i + 1] = t.y, v[4 * i + 2] = t.z, v[4 * i + 3] = t.w;
+      }
+    } else {
+      const uint4* p = (const uint4*)((const bf16_t*)x + base + k0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 t = p[i];
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (DT == LQER_F16) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            const h2 h = __builtin_bit_cast(h2, w[j]);
+            v[8 * i + 2 * j] = (float)h[0], v[8 * i + 2 * j + 1] = (float)h[1];
+          } else {
+            v[8 * i + 2 * j] = __uint_as_float(w[j] << 16), v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (k0 + i < cols) ? load_elem<DT>(x, base + k0 + i) : 0.0f;
+  }
+}
+
+__device__ __forceinline__ int qx_swz(int row, int chunk) { return row * (QX_K * 2) + ((chunk ^ (row & 15)) << 4); }
+
+template <int DT, int NT>
+__global__ __launch_bounds__(256) void k_quant_xa16(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, bool vec,
+                                                    QP q, bf16_t* __restrict__ xq, int64_t Kp,
+                                                    const bf16_t* __restrict__ a_t, int a_limbs, int rp, int row_groups,
+                                                    float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) unsigned char slab[32 * QX_K * 2];   // 16 KiB
+  __shared__ __attribute__((aligned(16))) float red[3 * 32 * 32 * NT];         // waves 1..3 park their tiles here
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunk = (int)((Kp + QX_K - 1) / QX_K);
+  const int rg = blockIdx.x / nchunk, c = blockIdx.x - rg * nchunk;
+  const int64_t kbase = (int64_t)c * QX_K;
+  // ---- phase 1: quantize
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    const int s = tid + s2 * 256;          // 512 blocks of 16: row = s / 16, segment = s % 16
+    const int row = s >> 4, seg = s & 15;
+    const int64_t m = (int64_t)rg * 32 + row, k0 = kbase + seg * 16;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k0 < Kp) {
+      if (m < M && k0 < K) {
+        float v[16];
+        qx_load16<DT>(x, m * ldx, k0, K, vec, v);
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+        if (amax > 0.f) {
+          const int e = block_exponent(amax, q);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const uint32_t lo = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i], e, q), e - q.mbits));
+            const uint32_t hi = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i + 1], e, q), e - q.mbits));
+            w[i] = lo | (hi << 16);
+          }
+        }
+      }
+      uint4* dst = (uint4*)(xq + m * Kp + k0);   // rows up to the padded M are allocated
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    *(uint4*)(slab + qx_swz(row, 2 * seg)) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(uint4*)(slab + qx_swz(row, 2 * seg + 1)) = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+  __syncthreads();
+  // ---- phase 2: partial side GEMM, wave w covers k [64w, 64w + 64) of the slab
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  const int64_t kw = kbase + 64 * wave;
+  if (kw < Kp) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 xf = *(const bf16x8*)(slab + qx_swz(r, (64 * wave + 16 * ks) / 8 + h));
+      for (int l = 0; l < a_limbs; ++l) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int n = t * 32 + r;
+          bf16x8 af = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (n < rp) af = *(const bf16x8*)(a_t + ((int64_t)l * rp + n) * Kp + kw + 16 * ks + 8 * h);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, af, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // fixed-order combine: ((w0 + w1) + w2) + w3
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) red[(((wave - 1) * NT + t) * 16 + j) * 64 + lane] = acc[t][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* dst = part + ((int64_t)c * row_groups + rg) * XA_ROWS * rp;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = t * 32 + r;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float sum = acc[t][j];
+#pragma unroll
+        for (int w2 = 0; w2 < 3; ++w2) sum += red[((w2 * NT + t) * 16 + j) * 64 + lane];
+        if (n < rp) dst[((j & 3) + 8 * (j >> 2) + 4 * h) * rp + n] = sum;
+      }
+    }
+  }
+}
+
+// Fused activation quantize + side path.  Returns LQER_E_UNSUPPORTED (without launching) when the shape or
+// formats are outside what the fused kernel covers; the caller then runs the two separate steps.
+int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, bf16_t* xq,
+                            const bf16_t* a_t, int a_limbs, int64_t r, const QP& qa, bf16_t* xaq, float* scratch,
+                            size_t scratch_bytes, hipStream_t st) {
+  const int64_t Kp = lqer_padded_k(K);
+  const int rp = (int)lqer_padded_r(r);
+  if (qx.kind != LQER_Q_MXINT || qx.block != 16 || qx.mbits > 8 || rp > 64 || qa.kind != LQER_Q_MXINT || qa.mbits > 8)
+    return LQER_E_UNSUPPORTED;
+  const int La = (qa.block <= 0 || qa.block >= rp) ? rp : qa.block;
+  const int G = La / 4;
+  if (rp % La != 0 || La % 4 != 0 || (G & (G - 1)) != 0 || G > 64) return LQER_E_UNSUPPORTED;
+  if (M == 0) return LQER_OK;
+  XaPlan plan;
+  plan.row_groups = (int)((M + XA_ROWS - 1) / XA_ROWS);
+  plan.nchunk = (int)((Kp + QX_K - 1) / QX_K);
+  plan.kc = QX_K;
+  const size_t need = (size_t)plan.nchunk * plan.row_groups * XA_ROWS * rp * sizeof(float);
+  if (!scratch || scratch_bytes < need) return LQER_E_UNSUPPORTED;  // sized for the unfused plan: fall back
+  const int esz = dtype == LQER_F32 ? 4 : 2;
+  const bool vec = ((uintptr_t)x % 16 == 0) && ((ldx * esz) % 16 == 0);
+  const unsigned grid = (unsigned)(plan.row_groups * plan.nchunk);
+#define QX_LAUNCH(DT, NT) k_quant_xa16<DT, NT><<<grid, 256, 0, st>>>(x, M, K, ldx, vec, qx, xq, Kp, a_t, a_limbs, rp, plan.row_groups, scratch)
+  const int nt = (rp + 31) / 32;
+  switch (dtype) {
+    case LQER_F32: if (nt == 1) QX_LAUNCH(LQER_F32, 1); else QX_LAUNCH(LQER_F32, 2); break;
+    case LQER_F16: if (nt == 1) QX_LAUNCH(LQER_F16, 1); else QX_LAUNCH(LQER_F16, 2); break;
+    case LQER_BF16: if (nt == 1) QX_LAUNCH(LQER_BF16, 1); else QX_LAUNCH(LQER_BF16, 2); break;
+    default: set_error("unknown dtype %d", dtype); return LQER_E_INVALID;
+  }
+#undef QX_LAUNCH
+  const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
+  const unsigned grid2 = (unsigned)((items + 255) / 256);
+  switch (G) {
+    case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    default: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+  }
+  return check_launch("quantize_act_xa");
 }
 
 int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,

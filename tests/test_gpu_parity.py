@@ -187,7 +187,7 @@ def test_forward_stages_vs_reference_vectors(ops, golden_fwd):
         xaq = torch.empty(xq.shape[0], rp, dtype=torch.bfloat16, device=DEV)
         desc = mod._desc()
         p = mod._packed
-        nscr = _lib.lib().lqer_lowrank_xa_scratch_bytes(M, mod.rank)
+        nscr = _lib.lib().lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
         scr = torch.empty(nscr, dtype=torch.uint8, device=DEV)
         _lib.check(_lib.lib().lqer_lowrank_xa(C.byref(desc), xq.data_ptr(), M, p["a_t"].data_ptr(), p["a_limbs"], xaq.data_ptr(),
                                               scr.data_ptr(), nscr, None), "xa")
