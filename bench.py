@@ -240,8 +240,15 @@ def main():
             tot_fl += 2.0 * M * K * N + 2.0 * M * r * N
             n_launch += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (a profiler
+        # cannot run inside this process); the committed summary is quoted for the workload it was taken on
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_v12_gemm_traffic.json")
+        if args.workload == "c2" and os.path.exists(tfile):
+            with open(tfile) as fh:
+                traffic = json.load(fh)["traffic_bytes_per_launch"]
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_lqer_gemm",
+                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": "k_lqer_gemm",
                     "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
                     "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4)}
         out = {
