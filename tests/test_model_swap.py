@@ -1,0 +1,108 @@
+"""Module-swap helper: structure on CPU, end-to-end logits parity on the GPU."""
+import pytest
+import torch
+import torch.nn as nn
+
+from bench import MXINT_Q, OPT_Q
+
+
+def _tiny_llama():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=320, max_position_embeddings=128)
+    return LlamaForCausalLM(cfg).eval()
+
+
+def _tiny_opt():
+    from transformers import OPTConfig, OPTForCausalLM
+
+    torch.manual_seed(0)
+    cfg = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=4, vocab_size=200,
+                    max_position_embeddings=64, word_embed_proj_dim=128)
+    return OPTForCausalLM(cfg).eval()
+
+
+def _ab_dict(model, rank, seed=1):
+    from lqer_amd import LinearFlexibleLqer
+    from oracle import lqer_oracle as O
+
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, m in model.named_modules():
+        if isinstance(m, LinearFlexibleLqer):
+            A = O.mxint_quantize(0.02 * torch.randn(m.in_features, rank, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
+            B = O.mxint_quantize(0.02 * torch.randn(rank, m.out_features, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
+            out[f"{name}.A"], out[f"{name}.B"] = A, B
+    return out
+
+
+def test_swap_structure_cpu():
+    from lqer_amd import LinearFlexibleLqer
+    from lqer_amd.models import load_low_rank_dict, quantize_model
+
+    model = _tiny_llama()
+    ref_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    qc = {"linear": MXINT_Q, "model_layer_1": {"self_attn": {"q_proj": dict(MXINT_Q, name="flexible")}}}
+    quantize_model(model, qc, {"linear": {"rank": 16}})
+    l0, l1 = model.model.layers[0], model.model.layers[1]
+    assert isinstance(l0.self_attn.q_proj, LinearFlexibleLqer) and isinstance(l0.mlp.down_proj, LinearFlexibleLqer)
+    assert type(l1.self_attn.q_proj).__name__ == "LinearFlexible"  # per-layer override
+    assert isinstance(model.lm_head, nn.Linear) and not isinstance(model.lm_head, LinearFlexibleLqer)
+    sd = model.state_dict()
+    for k, v in ref_sd.items():  # original weights carried over, same keys
+        assert torch.equal(sd[k], v), k
+    assert sd["model.layers.0.self_attn.q_proj.A"].shape == (256, 16) and sd["model.layers.0.mlp.gate_proj.B"].shape == (16, 512)
+    ab = _ab_dict(model, 16)
+    assert len(ab) == 2 * (14 - 1)
+    assert load_low_rank_dict(model, ab) == []
+    assert torch.equal(model.state_dict()["model.layers.1.mlp.up_proj.A"], ab["model.layers.1.mlp.up_proj.A"])
+    assert load_low_rank_dict(model, {"model.layers.9.mlp.up_proj.A": torch.zeros(1)}) == ["model.layers.9.mlp.up_proj.A"]
+    opt = quantize_model(_tiny_opt(), {"linear": OPT_Q}, {"linear": {"rank": 16}})
+    d0 = opt.model.decoder.layers[0]
+    assert isinstance(d0.fc1, LinearFlexibleLqer) and isinstance(d0.self_attn.out_proj, LinearFlexibleLqer)
+    assert "model.decoder.layers.0.fc2.A" in opt.state_dict()
+    with pytest.raises(ValueError):
+        quantize_model(nn.Sequential(nn.Linear(4, 4)), {"linear": MXINT_Q}, None)
+
+
+class _OracleLinear(nn.Module):
+    """CPU stand-in with the oracle's forward, for the end-to-end comparison only."""
+
+    def __init__(self, src, q_config):
+        super().__init__()
+        self.w, self.b, self.A, self.B, self.qc = src.weight.detach().float().cpu(), None if src.bias is None else src.bias.detach().float().cpu(), src.A.detach().float().cpu(), src.B.detach().float().cpu(), q_config
+
+    def forward(self, x):
+        from oracle import lqer_oracle as O
+
+        return O.lqer_linear_forward(x, self.w, self.b, self.A, self.B, self.qc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["llama", "opt"])
+def test_end_to_end_logits_vs_oracle(family):
+    from lqer_amd import LinearFlexibleLqer
+    from lqer_amd.models import load_low_rank_dict, quantize_model
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    qc = MXINT_Q if family == "llama" else OPT_Q
+    model = quantize_model(_tiny_llama() if family == "llama" else _tiny_opt(), {"linear": qc}, {"linear": {"rank": 16}})
+    load_low_rank_dict(model, _ab_dict(model, 16))
+    # CPU twin whose projections run the oracle, built from the same parameters before they are quantized in place
+    import copy
+
+    twin = copy.deepcopy(model)
+    for name, m in list(twin.named_modules()):
+        if isinstance(m, LinearFlexibleLqer):
+            parent = twin.get_submodule(name.rsplit(".", 1)[0])
+            setattr(parent, name.rsplit(".", 1)[1], _OracleLinear(m, qc))
+    ids = torch.randint(0, 200, (2, 24), generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        ref = twin(input_ids=ids).logits
+        got = model.to("cuda:0")(input_ids=ids.to("cuda:0")).logits.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).norm() / ref.norm()
+    assert err <= 1e-4, float(err)  # fp32 model: only accumulation order differs, layer after layer
