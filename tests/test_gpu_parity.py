@@ -231,6 +231,31 @@ def test_forward_llama_shape_vs_oracle(ops, dtype, tol):
     assert err <= tol, float(err)
 
 
+@pytest.mark.parametrize("K,N,r,bias,cfg", [(4096, 11008, 32, False, "mxint"), (11008, 4096, 32, False, "mxint"),
+                                            (1000, 1500, 48, True, "opt"), (5120, 1280, 64, False, "int")])
+def test_forward_model_shapes_vs_oracle(ops, K, N, r, bias, cfg):
+    """Llama-7B MLP shapes (N and K = 11008 = 43 * 256), a ragged shape (K, N, rank not multiples of the tile
+    constants, bias in blocks of 16) and the INT configuration (per-token activation blocks, weight blocks of
+    128, unquantized A/B) against the oracle at M = 200."""
+    import lqer_amd
+    from bench import INT_Q, MXINT_Q, OPT_Q, make_case
+
+    qc = {"mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q}[cfg]
+    M = 200
+    case = make_case(M, K, N, r, seed=11, bias=bias, quantize_ab=cfg != "int")
+    x, W, A, B = case[:4]
+    b = case[4] if bias else None
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = b
+    mod.load_state_dict(sd)
+    y = mod.to(DEV)(x.to(DEV)).cpu()
+    ref = O.lqer_linear_forward(x, W, b, A, B, qc)
+    err = (y - ref).norm() / ref.norm()
+    assert err <= 2e-5, float(err)
+
+
 def test_size_independent_properties_full_size(ops):
     """At BASELINE's full size (M=2048, 4096x4096, r=32): rows and output columns are independent,
     so a row permutation, a row split and a column split must reproduce the same bits."""
