@@ -30,7 +30,10 @@
 namespace lqer {
 
 constexpr int BM = 128, BN = 256, BK = 64;
-constexpr int DEPTH = 3;                              // k-steps of prefetch in flight
+#ifndef LQER_DEPTH
+#define LQER_DEPTH 3
+#endif
+constexpr int DEPTH = LQER_DEPTH;                     // k-steps of prefetch in flight
 constexpr int NSLOT = DEPTH + 1;                      // LDS ring slots
 constexpr int A_SLOT = BM * BK * 2;                   // 16 KiB  activation tile, bf16
 constexpr int R_SLOT = (BN / 16) * LQER_PANEL_BYTES;  // 9216 B  packed weight panels (4-bit codes + exponents)
@@ -297,6 +300,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     // ---- LOAD(kt): prefetch issue, then ONE asm statement with the 18 LDS reads, the waits and the barrier.
     // (Reads and their wait must not be separate statements: hipcc treats an asm output as valid when the
     // statement ends and was seen to copy such registers to others BEFORE the separate wait - stale data.)
+    // the loading wave gets issue priority over its computing SIMD partner (measured -5 %: the LOAD section
+    // is a chain of issue-limited LDS-DMA / LDS reads, the partner's MFMAs only need an issue slot every 32 cycles)
+    __builtin_amdgcn_s_setprio(1);
     if (kt + DEPTH < nk) issue_loads(kt + DEPTH, slot_new);
     bf16x8 xa[4][4];  // [ks][m tile]
     u32x4 wr;
@@ -338,6 +344,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 #undef LQER_LOAD_ASM
     }
 #endif
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4);  // LOAD: issue + waits + barrier
     // ---- COMPUTE(kt)
