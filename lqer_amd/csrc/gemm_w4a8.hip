@@ -25,6 +25,8 @@
 //  * the two waves of a SIMD run half a k-step apart (LOAD / COMPUTE ping-pong, see the main loop).
 //  * tiles are numbered so that each of the 8 XCDs works on a contiguous run of tiles (same token
 //    rows -> the activation slab stays in that XCD's L2).
+#include <type_traits>
+
 #include "common.h"
 
 namespace lqer {
@@ -174,19 +176,20 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   const auto w_rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
   const auto w_rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(w_base + (int64_t)nk * LQER_PANEL_BYTES), 0, 0x7fffffff, 0x00020000);
   const int w_voff = (lane < 36 ? lane : 35) * 16;
+  unsigned char* const a_dst0 = smem + OFF_A + wave * 16 * 128;                 // + slot * A_SLOT + piece * 1024
+  unsigned char* const w_dst0 = smem + OFF_R + 2 * wave * LQER_PANEL_BYTES;       // + slot * R_SLOT + panel * 576
   auto issue_loads = [&](int kt, int slot) {  // 4 LDS-DMA instructions per wave
 #ifndef LQER_ABL_NO_A_LOAD
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      unsigned char* dst = smem + OFF_A + slot * A_SLOT + (wave * 16 + i * 8) * 128;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)dst, 16, a_voff[i], kt * (BK * 2), 0, 0);
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(a_dst0 + slot * A_SLOT + i * 1024), 16, a_voff[i],
+                                               kt * (BK * 2), 0, 0);
 #endif
 #ifndef LQER_ABL_NO_W_LOAD
-    unsigned char* dst = smem + OFF_R + slot * R_SLOT + 2 * wave * LQER_PANEL_BYTES;
     if (lane < 36) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc0, (lds_void*)dst, 16, w_voff, kt * LQER_PANEL_BYTES, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc1, (lds_void*)(dst + LQER_PANEL_BYTES), 16, w_voff, kt * LQER_PANEL_BYTES, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc0, (lds_void*)(w_dst0 + slot * R_SLOT), 16, w_voff, kt * LQER_PANEL_BYTES, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc1, (lds_void*)(w_dst0 + slot * R_SLOT + LQER_PANEL_BYTES), 16, w_voff,
+                                               kt * LQER_PANEL_BYTES, 0, 0);
     }
 #endif
   };
@@ -287,15 +290,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if (late) asm volatile("s_barrier" ::: "memory");
-  int slot = 0;
 #ifdef LQER_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-  // One k-step.
-  auto step = [&](int kt) {
-    const uint32_t oa = slot * A_SLOT, orw = slot * R_SLOT;
-    const int slot_new = slot == 0 ? NSLOT - 1 : slot - 1;  // (slot + DEPTH) % NSLOT
+  // One k-step.  The ring slot is a compile-time constant (the loop below is unrolled by the ring size), so
+  // every LDS address is a per-lane base register + an immediate offset and the LDS-DMA destinations are
+  // constants; STEADY = not within DEPTH + 1 steps of the end: no tail checks, always vmcnt(8).
+  auto step = [&](int kt, auto slot_c, auto steady_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    constexpr int slot_new = SLOT == 0 ? NSLOT - 1 : SLOT - 1;  // (slot + DEPTH) % NSLOT
     STAMP(7);
     // ---- LOAD(kt): prefetch issue, then ONE asm statement with the 18 LDS reads, the waits and the barrier.
     // (Reads and their wait must not be separate statements: hipcc treats an asm output as valid when the
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     // the loading wave gets issue priority over its computing SIMD partner (measured -5 %: the LOAD section
     // is a chain of issue-limited LDS-DMA / LDS reads, the partner's MFMAs only need an issue slot every 32 cycles)
     __builtin_amdgcn_s_setprio(1);
-    if (kt + DEPTH < nk) issue_loads(kt + DEPTH, slot_new);
+    if (STEADY || kt + DEPTH < nk) issue_loads(kt + DEPTH, slot_new);
     bf16x8 xa[4][4];  // [ks][m tile]
     u32x4 wr;
     uint32_t we;
@@ -315,27 +320,26 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #else
     {
-      const uint32_t aw = fw_addr + orw, ae = fe_addr + orw;
-      const uint32_t aa0 = fa_addr[0] + oa, aa1 = fa_addr[1] + oa, aa2 = fa_addr[2] + oa, aa3 = fa_addr[3] + oa;
       const int younger = nk - 2 - kt;  // batches issued for steps beyond kt+1: they may stay in flight
 #define LQER_LOAD_ASM(VM)                                                                                         \
   asm volatile(                                                                                                   \
-      "ds_read_b128 %0, %18\n\tds_read_b32 %1, %19 offset:512\n\t"                                                 \
-      "ds_read_b128 %2, %20\n\tds_read_b128 %3, %20 offset:4096\n\tds_read_b128 %4, %20 offset:8192\n\t"           \
-      "ds_read_b128 %5, %20 offset:12288\n\t"                                                                      \
-      "ds_read_b128 %6, %21\n\tds_read_b128 %7, %21 offset:4096\n\tds_read_b128 %8, %21 offset:8192\n\t"           \
-      "ds_read_b128 %9, %21 offset:12288\n\t"                                                                      \
-      "ds_read_b128 %10, %22\n\tds_read_b128 %11, %22 offset:4096\n\tds_read_b128 %12, %22 offset:8192\n\t"        \
-      "ds_read_b128 %13, %22 offset:12288\n\t"                                                                     \
-      "ds_read_b128 %14, %23\n\tds_read_b128 %15, %23 offset:4096\n\tds_read_b128 %16, %23 offset:8192\n\t"        \
-      "ds_read_b128 %17, %23 offset:12288\n\t"                                                                     \
+      "ds_read_b128 %0, %18 offset:%c25\n\tds_read_b32 %1, %19 offset:%c25+512\n\t"                                \
+      "ds_read_b128 %2, %20 offset:%c24\n\tds_read_b128 %3, %20 offset:%c24+4096\n\t"                              \
+      "ds_read_b128 %4, %20 offset:%c24+8192\n\tds_read_b128 %5, %20 offset:%c24+12288\n\t"                        \
+      "ds_read_b128 %6, %21 offset:%c24\n\tds_read_b128 %7, %21 offset:%c24+4096\n\t"                              \
+      "ds_read_b128 %8, %21 offset:%c24+8192\n\tds_read_b128 %9, %21 offset:%c24+12288\n\t"                        \
+      "ds_read_b128 %10, %22 offset:%c24\n\tds_read_b128 %11, %22 offset:%c24+4096\n\t"                            \
+      "ds_read_b128 %12, %22 offset:%c24+8192\n\tds_read_b128 %13, %22 offset:%c24+12288\n\t"                      \
+      "ds_read_b128 %14, %23 offset:%c24\n\tds_read_b128 %15, %23 offset:%c24+4096\n\t"                            \
+      "ds_read_b128 %16, %23 offset:%c24+8192\n\tds_read_b128 %17, %23 offset:%c24+12288\n\t"                      \
       "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                                           \
       : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]), \
         "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),      \
         "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])                        \
-      : "v"(aw), "v"(ae), "v"(aa0), "v"(aa1), "v"(aa2), "v"(aa3)                                                   \
+      : "v"(fw_addr), "v"(fe_addr), "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3]),            \
+        "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT)                                                                     \
       : "memory")
-      if (younger >= 2)
+      if (STEADY || younger >= 2)
         LQER_LOAD_ASM(8);
       else if (younger == 1)
         LQER_LOAD_ASM(4);
@@ -369,9 +373,21 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     STAMP(6);  // barrier after COMPUTE
-    slot = slot == NSLOT - 1 ? 0 : slot + 1;
   };
-  for (int kt = 0; kt < nk; ++kt) step(kt);
+  using std::integral_constant;
+  int kt = 0;
+  for (; kt + NSLOT + DEPTH <= nk; kt += NSLOT) {  // steady state: 4 steps per trip, slots 0..3
+    step(kt, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    step(kt + 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+    step(kt + 2, integral_constant<int, 2>{}, integral_constant<bool, true>{});
+    step(kt + 3, integral_constant<int, 3>{}, integral_constant<bool, true>{});
+  }
+  for (; kt < nk; kt += NSLOT) {  // last steps, with the tail checks (kt is a multiple of 4 here)
+    step(kt, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+    if (kt + 1 < nk) step(kt + 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    if (kt + 2 < nk) step(kt + 2, integral_constant<int, 2>{}, integral_constant<bool, false>{});
+    if (kt + 3 < nk) step(kt + 3, integral_constant<int, 3>{}, integral_constant<bool, false>{});
+  }
   if (!late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_STAMPS
   if (g_stamp_buf && lane == 0)
