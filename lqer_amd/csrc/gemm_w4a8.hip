@@ -124,6 +124,11 @@ __device__ __forceinline__ void lds_wait(u32x2& a, int& b) {
 }
 
 #ifdef LQER_STAMPS
+#define LQER_LOAD_BARRIER ""  // the diagnostic build stamps between the waits and the barrier
+#else
+#define LQER_LOAD_BARRIER "\n\ts_barrier"
+#endif
+#ifdef LQER_STAMPS
 // Diagnostic build only: per-section cycle sums (s_memtime) of the main loop, written to a buffer that
 // nothing else reads.  Never quote this build's run time (the stamps serialise the sections).
 __device__ unsigned long long* g_stamp_buf = nullptr;
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     // is a chain of issue-limited LDS-DMA / LDS reads, the partner's MFMAs only need an issue slot every 32 cycles)
     __builtin_amdgcn_s_setprio(1);
     if (STEADY || kt + DEPTH < nk) issue_loads(kt + DEPTH, slot_new);
+    STAMP(0);  // LDS-DMA issue
     bf16x8 xa[4][4];  // [ks][m tile]
     u32x4 wr;
     uint32_t we;
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       "ds_read_b128 %12, %22 offset:%c24+8192\n\tds_read_b128 %13, %22 offset:%c24+12288\n\t"                      \
       "ds_read_b128 %14, %23 offset:%c24\n\tds_read_b128 %15, %23 offset:%c24+4096\n\t"                            \
       "ds_read_b128 %16, %23 offset:%c24+8192\n\tds_read_b128 %17, %23 offset:%c24+12288\n\t"                      \
-      "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                                           \
+      "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" LQER_LOAD_BARRIER                                                      \
       : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]), \
         "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),      \
         "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])                        \
@@ -347,6 +353,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         LQER_LOAD_ASM(0);
 #undef LQER_LOAD_ASM
     }
+#endif
+#ifdef LQER_STAMPS
+    STAMP(1);  // LDS reads + waits
+    asm volatile("s_barrier" ::: "memory");
 #endif
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);

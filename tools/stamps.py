@@ -6,10 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lqer_amd import _lib
 from tools.ab_gemm import load
 L = load(sys.argv[1])
+NW = int(sys.argv[2]) if len(sys.argv) > 2 else 8  # waves per workgroup of the build
 L.lqer_debug_set_stamp_buffer.argtypes = [C.c_void_p]
 M, K, N, r = 2048, 4096, 4096, 32
 dev = torch.device("cuda:0")
-buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(256 * NW * 8, dtype=torch.int64, device=dev)
 assert L.lqer_debug_set_stamp_buffer(buf.data_ptr()) == 0
 xq = torch.randn(M, K).to(torch.bfloat16).to(dev)
 wp = torch.randint(0, 256, ((N // 16) * (K // 64) * 576,), dtype=torch.uint8)
@@ -23,9 +24,9 @@ desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
 for _ in range(3):
     assert L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(), 1, N, None, 0, None) == 0
 torch.cuda.synchronize()
-b = buf.cpu().view(256, 8, 8).double()
-names = ["s0", "s1", "s2", "s3", "LOAD(issue+waits+barrier)", "COMPUTE issue", "barrier after COMPUTE", "loop overhead"]
+b = buf.cpu().view(256, NW, 8).double()
+names = ["DMA issue", "LDS reads+waits", "s2", "s3", "LOAD barrier", "COMPUTE issue", "barrier after COMPUTE", "loop overhead"]
 steps = K // 64
-for grp, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+for grp, sl in [(f"waves {a}-{a+3}", slice(a, a + 4)) for a in range(0, NW, 4)]:
     m = b[:, sl, :].mean(dim=(0, 1)) / steps
     print(grp, "cycles per k-step:", ", ".join(f"{n} {v:.0f}" for n, v in zip(names, m.tolist())), f"| total {m.sum():.0f}")
