@@ -176,14 +176,20 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_voff[i] = (row * g.Kp + chunk * 8) * 2;
   }
-  // weights: wave w stages panels 2w, 2w+1 of the tile (a panel = 16 rows x 64 k = 576 B = lanes 0..35 x 16 B)
-  const uint8_t* w_base = g.wp + ((int64_t)(n0 / 16 + 2 * wave) * nk) * LQER_PANEL_BYTES;
-  const auto w_rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
-  const auto w_rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(w_base + (int64_t)nk * LQER_PANEL_BYTES), 0, 0x7fffffff, 0x00020000);
-  const int w_voff = (lane < 36 ? lane : 35) * 16;
-  unsigned char* const a_dst0 = smem + OFF_A + wave * 16 * 128;                 // + slot * A_SLOT + piece * 1024
-  unsigned char* const w_dst0 = smem + OFF_R + 2 * wave * LQER_PANEL_BYTES;       // + slot * R_SLOT + panel * 576
-  auto issue_loads = [&](int kt, int slot) {  // 4 LDS-DMA instructions per wave
+  // weights: the 16 panels of a k-step (16 x 576 B) are contiguous in the ring slot and are filled by nine 1-KiB
+  // LDS-DMAs with per-lane source offsets (576 = 36 x 16: a lane's 16 bytes lie inside one panel): wave w issues
+  // piece w, wave 0 also piece 8 - 25 LDS-DMA instructions per k-step and workgroup, all with full EXEC.
+  const uint8_t* w_base = g.wp + ((int64_t)(n0 / 16) * nk) * LQER_PANEL_BYTES;
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+  auto w_piece_voff = [&](int piece) {
+    const int byte = piece * 1024 + lane * 16;
+    const int pnl = byte / LQER_PANEL_BYTES;
+    return pnl * nk * LQER_PANEL_BYTES + (byte - pnl * LQER_PANEL_BYTES);
+  };
+  const int w_voff = w_piece_voff(wave), w_voff8 = w_piece_voff(8);
+  unsigned char* const a_dst0 = smem + OFF_A + wave * 16 * 128;  // + slot * A_SLOT + piece * 1024
+  unsigned char* const w_dst0 = smem + OFF_R + wave * 1024;      // + slot * R_SLOT
+  auto issue_loads = [&](int kt, int slot) {  // 3 LDS-DMA instructions per wave (wave 0: 4)
 #ifndef LQER_ABL_NO_A_LOAD
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -191,11 +197,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
                                                kt * (BK * 2), 0, 0);
 #endif
 #ifndef LQER_ABL_NO_W_LOAD
-    if (lane < 36) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc0, (lds_void*)(w_dst0 + slot * R_SLOT), 16, w_voff, kt * LQER_PANEL_BYTES, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc1, (lds_void*)(w_dst0 + slot * R_SLOT + LQER_PANEL_BYTES), 16, w_voff,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(w_dst0 + slot * R_SLOT), 16, w_voff, kt * LQER_PANEL_BYTES, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_R + 8192 + slot * R_SLOT), 16, w_voff8,
                                                kt * LQER_PANEL_BYTES, 0, 0);
-    }
 #endif
   };
   // fragment read addresses (slot 0).  Activation: row = wave tile row + lane & 31, chunk 2 ks + (lane >> 5),
@@ -281,16 +286,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   //   waves 0-3:    ... | LOAD(kt)  | COMPUTE(kt) | LOAD(kt+1)  | ...
   //   waves 4-7:    ... | COMP(kt-1)| LOAD(kt)    | COMPUTE(kt) | ...
   // RAW: every wave ends LOAD(kt-1) with a counted vmcnt that retires its own loads of step kt (the
-  // DEPTH-1 younger batches of 4 stay in flight) and then passes a barrier (2kt-2 or 2kt-1) before
+  // DEPTH-1 younger batches of 3 stay in flight) and then passes a barrier (2kt-2 or 2kt-1) before
   // anyone starts LOAD(kt).  WAR: slot (kt+3) % 4 held step kt-1, last read in LOAD(kt-1) of waves 4-7,
   // which ends (lgkmcnt(0)) before barrier 2kt-1; the overwriting loads are issued after it.
   const bool late = wave >= 4;
   {
     const int issued = nk < DEPTH ? nk : DEPTH;
+    // (a batch = this wave's 3 loads of one k-step; wave 0 has 4 and waits a little more than it must)
     if (issued >= 3)
-      asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
     else if (issued == 2)
-      asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 #endif
   // One k-step.  The ring slot is a compile-time constant (the loop below is unrolled by the ring size), so
   // every LDS address is a per-lane base register + an immediate offset and the LDS-DMA destinations are
-  // constants; STEADY = not within DEPTH + 1 steps of the end: no tail checks, always vmcnt(8).
+  // constants; STEADY = not within DEPTH + 1 steps of the end: no tail checks, always vmcnt(6).
   auto step = [&](int kt, auto slot_c, auto steady_c) {
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr bool STEADY = decltype(steady_c)::value;
@@ -346,9 +352,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT)                                                                     \
       : "memory")
       if (STEADY || younger >= 2)
-        LQER_LOAD_ASM(8);
+        LQER_LOAD_ASM(6);
       else if (younger == 1)
-        LQER_LOAD_ASM(4);
+        LQER_LOAD_ASM(3);
       else
         LQER_LOAD_ASM(0);
 #undef LQER_LOAD_ASM
