@@ -120,6 +120,31 @@ __device__ __forceinline__ float row16_max(float v) {
 }
 
 
+// Expand 8 sign-magnitude 4-bit codes (one 32-bit word = 8 consecutive k of one weight row; nibble p
+// holds k = p/2 for even p, 4 + p/2 for odd p) times the block scale into one MFMA operand fragment:
+// magnitude -> fp8 (e4m3) byte through a v_perm_b32 table, sign bit OR-ed in, then
+// v_cvt_scalef32_pk_bf16_fp8 converts two elements per instruction and applies the scale.
+// 14 VALU ops per 8 weights; every step is exact (integers 0..7 and powers of two).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+__device__ __forceinline__ bf16x8 expand_frag(uint32_t word, uint32_t scale_bits) {
+  const float scale = __uint_as_float(scale_bits);
+  constexpr uint32_t LUT_LO = 0x44403800u, LUT_HI = 0x4E4C4A48u;  // e4m3 bytes of 0,1,2,3 | 4,5,6,7
+  const uint32_t t = word >> 4;
+  uint32_t fe = __builtin_amdgcn_perm(LUT_HI, LUT_LO, word & 0x07070707u);  // k 0..3
+  uint32_t fo = __builtin_amdgcn_perm(LUT_HI, LUT_LO, t & 0x07070707u);     // k 4..7
+  fe |= (word << 4) & 0x80808080u;
+  fo |= word & 0x80808080u;
+  u32x4 r;
+  r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, false));
+  r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, true));
+  r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, false));
+  r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, true));
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+
 // ---- cross-file declarations ----------------------------------------------------------------------
 struct QuantOut {
   float* deq;      // [rows, cols] or null
@@ -162,6 +187,8 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
                             size_t scratch_bytes, hipStream_t st);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
+bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
+int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 
 // ---- error plumbing (host) -------------------------------------------------------------------
 void set_error(const char* fmt, ...);

@@ -50,30 +50,6 @@ __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >>
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 
-// Expand 8 sign-magnitude 4-bit codes (one 32-bit word = 8 consecutive k of one weight row; nibble p
-// holds k = p/2 for even p, 4 + p/2 for odd p) times the block scale into one MFMA operand fragment:
-// magnitude -> fp8 (e4m3) byte through a v_perm_b32 table, sign bit OR-ed in, then
-// v_cvt_scalef32_pk_bf16_fp8 converts two elements per instruction and applies the scale.
-// 14 VALU ops per 8 weights; every step is exact (integers 0..7 and powers of two).
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-__device__ __forceinline__ bf16x8 expand_frag(uint32_t word, uint32_t scale_bits) {
-  const float scale = __uint_as_float(scale_bits);
-  constexpr uint32_t LUT_LO = 0x44403800u, LUT_HI = 0x4E4C4A48u;  // e4m3 bytes of 0,1,2,3 | 4,5,6,7
-  const uint32_t t = word >> 4;
-  uint32_t fe = __builtin_amdgcn_perm(LUT_HI, LUT_LO, word & 0x07070707u);  // k 0..3
-  uint32_t fo = __builtin_amdgcn_perm(LUT_HI, LUT_LO, t & 0x07070707u);     // k 4..7
-  fe |= (word << 4) & 0x80808080u;
-  fo |= word & 0x80808080u;
-  u32x4 r;
-  r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, false));
-  r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, true));
-  r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, false));
-  r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, true));
-  return __builtin_bit_cast(bf16x8, r);
-}
-
 // max over lanes l and l^32
 __device__ __forceinline__ float pair32_max(float v) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -586,6 +562,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
     set_error("B_out_quantizer kind %d not implemented", g.bout.kind);
     return LQER_E_UNSUPPORTED;
   }
+  if (smallm_eligible(g, bout)) return smallm_dispatch(g, dtype, lowrank, bout, st);  // decode sizes: HBM-bound variant
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
   switch (dtype) {

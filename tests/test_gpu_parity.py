@@ -256,6 +256,33 @@ def test_forward_model_shapes_vs_oracle(ops, K, N, r, bias, cfg):
     assert err <= 2e-5, float(err)
 
 
+@pytest.mark.parametrize("M", [1, 16, 17, 33, 48, 64, 65])
+@pytest.mark.parametrize("cfg,K,N,r,bias", [("mxint", 4096, 4096, 32, False), ("opt", 1000, 1500, 48, True)])
+def test_small_m_kernel_vs_oracle(ops, M, cfg, K, N, r, bias):
+    """Decode sizes: M <= 64 runs the HBM-bound small-M kernel (one workgroup per 16 output columns, 1..4 token
+    tiles of 16), M = 65 the tile kernel; fp16 in/out against the oracle at the north star's tolerance."""
+    import lqer_amd
+    from bench import MXINT_Q, OPT_Q, make_case
+
+    qc = {"mxint": MXINT_Q, "opt": OPT_Q}[cfg]
+    case = make_case(M, K, N, r, seed=5, bias=bias)
+    x, W, A, B = case[:4]
+    b = case[4] if bias else None
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = b
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).half()
+    xin = x.half()
+    y = mod(xin.to(DEV)).float().cpu()
+    ref = O.lqer_linear_forward(xin.float(), W.half().float(), b.half().float() if bias else None, A.half().float(),
+                                B.half().float(), qc)
+    assert y.shape == ref.shape
+    err = (y - ref).norm() / ref.norm()
+    assert err <= 1e-3, float(err)
+
+
 def test_size_independent_properties_full_size(ops):
     """At BASELINE's full size (M=2048, 4096x4096, r=32): rows and output columns are independent,
     so a row permutation, a row split and a column split must reproduce the same bits."""
