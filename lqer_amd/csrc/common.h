@@ -102,6 +102,39 @@ __device__ __forceinline__ float mxint_mantissa(float x, int e, const QP& q) {
   return fabsf(x) <= 1e-8f ? 0.0f : copysignf(m, x);
 }
 
+// The bf16 image of 16 values that share the block exponent e, in packed-fp32 arithmetic (v_pk_add/fma/mul_f32: two
+// elements per instruction) - the same results as mxint_mantissa + ldexpf element by element (block_fp.py:55-65):
+//   t = |x| + 1e-9;  m = min(rne(t * 2^(mbits-e)), mmax);  value = sign(x) * m * 2^(e-mbits);  |x| <= 1e-8 -> 0.
+// rne(t s) = fma(t, s, 1.5 * 2^23) - 1.5 * 2^23: t s is exact (s is a power of two), the fma rounds once to an integer
+// (t s < 2^22 because t <= 2^e + 1e-9).  Needs s and 1/s to be normal floats: mxint16_fast_ok(e, q).
+__device__ __forceinline__ bool mxint16_fast_ok(int e, const QP& q) { return q.mbits - e <= 126 && e - q.mbits >= -126; }
+
+template <bool FLUSH_TINY>  // false when the input type cannot hold a non-zero |x| <= 1e-8 (fp16)
+__device__ __forceinline__ void mxint16_bf16_fast(const float (&v)[16], int e, const QP& q, uint32_t (&w)[8]) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  const float s = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
+  const float inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
+  const f2 magic = {12582912.0f, 12582912.0f}, eps = {1e-9f, 1e-9f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f2 x = {v[2 * i], v[2 * i + 1]};
+    const f2 a = {fabsf(x[0]), fabsf(x[1])};
+    const f2 t = a + eps;
+    f2 r = __builtin_elementwise_fma(t, (f2){s, s}, magic) - magic;
+    r[0] = fminf(r[0], q.mmax);
+    r[1] = fminf(r[1], q.mmax);
+    const f2 val = r * (f2){inv, inv};
+    // sign of x over the magnitude; the bf16 image is the high half of each (exactly representable) value
+    uint32_t b0 = (__float_as_uint(val[0]) & 0x7fffffffu) | (__float_as_uint(x[0]) & 0x80000000u);
+    uint32_t b1 = (__float_as_uint(val[1]) & 0x7fffffffu) | (__float_as_uint(x[1]) & 0x80000000u);
+    if constexpr (FLUSH_TINY) {
+      b0 = a[0] <= 1e-8f ? 0u : b0;
+      b1 = a[1] <= 1e-8f ? 0u : b1;
+    }
+    w[i] = (b0 >> 16) | (b1 & 0xffff0000u);
+  }
+}
+
 // bf16 bits of an exactly representable fp32 value (low 16 bits are zero by construction).
 __device__ __forceinline__ uint32_t exact_bf16_bits(float v) { return __float_as_uint(v) >> 16; }
 

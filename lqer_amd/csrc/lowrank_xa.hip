@@ -222,6 +222,18 @@ __global__ __launch_bounds__(256) void k_quant_xa16(const void* __restrict__ x, 
   const int nchunk = (int)((Kp + QX_K - 1) / QX_K);
   const int rg = blockIdx.x / nchunk, c = blockIdx.x - rg * nchunk;
   const int64_t kbase = (int64_t)c * QX_K;
+  // the wave's A^T fragments (limb 0) are fetched first, so their L2 latency overlaps the activation loads
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t kw = kbase + 64 * wave;
+  bf16x8 af0[4][NT];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = t * 32 + r;
+      af0[ks][t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (n < rp && kw < Kp && a_limbs > 0) af0[ks][t] = *(const bf16x8*)(a_t + (int64_t)n * Kp + kw + 16 * ks + 8 * h);
+    }
   // ---- phase 1: quantize
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
@@ -238,11 +250,15 @@ __global__ __launch_bounds__(256) void k_quant_xa16(const void* __restrict__ x, 
         for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
         if (amax > 0.f) {
           const int e = block_exponent(amax, q);
+          if (mxint16_fast_ok(e, q)) {
+            mxint16_bf16_fast<DT != LQER_F16>(v, e, q, w);
+          } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const uint32_t lo = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i], e, q), e - q.mbits));
-            const uint32_t hi = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i + 1], e, q), e - q.mbits));
-            w[i] = lo | (hi << 16);
+            for (int i = 0; i < 8; ++i) {
+              const uint32_t lo = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i], e, q), e - q.mbits));
+              const uint32_t hi = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i + 1], e, q), e - q.mbits));
+              w[i] = lo | (hi << 16);
+            }
           }
         }
       }
@@ -255,18 +271,18 @@ __global__ __launch_bounds__(256) void k_quant_xa16(const void* __restrict__ x, 
   }
   __syncthreads();
   // ---- phase 2: partial side GEMM, wave w covers k [64w, 64w + 64) of the slab
-  const int r = lane & 31, h = lane >> 5;
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
-  const int64_t kw = kbase + 64 * wave;
   if (kw < Kp) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 xf = *(const bf16x8*)(slab + qx_swz(r, (64 * wave + 16 * ks) / 8 + h));
-      for (int l = 0; l < a_limbs; ++l) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, af0[ks][t], acc[t], 0, 0, 0);
+      for (int l = 1; l < a_limbs; ++l) {  // fp16 / fp32 A: further exact bf16 limbs
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int n = t * 32 + r;

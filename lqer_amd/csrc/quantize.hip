@@ -51,6 +51,14 @@ __device__ __forceinline__ void load16(const void* x, int64_t base, int64_t k0, 
 // Quantize 16 values that share exponent e (or are all zero when !any) and emit every requested image.
 __device__ __forceinline__ void emit16(const float (&v)[16], bool any, int e, const QP& q, const QuantOut& o,
                                        int64_t row, int64_t k0, int64_t cols) {
+  if (o.xq && !o.deq && !o.codes && any && mxint16_fast_ok(e, q)) {  // the activation image alone: packed-fp32 route
+    uint32_t w[8];
+    mxint16_bf16_fast<true>(v, e, q, w);
+    uint4* dst = (uint4*)(o.xq + row * o.cols_p + k0);
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    return;
+  }
   float m[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) m[i] = any ? mxint_mantissa(v[i], e, q) : 0.0f;
