@@ -56,7 +56,11 @@ WORKLOADS = {
            INT_Q, [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)], 5),
     "c5": ("OPT-6.7B 6 projections x 32 layers rank128 W4A8-MXINT16 M=2048 (BASELINE configs[4])", 2048, 128, True, OPT_Q,
            [(4096, 4096, 4), (4096, 16384, 1), (16384, 4096, 1)], 32),
+    # decode sizes (HBM-bound on the packed weight; roofline quoted in GB/s): the small-M kernel
+    "d1": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=1 (decode)", 1, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
+    "d16": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=16 (decode)", 16, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
 }
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md, HBM3E
 
 
 def flops(M, K, N, r):
@@ -251,6 +255,17 @@ def main():
                     "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": "k_lqer_gemm",
                     "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
                     "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4)}
+        if M <= 64:
+            # small-M kernel: HBM-bound.  Algorithmic bytes per launch: packed W (0.5625 B per weight)
+            # + B^T limbs + bias + the activation image + xAq + y
+            tot_by = 0.0
+            for _, _, K, N in gemm_events:
+                Kp, Np, rp = -(-K // 64) * 64, -(-N // 256) * 256, -(-r // 16) * 16
+                tot_by += Np * Kp * 0.5625 + Np * rp * 2 + M * Kp * 2 + M * rp * 2 + M * N * 2 + (Np * 4 if has_bias else 0)
+            gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_lqer_gemm_smallm",
+                        "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch}
         out = {
             "metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv",
             "value": round(value, 2),
