@@ -39,6 +39,7 @@ class _LinearBase(nn.Linear):
         self.w_is_quantized = False if self.is_ptq else None
         self._fmt = {}
         self._packed = None
+        self._packed_only = False  # True: images came from a packed checkpoint, the dense parameters are not used
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
 
@@ -66,14 +67,94 @@ class _LinearBase(nn.Linear):
         if self.is_ptq:
             self.w_is_quantized = False
 
-    def _load_from_state_dict(self, *args, **kwargs):
-        super()._load_from_state_dict(*args, **kwargs)
-        self.invalidate_packed()
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        if any((prefix + k) in state_dict for k in ("weight", "bias", "A", "B")):  # dense operands (re)loaded
+            self._packed_only = False
+            self.invalidate_packed()
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
-        self.invalidate_packed()
+        if getattr(self, "_packed_only", False):
+            # images loaded from a packed checkpoint are the only copy of the operands: keep them, follow the module
+            # to its new device (dtype casts do not concern them)
+            dev = self.weight.device
+            if dev.type == "cuda" and self._packed is not None:
+                self._packed = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in self._packed.items()}
+        else:
+            self.invalidate_packed()
         return out
+
+    # -- packed checkpoint (lqer_amd/checkpoint.py) ------------------------------------------------
+    PACKED_FORMAT_VERSION = 1
+
+    def _fmt_digest(self) -> list:
+        """Quantizer settings the packed images depend on: [kind, width, block, exp_width, exp_bias] per role."""
+        out = []
+        for role in ("x", "w", "b", "A_out", "B_out"):
+            f = self._fmt.get(role)
+            out += [-1] * 5 if f is None else [f.kind, f.width, f.block, f.exp_width, f.exp_bias]
+        return out
+
+    @torch.no_grad()
+    def pack(self) -> None:
+        """Build the packed images now (normally done by the first forward)."""
+        if self._packed is None or self.w_is_quantized is False:
+            self._pack()
+
+    @torch.no_grad()
+    def packed_state(self) -> dict:
+        """The packed operands as flat tensors: 4-bit weight panels with their block exponents, the used bf16 limbs
+        of A^T and B^T, the quantized bias, and an int32 header (version, K, N, rank, limb counts, formats)."""
+        self.pack()
+        p = self._packed
+        al, bl = int(p.get("a_limbs", 0)), int(p.get("b_limbs", 0))
+        out = {"w": p["w"].reshape(-1).view(torch.uint8)}
+        if self.rank > 0:
+            Kp, Np = _lib.lib().lqer_padded_k(self.in_features), _lib.lib().lqer_padded_n(self.out_features)
+            rp = _lib.lib().lqer_padded_r(self.rank)
+            out["a_t"] = p["a_t"].reshape(-1).view(torch.uint8)[: al * rp * Kp * 2].clone()
+            out["b_t"] = p["b_t"].reshape(-1).view(torch.uint8)[: bl * Np * rp * 2].clone()
+        if self.bias is not None:
+            out["bias_q"] = p["bias"].reshape(-1).view(torch.uint8)
+        hdr = [self.PACKED_FORMAT_VERSION, self.in_features, self.out_features, self.rank, al, bl,
+               int(self.bias is not None)] + self._fmt_digest()
+        out["header"] = torch.tensor(hdr, dtype=torch.int32)
+        return out
+
+    @torch.no_grad()
+    def load_packed_state(self, state: dict, device: torch.device) -> None:
+        """Attach images written by packed_state(); the dense weight / A / B parameters are not consulted afterwards
+        (they may be left uninitialised).  Raises if the file does not match this module's shape or quantizers."""
+        hdr = [int(v) for v in state["header"].tolist()]
+        want = [self.PACKED_FORMAT_VERSION, self.in_features, self.out_features, self.rank]
+        if hdr[:4] != want:
+            raise RuntimeError(f"packed checkpoint header {hdr[:4]} does not match module {want} (version, in, out, rank)")
+        if hdr[6] != int(self.bias is not None) or hdr[7:] != self._fmt_digest():
+            raise RuntimeError("packed checkpoint was written with different quantizer settings or bias layout")
+        al, bl = hdr[4], hdr[5]
+        L = _lib.lib()
+        sz = ops.linear_sizes(self._desc(), 1)
+        dev = torch.device(device)
+
+        def full(name, nbytes):
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            src = state[name].to(dev).reshape(-1).view(torch.uint8)
+            if src.numel() > nbytes:
+                raise RuntimeError(f"packed checkpoint tensor {name}: {src.numel()} B > {nbytes} B")
+            buf[: src.numel()] = src
+            return buf
+
+        p = {"w": full("w", sz.w_packed)}
+        if p["w"].numel() != state["w"].numel():
+            raise RuntimeError("packed weight size mismatch")
+        if self.rank > 0:
+            p["a_t"], p["b_t"], p["a_limbs"], p["b_limbs"] = full("a_t", sz.a_t), full("b_t", sz.b_t), al, bl
+        if self.bias is not None:
+            p["bias"] = full("bias_q", sz.bias_q).view(torch.float32)
+        self._packed = p
+        self._packed_only = True
+        self.w_is_quantized = True
 
     @torch.no_grad()
     def _pack(self) -> None:
