@@ -351,3 +351,19 @@ def unpack_weight_mxint4(packed: torch.Tensor, exps: torch.Tensor, N: int, K: in
 def flops(M: int, K: int, N: int, r: int) -> int:
     """The reference's multiply model (experiments/hw_performance/README.md:81-106), x2 for FMA."""
     return 2 * M * K * N + 2 * M * K * r + 2 * M * r * N
+
+
+# ----------------------------------------------------------------------------------------------
+# quantized attention matmuls (quantized_functions/matmul.py:12-37)
+# ----------------------------------------------------------------------------------------------
+def matmul_flexible(x: torch.Tensor, y: torch.Tensor, q_config: dict, style: str = "matmul") -> torch.Tensor:
+    """product = matmul(x_quantizer(x), w_quantizer(y)); blocks run along the LAST dim of each operand (for y that is
+    not the contraction dim - llama-7b.toml:110-126).  q_config["default"] is evaluated eagerly, as in the reference."""
+    xq = get_quantizer(q_config.get("x_quantizer", q_config["default"]))
+    wq = get_quantizer(q_config.get("w_quantizer", q_config["default"]))
+    mm = torch.matmul if style == "matmul" else torch.bmm
+    return mm(xq(x), wq(y))
+
+
+def bmm_flexible(x: torch.Tensor, y: torch.Tensor, q_config: dict) -> torch.Tensor:
+    return matmul_flexible(x, y, q_config, style="bmm")

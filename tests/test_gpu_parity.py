@@ -283,6 +283,32 @@ def test_small_m_kernel_vs_oracle(ops, M, cfg, K, N, r, bias):
     assert err <= 1e-3, float(err)
 
 
+def test_quantized_attention_matmuls_vs_reference_vectors(ops):
+    """lqer_amd.matmul_flexible / bmm_flexible (quantizers on the GPU, product through torch) against the reference's
+    outputs; the second operand of Q K^T is passed as the transposed view the model code uses."""
+    import json
+    import os
+
+    import numpy as np
+
+    import lqer_amd
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(here, "matmul.npz"))
+    qc = json.load(open(os.path.join(here, "matmul_config.json")))
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    out = lqer_amd.get_quantized_func("matmul", qc)(t("qk/x"), t("qk/y").transpose(1, 2).contiguous().transpose(1, 2), q_config=qc)
+    assert (out.cpu() - torch.from_numpy(g["qk/out"])).norm() / torch.from_numpy(g["qk/out"]).norm() <= 1e-6
+    out = lqer_amd.matmul_flexible(t("pv/x"), t("pv/y"), qc)
+    assert (out.cpu() - torch.from_numpy(g["pv/out"])).norm() / torch.from_numpy(g["pv/out"]).norm() <= 1e-6
+    out = lqer_amd.bmm_flexible(t("bmm/x"), t("bmm/y"), qc)
+    assert (out.cpu() - torch.from_numpy(g["bmm/out"])).norm() / torch.from_numpy(g["bmm/out"]).norm() <= 1e-6
+    with pytest.raises(KeyError):
+        lqer_amd.matmul_flexible(t("pv/x"), t("pv/y"), {"name": "flexible", "x_quantizer": qc["x_quantizer"]})
+    with pytest.raises(RuntimeError):  # no software fallback
+        lqer_amd.matmul_flexible(t("pv/x").cpu(), t("pv/y").cpu(), qc)
+
+
 def test_size_independent_properties_full_size(ops):
     """At BASELINE's full size (M=2048, 4096x4096, r=32): rows and output columns are independent,
     so a row permutation, a row split and a column split must reproduce the same bits."""

@@ -120,3 +120,21 @@ def test_pack_unpack_roundtrip(golden_q):
 
 def test_flop_model():
     assert O.flops(2048, 4096, 4096, 32) == 2 * 2048 * 4096 * 4096 + 2 * 2048 * 4096 * 32 + 2 * 2048 * 32 * 4096
+
+
+def test_oracle_quantized_matmuls_vs_reference_vectors():
+    """matmul_flexible / bmm_flexible (quantized_functions/matmul.py) against outputs of the imported reference:
+    Q K^T with a transposed second operand whose last dim is not a block multiple, P V, and a 3-D bmm."""
+    import json
+    import os
+
+    import numpy as np
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(here, "matmul.npz"))
+    qc = json.load(open(os.path.join(here, "matmul_config.json")))
+    for name, fn in (("qk", O.matmul_flexible), ("pv", O.matmul_flexible), ("bmm", O.bmm_flexible)):
+        out = fn(torch.from_numpy(g[f"{name}/x"]), torch.from_numpy(g[f"{name}/y"]), qc)
+        assert torch.equal(out, torch.from_numpy(g[f"{name}/out"])), name
+    with pytest.raises(KeyError):  # the reference evaluates q_config["default"] eagerly
+        O.matmul_flexible(torch.zeros(1, 2, 16), torch.zeros(1, 16, 2), {"name": "flexible", "x_quantizer": qc["x_quantizer"]})
