@@ -309,6 +309,40 @@ def test_quantized_attention_matmuls_vs_reference_vectors(ops):
         lqer_amd.matmul_flexible(t("pv/x").cpu(), t("pv/y").cpu(), qc)
 
 
+@pytest.mark.parametrize("M", [4, 300])
+def test_forward_captured_in_a_graph(ops, M):
+    """include/lqer_hip.h: calls are stream-ordered, perform no host synchronisation and may be captured in a
+    hipGraph.  Capture one module forward (small-M kernel at M = 4, tile kernel at M = 300), replay it on new input
+    and compare bit for bit with the eager call."""
+    import lqer_amd
+    from bench import MXINT_Q, make_case
+
+    K, N, r = 512, 768, 32
+    x, W, A, B = make_case(M, K, N, r, seed=9)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).half()
+    xs = x.half().to(DEV)
+    x2 = (x.flip(0) * 1.5).half().to(DEV)
+    eager1, eager2 = mod(xs).clone(), mod(x2).clone()  # also packs and sizes the workspace before the capture
+    static_x = xs.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        mod(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_y = mod(static_x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_y, eager1)
+    static_x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_y, eager2)
+
+
 def test_size_independent_properties_full_size(ops):
     """At BASELINE's full size (M=2048, 4096x4096, r=32): rows and output columns are independent,
     so a row permutation, a row split and a column split must reproduce the same bits."""

@@ -16,3 +16,22 @@ for M in (1, 4, 16, 32, 64):
     for _ in range(50): mod(xd)
     e1.record(); torch.cuda.synchronize()
     print(f"M={M:3d}: {e0.elapsed_time(e1)/50*1e3:7.1f} us per forward")
+
+# the same forwards replayed from a captured graph (no per-launch host work)
+for M in (1, 16, 64):
+    xd = x[:M].half().to(dev)
+    mod(xd)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        mod(xd)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        y = mod(xd)
+    for _ in range(5): g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f"M={M:3d}: {e0.elapsed_time(e1)/200*1e3:7.1f} us per forward (graph replay)")
