@@ -104,10 +104,12 @@ __device__ __forceinline__ void lds_wait(u32x2& a, int& b) {
 #else
 #define LQER_LOAD_BARRIER "\n\ts_barrier"
 #endif
+#if defined(LQER_STAMPS) || defined(LQER_CLOCKPROBE)
+__device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
+#endif
 #ifdef LQER_STAMPS
 // Diagnostic build only: per-section cycle sums (s_memtime) of the main loop, written to a buffer that
 // nothing else reads.  Never quote this build's run time (the stamps serialise the sections).
-__device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP(i)                                                                        \
   do {                                                                                  \
     unsigned long long t_;                                                              \
@@ -277,6 +279,11 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if (late) asm volatile("s_barrier" ::: "memory");
+#ifdef LQER_CLOCKPROBE
+  // diagnostic build: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) around the whole main loop
+  unsigned long long cp_c0, cp_r0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_c0), "=s"(cp_r0)::"memory");
+#endif
 #ifdef LQER_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
@@ -381,6 +388,16 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     if (kt + 3 < nk) step(kt + 3, integral_constant<int, 3>{}, integral_constant<bool, false>{});
   }
   if (!late) asm volatile("s_barrier" ::: "memory");
+#ifdef LQER_CLOCKPROBE
+  {
+    unsigned long long cp_c1, cp_r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_c1), "=s"(cp_r1)::"memory");
+    if (g_stamp_buf && lane == 0) {
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 0] = cp_c1 - cp_c0;
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 1] = cp_r1 - cp_r0;
+    }
+  }
+#endif
 #ifdef LQER_STAMPS
   if (g_stamp_buf && lane == 0)
     for (int i = 0; i < 8; ++i) g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + i] = st_sum[i];
@@ -519,7 +536,7 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
   return check_launch("lqer_gemm");
 }
 
-#ifdef LQER_STAMPS
+#if defined(LQER_STAMPS) || defined(LQER_CLOCKPROBE)
 extern "C" int lqer_debug_set_stamp_buffer(void* p) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p));
 }

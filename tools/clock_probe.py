@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""In-kernel clock of the GEMM main loop: a -DLQER_CLOCKPROBE build stamps s_memtime (shader cycles) and
+s_memrealtime (100 MHz) around the loop of every wave.  Runs >= 2 s of back-to-back launches first (DVFS settles),
+then reports cycles per k-step and the sustained clock.  usage: clock_probe.py lib_CLOCKPROBE.so [K]"""
+import ctypes as C, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lqer_amd import _lib
+from tools.ab_gemm import load
+L = load(sys.argv[1])
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+L.lqer_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+M, N, r = 2048, 4096, 32
+dev = torch.device("cuda:0")
+buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+assert L.lqer_debug_set_stamp_buffer(buf.data_ptr()) == 0
+xq = torch.randn(M, K).to(torch.bfloat16).to(dev)
+wp = torch.randint(0, 256, ((N // 16) * (K // 64) * 576,), dtype=torch.uint8)
+wv = wp.view(-1, 576); wv[:, 512:] = torch.randint(0, 3, (wv.shape[0], 64), dtype=torch.uint8) + 250
+wp = wp.to(dev)
+xaq = (0.1 * torch.randn(M, 32)).to(torch.bfloat16).to(dev)
+bt = (0.1 * torch.randn(3 * N * 32)).to(torch.bfloat16).to(dev)
+y = torch.empty(M, N, dtype=torch.float16, device=dev)
+f8 = _lib.QFmt(1, 8, 16, 8, 127); f4 = _lib.QFmt(1, 4, 16, 8, 127)
+desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
+def launch():
+    assert L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(), 1, N, None, 0, None) == 0
+t0 = time.time()
+while time.time() - t0 < 2.5:
+    for _ in range(200): launch()
+    torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(100): launch()
+e1.record(); torch.cuda.synchronize()
+b = buf.cpu().view(256, 8, 8).double()
+cyc, rt = b[:, :, 0], b[:, :, 1]
+steps = K // 64
+clk = (cyc / rt * 100e6).median().item()
+print(f"K={K}: kernel {e0.elapsed_time(e1) / 100 * 1e3:.2f} us; main loop {cyc.median().item():.0f} cycles = "
+      f"{cyc.median().item() / steps:.0f} cycles per k-step, {rt.median().item() / 100:.2f} us; in-kernel clock {clk / 1e9:.3f} GHz")
