@@ -256,6 +256,26 @@ def test_forward_model_shapes_vs_oracle(ops, K, N, r, bias, cfg):
     assert err <= 2e-5, float(err)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 5e-3), (torch.float32, 2e-5)])
+def test_small_m_kernel_output_dtypes(ops, dtype, tol):
+    """bf16 and fp32 in/out through the small-M kernel (M = 20: two token tiles), B_out pass-through variant included."""
+    import lqer_amd
+    from bench import MXINT_Q, make_case
+
+    M, K, N, r = 20, 768, 1024, 32
+    x, W, A, B = make_case(M, K, N, r, seed=21)
+    for qc in (MXINT_Q, dict(MXINT_Q, B_out_quantizer={"name": "passthrough"})):
+        mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+        mod.load_state_dict({"weight": W, "A": A, "B": B})
+        mod = mod.to(DEV).to(dtype)
+        xin = x.to(dtype)
+        y = mod(xin.to(DEV))
+        assert y.dtype == dtype
+        ref = O.lqer_linear_forward(xin.float(), W.to(dtype).float(), None, A.to(dtype).float(), B.to(dtype).float(), qc)
+        err = (y.float().cpu() - ref).norm() / ref.norm()
+        assert err <= tol, (float(err), qc.get("B_out_quantizer"))
+
+
 @pytest.mark.parametrize("M", [1, 16, 17, 33, 48, 64, 65])
 @pytest.mark.parametrize("cfg,K,N,r,bias", [("mxint", 4096, 4096, 32, False), ("opt", 1000, 1500, 48, True)])
 def test_small_m_kernel_vs_oracle(ops, M, cfg, K, N, r, bias):
