@@ -482,32 +482,80 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 // prologue); the per-16-column maxima are folded into amax[m][n / L] with atomicMax on the fp32 bit pattern
 // (non-negative floats order like unsigned integers; max is order-independent, so the result is
 // reproducible).  The buffer is zeroed on the stream before this kernel.
-__global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32) {
+template <int RG>  // 32-row groups per wave: every B^T fragment feeds RG MFMAs (the B^T stream from L2 is the bound)
+__global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, int seg_tiles) {
+  // One wave = 32 RG token rows x a run of `seg_tiles` 32-column tiles: the rows' xAq fragments stay in registers, the
+  // running maximum of the current B_out block stays in a register and is committed (one atomicMax per row) when
+  // the run leaves the block - a handful of atomics per row instead of one per 16 columns.
+  constexpr int MAXKS = 16 / RG;  // rank <= 256 / RG
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t tiles_m32 = (g.M + 31) / 32;
-  if (wid >= tiles_m32 * tiles_n32) return;
-  const int tm = (int)(wid / tiles_n32), tn = (int)(wid - (int64_t)tm * tiles_n32);
+  const int64_t groups = ((g.M + 31) / 32 + RG - 1) / RG;
+  const int nseg = (tiles_n32 + seg_tiles - 1) / seg_tiles;
+  if (wid >= groups * nseg) return;
+  const int tg = (int)(wid / nseg), sg = (int)(wid - (int64_t)tg * nseg);
   const int l31 = lane & 31, lh = lane >> 5;
-  f32x16 acc;
+  const int nks = g.rp / 16;
+  const int Mp = (g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;  // rows of xaq / bout_amax that exist
+  bf16x8 xa[RG][MAXKS];
+  int rowv[RG];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-  for (int l = 0; l < g.b_limbs; ++l)
-    for (int ks = 0; ks < g.rp / 16; ++ks) {
-      const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + tn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
-      const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(tm * 32 + l31) * g.rp + ks * 16 + 8 * lh);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa, acc, 0, 0, 0);
+  for (int u = 0; u < RG; ++u) {
+    const int row = (tg * RG + u) * 32 + l31;
+    rowv[u] = row < Mp ? row : -1;
+#pragma unroll
+    for (int ks = 0; ks < MAXKS; ++ks) {
+      xa[u][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks < nks && row < Mp) xa[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)row * g.rp + ks * 16 + 8 * lh);
+    }
+  }
+  const int t_begin = sg * seg_tiles;
+  const int t_end = t_begin + seg_tiles < tiles_n32 ? t_begin + seg_tiles : tiles_n32;
+  int cur_blk = (t_begin * 32) / g.bout_L;
+  float cur[RG];
+#pragma unroll
+  for (int u = 0; u < RG; ++u) cur[u] = 0.f;
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < RG; ++u)
+      if (lh == 0 && rowv[u] >= 0)
+        atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(cur[u]));
+  };
+  for (int tn = t_begin; tn < t_end; ++tn) {
+    f32x16 acc[RG];
+#pragma unroll
+    for (int u = 0; u < RG; ++u)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[u][k] = 0.f;
+    for (int l = 0; l < g.b_limbs; ++l) {
+      const bf16_t* brow = g.bt + ((int64_t)l * g.Np + tn * 32 + l31) * g.rp + 8 * lh;
+#pragma unroll
+      for (int ks = 0; ks < MAXKS; ++ks)
+        if (ks < nks) {
+          const bf16x8 bb = *(const bf16x8*)(brow + ks * 16);
+#pragma unroll
+          for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa[u][ks], acc[u], 0, 0, 0);
+        }
     }
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    float amax = 0.f;
+    for (int b = 0; b < 2; ++b) {
+      const int blk = (tn * 32 + 16 * b) / g.bout_L;  // wave-uniform
+      if (blk != cur_blk) {
+        commit();
+        cur_blk = blk;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[8 * b + k]));
-    amax = pair32_max(amax);
-    if (lh == 0)
-      atomicMax((unsigned int*)g.bout_amax + (int64_t)(tm * 32 + l31) * g.bout_nblk + (tn * 32 + 16 * b) / g.bout_L,
-                __float_as_uint(amax));
+        for (int u = 0; u < RG; ++u) cur[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < RG; ++u) {
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[u][8 * b + k]));
+        cur[u] = fmaxf(cur[u], pair32_max(amax));
+      }
+    }
   }
+  commit();
 }
 
 template <int DT>
@@ -572,8 +620,19 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
       g.bout_amax = (float*)scratch;
       (void)hipMemsetAsync(scratch, 0, need, st);
       const int tiles_n32 = g.Np / 32;
-      const int64_t waves = (int64_t)((g.M + 31) / 32) * tiles_n32;
-      k_bout_amax<<<(unsigned)((waves + 3) / 4), 256, 0, st>>>(g, tiles_n32);
+      const int RG = g.rp <= 64 ? 4 : (g.rp <= 128 ? 2 : 1);
+      const int64_t groups = ((g.M + 31) / 32 + RG - 1) / RG;
+      int nseg = (int)(4096 / groups);  // about 16 waves per CU in total
+      nseg = nseg < 1 ? 1 : (nseg > tiles_n32 ? tiles_n32 : nseg);
+      const int seg_tiles = (tiles_n32 + nseg - 1) / nseg;
+      const int64_t waves = groups * ((tiles_n32 + seg_tiles - 1) / seg_tiles);
+      const unsigned grid = (unsigned)((waves + 3) / 4);
+      if (RG == 4)
+        k_bout_amax<4><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
+      else if (RG == 2)
+        k_bout_amax<2><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
+      else
+        k_bout_amax<1><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
     }
   } else if (lowrank && g.bout.kind != LQER_Q_PASSTHROUGH) {
     set_error("B_out_quantizer kind %d not implemented", g.bout.kind);

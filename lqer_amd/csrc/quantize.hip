@@ -109,15 +109,38 @@ __global__ __launch_bounds__(256) void k_quant_seg16(const void* __restrict__ x,
   }
 }
 
-// One workgroup per row, one exponent per row.
+// One workgroup per row, one exponent per row.  Rows of up to 256 x QR_KEEP x 16 elements are read ONCE: every
+// lane keeps its 16-element segments in registers between the row-maximum reduction and the quantization (longer
+// rows fall back to a second read).
+constexpr int QR_KEEP = 4;  // segments per lane held in registers: rows up to 16384 elements
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_quant_row(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
-                                                   QP q, QuantOut o) {
+                                                   QP q, QuantOut o, bool vec) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
   const int64_t segs = o.xq ? o.cols_p / 16 : (cols + 15) / 16;
+  const bool keep = segs <= 256 * QR_KEEP;
+  float v[QR_KEEP][16];
   float amax = 0.0f;
-  for (int64_t k = threadIdx.x; k < cols; k += 256) amax = fmaxf(amax, fabsf(load_elem<DT>(x, row * ld + k)));
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < QR_KEEP; ++j) {
+      const int64_t sg = threadIdx.x + 256 * j;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[j][i] = 0.f;
+      if (sg < segs && sg * 16 < cols) {
+        if (vec && sg * 16 + 16 <= cols)
+          load16<DT, true>(x, row * ld, sg * 16, cols, v[j]);
+        else
+          load16<DT, false>(x, row * ld, sg * 16, cols, v[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[j][i]));
+    }
+  } else {
+    for (int64_t k = threadIdx.x; k < cols; k += 256) amax = fmaxf(amax, fabsf(load_elem<DT>(x, row * ld + k)));
+  }
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
@@ -125,10 +148,18 @@ __global__ __launch_bounds__(256) void k_quant_row(const void* __restrict__ x, i
   amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   const bool any = amax > 0.0f;
   const int e = any ? block_exponent(amax, q) : 0;
-  for (int64_t s = threadIdx.x; s < segs; s += 256) {
-    float v[16];
-    load16<DT, false>(x, row * ld, s * 16, cols, v);
-    emit16(v, any, e, q, o, row, s * 16, cols);
+  if (keep) {
+#pragma unroll
+    for (int j = 0; j < QR_KEEP; ++j) {
+      const int64_t sg = threadIdx.x + 256 * j;
+      if (sg < segs) emit16(v[j], any, e, q, o, row, sg * 16, cols);
+    }
+  } else {
+    for (int64_t s = threadIdx.x; s < segs; s += 256) {
+      float t[16];
+      load16<DT, false>(x, row * ld, s * 16, cols, t);
+      emit16(t, any, e, q, o, row, s * 16, cols);
+    }
   }
   if (o.exps && threadIdx.x == 0) o.exps[row * o.nblk] = (int8_t)(e > 127 ? 127 : e);
 }
@@ -165,7 +196,9 @@ static int launch_quant(const void* x, int64_t rows, int64_t cols, int64_t ld, c
   const int64_t width = o.xq ? o.cols_p : cols;
   const bool whole = q.block <= 0 || q.block >= cols;
   if (whole) {
-    k_quant_row<DT><<<dim3((unsigned)rows), 256, 0, st>>>(x, rows, cols, ld, q, o);
+    const int esz0 = DT == LQER_F32 ? 4 : 2;
+    const bool vec0 = ((uintptr_t)x % 16 == 0) && ((ld * esz0) % 16 == 0);
+    k_quant_row<DT><<<dim3((unsigned)rows), 256, 0, st>>>(x, rows, cols, ld, q, o, vec0);
   } else if (q.block == 16) {
     const int64_t total = rows * ((width + 15) / 16);
     const unsigned grid = (unsigned)((total + 255) / 256 < 1 << 20 ? (total + 255) / 256 : 1 << 20);
