@@ -41,30 +41,54 @@ size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp) {
   return (size_t)(split > fused ? split : fused) * XA_ROWS * rp * sizeof(float);
 }
 
-// One wave = 32 token rows x one K chunk.  Within a 64-k window lane (r = lane & 31, h = lane >> 5) owns the
-// 32 consecutive k at 32h of its row - one 64-byte load - and feeds them to 4 MFMAs in the order it holds
-// them (the k order inside a window is a free permutation as long as both operands use the same one).
-template <int NT>
+// One wave = RG x 32 token rows x one K chunk.  Within a 64-k window lane (r = lane & 31, h = lane >> 5) owns the
+// 32 consecutive k at 32h of its rows - one 64-byte load per row - and feeds them to 4 MFMAs in the order it holds
+// them (the k order inside a window is a free permutation as long as both operands use the same one).  Every A^T
+// fragment (fetched from L2) feeds RG MFMAs: with one row group per wave the A^T stream, rp/32 times the activation
+// stream, is the bound.
+template <int NT, int RG>
 __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t Kp,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
                                                     float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= plan.row_groups * plan.nchunk) return;
-  const int rg = wid / plan.nchunk, c = wid - rg * plan.nchunk;
+  const int wave_rows = (plan.row_groups + RG - 1) / RG;
+  if (wid >= wave_rows * plan.nchunk) return;
+  const int wr = wid / plan.nchunk, c = wid - wr * plan.nchunk;
   const int r = lane & 31, h = lane >> 5;
   const int64_t k_begin = (int64_t)c * plan.kc;
   const int64_t k_end = k_begin + plan.kc < Kp ? k_begin + plan.kc : Kp;
-  f32x16 acc[NT];
+  f32x16 acc[RG][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int u = 0; u < RG; ++u)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
-  const bf16_t* xrow = xq + ((int64_t)rg * XA_ROWS + r) * Kp + 32 * h;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[u][t][j] = 0.f;
+  const bf16_t* xrow[RG];
+#pragma unroll
+  for (int u = 0; u < RG; ++u) {
+    const int rg = wr * RG + u < plan.row_groups ? wr * RG + u : plan.row_groups - 1;  // a clamped duplicate is not stored
+    xrow[u] = xq + ((int64_t)rg * XA_ROWS + r) * Kp + 32 * h;
+  }
+  // the next window's activation loads are issued before this window's MFMAs (the stream from HBM is the bound)
+  bf16x8 xn[RG][4];
+#pragma unroll
+  for (int u = 0; u < RG; ++u)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k_begin + 8 * i);
   for (int64_t k0 = k_begin; k0 < k_end; k0 += 64) {
-    bf16x8 xf[4];
+    bf16x8 xf[RG][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xrow + k0 + 8 * i);
+    for (int u = 0; u < RG; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[u][i] = xn[u][i];
+    if (k0 + 64 < k_end) {
+#pragma unroll
+      for (int u = 0; u < RG; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k0 + 64 + 8 * i);
+    }
     for (int l = 0; l < a_limbs; ++l) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -79,18 +103,26 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
           for (int i = 0; i < 4; ++i) af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[i], af[i], acc[t], 0, 0, 0);
+        for (int u = 0; u < RG; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u][i], af[i], acc[u][t], 0, 0, 0);
       }
     }
   }
   // D layout: col n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 h.  part[c][rg*32 + m][n]
-  float* dst = part + ((int64_t)c * plan.row_groups + rg) * XA_ROWS * rp;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = t * 32 + r;
-    if (n < rp) {
+  for (int u = 0; u < RG; ++u) {
+    const int rg = wr * RG + u;
+    if (rg < plan.row_groups) {
+      float* dst = part + ((int64_t)c * plan.row_groups + rg) * XA_ROWS * rp;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) dst[((j & 3) + 8 * (j >> 2) + 4 * h) * rp + n] = acc[t][j];
+      for (int t = 0; t < NT; ++t) {
+        const int n = t * 32 + r;
+        if (n < rp) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) dst[((j & 3) + 8 * (j >> 2) + 4 * h) * rp + n] = acc[u][t][j];
+        }
+      }
     }
   }
 }
@@ -385,13 +417,17 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_
     set_error("lowrank_xa: scratch %zu B < %zu B", scratch_bytes, need);
     return LQER_E_WORKSPACE;
   }
-  const unsigned grid = (unsigned)((plan.row_groups * plan.nchunk + 3) / 4);
-#define XA_CASE(NT)                                                                   \
-  case NT:                                                                            \
-    k_xa_partial<NT><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);  \
+  // row groups per wave: two while RG x NT accumulator tiles + two activation windows fit the register file
+  const int nt = (rp + 31) / 32;
+  const int rgw = nt <= 4 ? 2 : 1;
+  const int wave_rows = (plan.row_groups + rgw - 1) / rgw;
+  const unsigned grid = (unsigned)((wave_rows * plan.nchunk + 3) / 4);
+#define XA_CASE(NT, RG)                                                                   \
+  case NT:                                                                                \
+    k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);  \
     break;
-  switch ((rp + 31) / 32) {
-    XA_CASE(1) XA_CASE(2) XA_CASE(3) XA_CASE(4) XA_CASE(5) XA_CASE(6) XA_CASE(7) XA_CASE(8)
+  switch (nt) {
+    XA_CASE(1, 2) XA_CASE(2, 2) XA_CASE(3, 2) XA_CASE(4, 2) XA_CASE(5, 1) XA_CASE(6, 1) XA_CASE(7, 1) XA_CASE(8, 1)
   }
 #undef XA_CASE
   const int G = L / 4;
