@@ -367,3 +367,22 @@ def matmul_flexible(x: torch.Tensor, y: torch.Tensor, q_config: dict, style: str
 
 def bmm_flexible(x: torch.Tensor, y: torch.Tensor, q_config: dict) -> torch.Tensor:
     return matmul_flexible(x, y, q_config, style="bmm")
+
+
+# ----------------------------------------------------------------------------------------------
+# low-rank factors of the quantization error (approximate/lqer_svd.py:37-47, lqer_act.py:74-97, base.py:44-49)
+# ----------------------------------------------------------------------------------------------
+def lqer_factors(W: torch.Tensor, w_cfg: dict, rank: int, a_cfg: Optional[dict] = None, b_cfg: Optional[dict] = None,
+                 scale: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A = Q_A(S^-1 U_k), B = Q_B(diag(s_k) V_k^T) with S E^T = U diag(s) V^T, E = W - Q_w(W), S = diag(scale) or I."""
+    Wf = W.float()
+    err_t = (Wf - get_quantizer(w_cfg)(Wf)).t()
+    if scale is not None:
+        err_t = torch.diag(scale.float()) @ err_t
+    U, S, Vh = torch.linalg.svd(err_t)
+    A, B = U[:, :rank], torch.diag(S[:rank]) @ Vh[:rank, :]
+    if scale is not None:
+        A = torch.diag(scale.float()).inverse() @ A
+    qa = get_quantizer(a_cfg) if a_cfg else (lambda t: t)
+    qb = get_quantizer(b_cfg) if b_cfg else (lambda t: t)
+    return qa(A), qb(B)

@@ -363,6 +363,36 @@ def test_forward_captured_in_a_graph(ops, M):
     assert torch.equal(static_y, eager2)
 
 
+@pytest.mark.parametrize("with_scale", [False, True])
+def test_gpu_approximator_reconstruction_error(ops, with_scale):
+    """lqer_amd.approximate.lqer_factors (HIP quantizers + rocSOLVER SVD) against the oracle's restatement of the
+    reference approximators: the factors are not unique, the error they leave is - |E^T - A B| must agree, and it
+    must beat the rank-0 error by the margin the oracle sees."""
+    from lqer_amd.approximate import lqer_factors
+
+    torch.manual_seed(3)
+    N, K, r = 192, 160, 16
+    W = 0.02 * torch.randn(N, K)
+    W[:, 5] *= 20
+    w_cfg = dict(name="block_fp", width=4, exponent_width=8, exponent_bias=None, block_size=[1, 16], skip_first_dim=False)
+    ab_cfg = dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[16, 1], skip_first_dim=False)
+    scale = (0.5 + torch.rand(K)) if with_scale else None
+    A, B = lqer_factors(W.to(DEV), w_cfg, r, ab_cfg, ab_cfg, scale.to(DEV) if with_scale else None)
+    Ao, Bo = O.lqer_factors(W, w_cfg, r, ab_cfg, ab_cfg, scale)
+    assert A.shape == (K, r) and B.shape == (r, N)
+    err_t = (W - O.get_quantizer(w_cfg)(W)).t()
+    e_gpu = (err_t - A.cpu() @ B.cpu()).norm() / err_t.norm()
+    e_ora = (err_t - Ao @ Bo).norm() / err_t.norm()
+    assert abs(float(e_gpu) - float(e_ora)) <= 2e-3 * float(e_ora), (float(e_gpu), float(e_ora))
+    assert float(e_gpu) < 0.97  # a rank-16 correction of a 160-dim error removes a visible part of it
+    # the factors are 8-bit block-floating-point numbers: in every block of 16 along dim 0 all values are integer
+    # multiples of (block maximum rounded up to a power of two) / 128
+    for t in (A.cpu(), B.cpu()):
+        blk = t.t().reshape(t.shape[1], -1, 16)
+        step = 2.0 ** torch.ceil(torch.log2(blk.abs().amax(-1, keepdim=True).clamp_min(1e-30))) / 128
+        assert torch.all((blk / step - torch.round(blk / step)).abs() < 1e-4)
+
+
 def test_size_independent_properties_full_size(ops):
     """At BASELINE's full size (M=2048, 4096x4096, r=32): rows and output columns are independent,
     so a row permutation, a row split and a column split must reproduce the same bits."""
