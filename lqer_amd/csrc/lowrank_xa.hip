@@ -14,6 +14,11 @@ namespace lqer {
 constexpr int XA_ROWS = 32;       // token rows per wave
 constexpr int XA_MAX_TILES = 8;   // rp <= 256
 constexpr int XA_TARGET_WAVES = 2048;
+#ifndef LQER_QX_K
+#define LQER_QX_K 256
+#endif
+constexpr int QX_K = LQER_QX_K;          // k per workgroup of the fused quantize + side-GEMM kernel
+constexpr int QX_WAVES = QX_K / 64;      // one wave per 64 k; QX_K threads, two 16-element blocks each
 
 struct XaPlan {
   int row_groups, nchunk, kc;  // kc = k per chunk (multiple of 64)
@@ -37,7 +42,7 @@ size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp) {
   // fused plan (k_quant_xa16): row_groups * ceil(Kp / 256) partial tiles
   const int64_t rg = (m_max + XA_ROWS - 1) / XA_ROWS;
   const int64_t split = XA_TARGET_WAVES + rg;
-  const int64_t fused = rg * ((lqer_padded_k(K) + 255) / 256);
+  const int64_t fused = rg * ((lqer_padded_k(K) + 255) / 256) * (QX_K < 256 ? 256 / QX_K : 1);
   return (size_t)(split > fused ? split : fused) * XA_ROWS * rp * sizeof(float);
 }
 
@@ -205,7 +210,6 @@ __global__ __launch_bounds__(256) void k_xa_reduce_blk(const float* __restrict__
 // slab (XOR-swizzled 16-byte chunks).  Phase 2: the 4 waves run v_mfma_f32_32x32x16_bf16 over 64 k each,
 // A^T fragments straight from L2; their partial tiles are summed in a fixed order through LDS and written as
 // ONE partial per workgroup.  The activation image is not read back from HBM for the side path.
-constexpr int QX_K = 256;
 
 template <int DT>
 __device__ __forceinline__ void qx_load16(const void* x, int64_t base, int64_t k0, int64_t cols, bool vec, float (&v)[16]) {
@@ -244,12 +248,12 @@ __device__ __forceinline__ void qx_load16(const void* x, int64_t base, int64_t k
 __device__ __forceinline__ int qx_swz(int row, int chunk) { return row * (QX_K * 2) + ((chunk ^ (row & 15)) << 4); }
 
 template <int DT, int NT>
-__global__ __launch_bounds__(256) void k_quant_xa16(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, bool vec,
+__global__ __launch_bounds__(QX_K) void k_quant_xa16(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, bool vec,
                                                     QP q, bf16_t* __restrict__ xq, int64_t Kp,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, int row_groups,
                                                     float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) unsigned char slab[32 * QX_K * 2];   // 16 KiB
-  __shared__ __attribute__((aligned(16))) float red[3 * 32 * 32 * NT];         // waves 1..3 park their tiles here
+  __shared__ __attribute__((aligned(16))) float red[(QX_WAVES > 1 ? QX_WAVES - 1 : 1) * 32 * 32 * NT];  // waves 1.. park their tiles here
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = (int)((Kp + QX_K - 1) / QX_K);
   const int rg = blockIdx.x / nchunk, c = blockIdx.x - rg * nchunk;
@@ -269,8 +273,8 @@ __global__ __launch_bounds__(256) void k_quant_xa16(const void* __restrict__ x, 
   // ---- phase 1: quantize
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
-    const int s = tid + s2 * 256;          // 512 blocks of 16: row = s / 16, segment = s % 16
-    const int row = s >> 4, seg = s & 15;
+    const int s = tid + s2 * QX_K;          // 2 QX_K blocks of 16: row = s / (QX_K / 16), segment = s % (QX_K / 16)
+    const int row = s / (QX_K / 16), seg = s % (QX_K / 16);
     const int64_t m = (int64_t)rg * 32 + row, k0 = kbase + seg * 16;
     uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (k0 < Kp) {
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void k_quant_xa16(const void* __restrict__ x, 
       for (int j = 0; j < 16; ++j) {
         float sum = acc[t][j];
 #pragma unroll
-        for (int w2 = 0; w2 < 3; ++w2) sum += red[((w2 * NT + t) * 16 + j) * 64 + lane];
+        for (int w2 = 0; w2 < QX_WAVES - 1; ++w2) sum += red[((w2 * NT + t) * 16 + j) * 64 + lane];
         if (n < rp) dst[((j & 3) + 8 * (j >> 2) + 4 * h) * rp + n] = sum;
       }
     }
@@ -371,7 +375,7 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
   const int esz = dtype == LQER_F32 ? 4 : 2;
   const bool vec = ((uintptr_t)x % 16 == 0) && ((ldx * esz) % 16 == 0);
   const unsigned grid = (unsigned)(plan.row_groups * plan.nchunk);
-#define QX_LAUNCH(DT, NT) k_quant_xa16<DT, NT><<<grid, 256, 0, st>>>(x, M, K, ldx, vec, qx, xq, Kp, a_t, a_limbs, rp, plan.row_groups, scratch)
+#define QX_LAUNCH(DT, NT) k_quant_xa16<DT, NT><<<grid, QX_K, 0, st>>>(x, M, K, ldx, vec, qx, xq, Kp, a_t, a_limbs, rp, plan.row_groups, scratch)
   const int nt = (rp + 31) / 32;
   switch (dtype) {
     case LQER_F32: if (nt == 1) QX_LAUNCH(LQER_F32, 1); else QX_LAUNCH(LQER_F32, 2); break;
