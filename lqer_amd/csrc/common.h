@@ -220,6 +220,8 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
                             size_t scratch_bytes, hipStream_t st);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
+bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: at least two rounds of 256 x 256 tiles
+int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 

@@ -639,6 +639,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
     return LQER_E_UNSUPPORTED;
   }
   if (smallm_eligible(g, bout)) return smallm_dispatch(g, dtype, lowrank, bout, st);  // decode sizes: HBM-bound variant
+  if (m256_eligible(g)) return m256_dispatch(g, dtype, lowrank, bout, st);            // large M: 256 x 256 tiles
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
   switch (dtype) {

@@ -393,6 +393,37 @@ def test_gpu_approximator_reconstruction_error(ops, with_scale):
         assert torch.all((blk / step - torch.round(blk / step)).abs() < 1e-4)
 
 
+@pytest.mark.parametrize("cfg,K", [("mxint", 320), ("int", 384), ("opt", 64)])
+def test_large_m_tile_kernel_vs_oracle(ops, cfg, K):
+    """M = 4096, N = 8192 (16 x 32 tiles of 256 x 256: the large-M kernel of gemm_w4a8_m256.hip) against the oracle:
+    MXINT blocks of 16, the INT configuration (per-token B_out blocks: row-block maxima from the pre-pass) and a bias;
+    K = 320 / 384 / 64 give 5, 6 and 1 k-steps (ring wrap-around and the shortest pipeline)."""
+    import lqer_amd
+    from bench import INT_Q, MXINT_Q, OPT_Q, make_case
+
+    qc = {"mxint": MXINT_Q, "int": INT_Q, "opt": OPT_Q}[cfg]
+    M, N, r = 4096, 8192, 32
+    bias = cfg == "opt"
+    case = make_case(M, K, N, r, seed=31, bias=bias, quantize_ab=cfg != "int")
+    x, W, A, B = case[:4]
+    b = case[4] if bias else None
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = b
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).half()
+    xin = x.half()
+    y = mod(xin.to(DEV)).float().cpu()
+    ref = O.lqer_linear_forward(xin.float(), W.half().float(), b.half().float() if bias else None, A.half().float(),
+                                B.half().float(), qc)
+    err = (y - ref).norm() / ref.norm()
+    assert err <= 1e-3, float(err)
+    # rows are independent: the 128-row kernel (M = 2000 < 2048) must give the same bits for the same rows
+    y2 = mod(xin[:2000].to(DEV)).float().cpu()
+    assert torch.equal(y2, y[:2000])
+
+
 def test_size_independent_properties_full_size(ops):
     """At BASELINE's full size (M=2048, 4096x4096, r=32): rows and output columns are independent,
     so a row permutation, a row split and a column split must reproduce the same bits."""
