@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // activation: wave w stages tile rows [16w, 16w+16): 2 x LDS-DMA of 8 rows x 128 B.  Buffer
   // addressing: wave-uniform descriptor + per-lane byte offset fixed for the whole kernel + the
   // k-step as scalar offset, so a prefetch costs no vector ALU work.
-  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xq + (int64_t)m0 * g.Kp), 0, 0x7fffffff, 0x00020000);
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xq + (int64_t)m0 * g.Kp), 0, BM * g.Kp * 2, 0x00020000);
   int a_voff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // LDS-DMAs with per-lane source offsets (576 = 36 x 16: a lane's 16 bytes lie inside one panel): wave w issues
   // piece w, wave 0 also piece 8 - 25 LDS-DMA instructions per k-step and workgroup, all with full EXEC.
   const uint8_t* w_base = g.wp + ((int64_t)(n0 / 16) * nk) * LQER_PANEL_BYTES;
-  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 0x7fffffff, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, 16 * nk * LQER_PANEL_BYTES, 0x00020000);
   auto w_piece_voff = [&](int piece) {
     const int byte = piece * 1024 + lane * 16;
     const int pnl = byte / LQER_PANEL_BYTES;
@@ -196,8 +196,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 
   // prologue loads: steps 0 .. DEPTH-1
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-    if (d < nk) issue_loads(d, d);
+  for (int d = 0; d < DEPTH; ++d) issue_loads(d, d);  // (past the end of K: dropped by the buffer range check)
 
   f32x16 acc[4];
 #pragma unroll
@@ -268,16 +267,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // anyone starts LOAD(kt).  WAR: slot (kt+3) % 4 held step kt-1, last read in LOAD(kt-1) of waves 4-7,
   // which ends (lgkmcnt(0)) before barrier 2kt-1; the overwriting loads are issued after it.
   const bool late = wave >= 4;
-  {
-    const int issued = nk < DEPTH ? nk : DEPTH;
-    // (a batch = this wave's 3 loads of one k-step; wave 0 has 4 and waits a little more than it must)
-    if (issued >= 3)
-      asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else if (issued == 2)
-      asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");  // loads(0) landed; two batches of 3 may stay in flight
   if (late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
   // diagnostic build: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) around the whole main loop
@@ -288,84 +278,78 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
-  // One k-step.  The ring slot is a compile-time constant (the loop below is unrolled by the ring size), so
-  // every LDS address is a per-lane base register + an immediate offset and the LDS-DMA destinations are
-  // constants; STEADY = not within DEPTH + 1 steps of the end: no tail checks, always vmcnt(6).
-  auto step = [&](int kt, auto slot_c, auto steady_c) {
+  // hand-built buffer descriptors for the in-asm LDS-DMA (wave-uniform words).  Exact ranges: every step issues its
+  // prefetch, also past the end of K - those lanes read inside the tile's rows or are dropped by the range check
+  const unsigned long long a_base64 = (unsigned long long)(g.xq + (int64_t)m0 * g.Kp);
+  const unsigned long long w_base64 = (unsigned long long)w_base;
+  const u32x4 a_rs = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a_base64),
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a_base64 >> 32)) & 0xffffu,
+                      (uint32_t)(BM * g.Kp * 2), 0x00020000u};
+  const u32x4 w_rs = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w_base64),
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w_base64 >> 32)) & 0xffffu,
+                      (uint32_t)(16 * nk * LQER_PANEL_BYTES), 0x00020000u};
+  const uint32_t m0_a = lds0 + OFF_A + wave * 16 * 128;  // + slot * A_SLOT (+ 1024: second piece)
+  const uint32_t m0_w = lds0 + OFF_R + wave * 1024;      // + slot * R_SLOT
+  const uint32_t m0_w8 = lds0 + OFF_R + 8192;            // + slot * R_SLOT (piece 8, wave 0)
+  // One k-step.  The ring slot is a compile-time constant (the loop below is unrolled by the ring size), so every
+  // LDS address is a per-lane base register + an immediate offset and the LDS-DMA destinations are constants.
+  // LOAD(kt) is ONE asm statement (a compiler-visible gap between LDS reads and their wait lets hipcc copy registers
+  // that have not landed): the 18 LDS reads first, then the LDS-DMA prefetch of step kt+3 - the reads' latency passes
+  // while the DMA instructions issue -, then the counted waits.  The step's first weight fragment is expanded in the
+  // slack left before the barrier, so that COMPUTE opens with an MFMA.  The loading wave has issue priority over
+  // its computing SIMD partner (whose MFMAs only need an issue slot every 32 cycles).
+  auto step = [&](int kt, auto slot_c) {
     constexpr int SLOT = decltype(slot_c)::value;
-    constexpr bool STEADY = decltype(steady_c)::value;
     constexpr int slot_new = SLOT == 0 ? NSLOT - 1 : SLOT - 1;  // (slot + DEPTH) % NSLOT
     STAMP(7);
-    // ---- LOAD(kt): prefetch issue, then ONE asm statement with the 18 LDS reads, the waits and the barrier.
-    // (Reads and their wait must not be separate statements: hipcc treats an asm output as valid when the
-    // statement ends and was seen to copy such registers to others BEFORE the separate wait - stale data.)
-    // the loading wave gets issue priority over its computing SIMD partner (measured -5 %: the LOAD section
-    // is a chain of issue-limited LDS-DMA / LDS reads, the partner's MFMAs only need an issue slot every 32 cycles)
     __builtin_amdgcn_s_setprio(1);
-    if (STEADY || kt + DEPTH < nk) issue_loads(kt + DEPTH, slot_new);
-    STAMP(0);  // LDS-DMA issue
+    const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
+    const int a_soff = ktn * (BK * 2), w_soff = ktn * LQER_PANEL_BYTES;
+    const uint32_t m0a0 = m0_a + slot_new * A_SLOT, m0a1 = m0a0 + 1024;
+    const uint32_t m0w = m0_w + slot_new * R_SLOT, m0w8 = m0_w8 + slot_new * R_SLOT;
     bf16x8 xa[4][4];  // [ks][m tile]
     u32x4 wr;
     uint32_t we;
-#ifdef LQER_ABL_DMA_ONLY
-    for (int ks = 0; ks < 4; ++ks)
-      for (int i = 0; i < 4; ++i) xa[ks][i] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
-    wr = (u32x4){1, 2, 3, 4};
-    we = 0x7c7c7c7cu;
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    {
-      const int younger = nk - 2 - kt;  // batches issued for steps beyond kt+1: they may stay in flight
-#define LQER_LOAD_ASM(VM)                                                                                         \
-  asm volatile(                                                                                                   \
-      "ds_read_b128 %0, %18 offset:%c25\n\tds_read_b32 %1, %19 offset:%c25+512\n\t"                                \
-      "ds_read_b128 %2, %20 offset:%c24\n\tds_read_b128 %3, %20 offset:%c24+4096\n\t"                              \
-      "ds_read_b128 %4, %20 offset:%c24+8192\n\tds_read_b128 %5, %20 offset:%c24+12288\n\t"                        \
-      "ds_read_b128 %6, %21 offset:%c24\n\tds_read_b128 %7, %21 offset:%c24+4096\n\t"                              \
-      "ds_read_b128 %8, %21 offset:%c24+8192\n\tds_read_b128 %9, %21 offset:%c24+12288\n\t"                        \
-      "ds_read_b128 %10, %22 offset:%c24\n\tds_read_b128 %11, %22 offset:%c24+4096\n\t"                            \
-      "ds_read_b128 %12, %22 offset:%c24+8192\n\tds_read_b128 %13, %22 offset:%c24+12288\n\t"                      \
-      "ds_read_b128 %14, %23 offset:%c24\n\tds_read_b128 %15, %23 offset:%c24+4096\n\t"                            \
-      "ds_read_b128 %16, %23 offset:%c24+8192\n\tds_read_b128 %17, %23 offset:%c24+12288\n\t"                      \
-      "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)" LQER_LOAD_BARRIER                                                      \
-      : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]), \
-        "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),      \
-        "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])                        \
-      : "v"(fw_addr), "v"(fe_addr), "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3]),            \
-        "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT)                                                                     \
-      : "memory")
-      if (STEADY || younger >= 2)
-        LQER_LOAD_ASM(6);
-      else if (younger == 1)
-        LQER_LOAD_ASM(3);
-      else
-        LQER_LOAD_ASM(0);
-#undef LQER_LOAD_ASM
-    }
-#endif
-#ifdef LQER_STAMPS
-    STAMP(1);  // LDS reads + waits
-    asm volatile("s_barrier" ::: "memory");
-#endif
+    asm volatile(
+        "ds_read_b128 %0, %18 offset:%c25\n\tds_read_b32 %1, %19 offset:%c25+512\n\t"
+        "ds_read_b128 %2, %20 offset:%c24\n\tds_read_b128 %3, %20 offset:%c24+4096\n\t"
+        "ds_read_b128 %4, %20 offset:%c24+8192\n\tds_read_b128 %5, %20 offset:%c24+12288\n\t"
+        "ds_read_b128 %6, %21 offset:%c24\n\tds_read_b128 %7, %21 offset:%c24+4096\n\t"
+        "ds_read_b128 %8, %21 offset:%c24+8192\n\tds_read_b128 %9, %21 offset:%c24+12288\n\t"
+        "ds_read_b128 %10, %22 offset:%c24\n\tds_read_b128 %11, %22 offset:%c24+4096\n\t"
+        "ds_read_b128 %12, %22 offset:%c24+8192\n\tds_read_b128 %13, %22 offset:%c24+12288\n\t"
+        "ds_read_b128 %14, %23 offset:%c24\n\tds_read_b128 %15, %23 offset:%c24+4096\n\t"
+        "ds_read_b128 %16, %23 offset:%c24+8192\n\tds_read_b128 %17, %23 offset:%c24+12288\n\t"
+        "s_mov_b32 m0, %32\n\ts_nop 0\n\tbuffer_load_dwordx4 %26, %30, %36 offen lds\n\t"
+        "s_mov_b32 m0, %33\n\ts_nop 0\n\tbuffer_load_dwordx4 %27, %30, %36 offen lds\n\t"
+        "s_mov_b32 m0, %34\n\ts_nop 0\n\tbuffer_load_dwordx4 %28, %31, %37 offen lds\n\t"
+        "s_cmp_lg_u32 %38, 0\n\ts_cbranch_scc1 1f\n\t"
+        "s_mov_b32 m0, %35\n\ts_nop 0\n\tbuffer_load_dwordx4 %29, %31, %37 offen lds\n\t"
+        // own loads of step kt+1 landed: the batches of kt+2 and kt+3 (3 loads each, wave 0: 4 - it waits a little
+        // more than it must) may stay in flight
+        "1:\n\ts_waitcnt vmcnt(6) lgkmcnt(0)"
+        : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]),
+          "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),
+          "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])
+        : "v"(fw_addr), "v"(fe_addr), "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3]),  // 18..23
+          "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT),                                                         // 24, 25
+          "v"(a_voff[0]), "v"(a_voff[1]), "v"(w_voff), "v"(w_voff8),                                       // 26..29
+          "s"(a_rs), "s"(w_rs), "s"(m0a0), "s"(m0a1), "s"(m0w), "s"(m0w8), "s"(a_soff), "s"(w_soff), "s"(wave)  // 30..38
+        : "memory");
+    STAMP(1);  // LDS reads + DMA issue + waits
+    bf16x8 wb_first = expand_frag(wr[0], (we & 0xffu) << 23);
+    asm volatile("s_barrier" : "+v"(wb_first)::"memory");
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    STAMP(4);  // LOAD: issue + waits + barrier
+    STAMP(4);  // expand of the first fragment + barrier
     // ---- COMPUTE(kt)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       // biased exponent byte ks -> fp32 bits of the block scale 2^(e - mbits)
       const uint32_t sc = ((we >> (8 * ks)) & 0xffu) << 23;
-#ifdef LQER_ABL_NO_EXPAND
-      const bf16x8 wb = __builtin_bit_cast(bf16x8, wr + sc);
-#else
-      const bf16x8 wb = expand_frag(wr[ks], sc);
-#endif
-#if defined(LQER_ABL_NO_MFMA) || defined(LQER_ABL_DMA_ONLY)
-      asm volatile("" ::"v"(wb), "v"(xa[ks][0]), "v"(xa[ks][1]), "v"(xa[ks][2]), "v"(xa[ks][3]));
-#else
+      const bf16x8 wb = ks == 0 ? wb_first : expand_frag(wr[ks], sc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, xa[ks][i], acc[i], 0, 0, 0);
-#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(5);  // COMPUTE section issue
@@ -374,19 +358,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     STAMP(6);  // barrier after COMPUTE
   };
   using std::integral_constant;
-  int kt = 0;
-  for (; kt + NSLOT + DEPTH <= nk; kt += NSLOT) {  // steady state: 4 steps per trip, slots 0..3
-    step(kt, integral_constant<int, 0>{}, integral_constant<bool, true>{});
-    step(kt + 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
-    step(kt + 2, integral_constant<int, 2>{}, integral_constant<bool, true>{});
-    step(kt + 3, integral_constant<int, 3>{}, integral_constant<bool, true>{});
+  for (int kt = 0;; kt += NSLOT) {  // 4 steps per trip, slots 0..3; every step is the same branch-free stream
+    step(kt, integral_constant<int, 0>{});
+    if (kt + 1 >= nk) break;
+    step(kt + 1, integral_constant<int, 1>{});
+    if (kt + 2 >= nk) break;
+    step(kt + 2, integral_constant<int, 2>{});
+    if (kt + 3 >= nk) break;
+    step(kt + 3, integral_constant<int, 3>{});
+    if (kt + 4 >= nk) break;
   }
-  for (; kt < nk; kt += NSLOT) {  // last steps, with the tail checks (kt is a multiple of 4 here)
-    step(kt, integral_constant<int, 0>{}, integral_constant<bool, false>{});
-    if (kt + 1 < nk) step(kt + 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
-    if (kt + 2 < nk) step(kt + 2, integral_constant<int, 2>{}, integral_constant<bool, false>{});
-    if (kt + 3 < nk) step(kt + 3, integral_constant<int, 3>{}, integral_constant<bool, false>{});
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetches issued past the end of K have drained
   if (!late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
   {
