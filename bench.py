@@ -247,7 +247,7 @@ def main():
         # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (a profiler
         # cannot run inside this process); the committed summary is quoted for the workload it was taken on
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_v15_gemm_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "r01_final_gemm_traffic.json")
         if args.workload == "c2" and os.path.exists(tfile):
             with open(tfile) as fh:
                 traffic = json.load(fh)["traffic_bytes_per_launch"]
