@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
           "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT),                                                         // 24, 25
           "v"(a_voff[0]), "v"(a_voff[1]), "v"(w_voff), "v"(w_voff8),                                       // 26..29
           "s"(a_rs), "s"(w_rs), "s"(m0a0), "s"(m0a1), "s"(m0w), "s"(m0w8), "s"(a_soff), "s"(w_soff), "s"(wave)  // 30..38
-        : "memory");
+        : "memory", "scc");  // (s_cmp inside)
     STAMP(1);  // LDS reads + DMA issue + waits
     bf16x8 wb_first = expand_frag(wr[0], (we & 0xffu) << 23);
     asm volatile("s_barrier" : "+v"(wb_first)::"memory");

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
                    "1:\n\ts_waitcnt vmcnt(5) lgkmcnt(0)"
                    : LQER_OUTS
                    : LQER_INS
-                   : "memory");
+                   : "memory", "scc");  // (s_cmp inside)
     }
 #undef LQER_READS
 #undef LQER_DMA_A
