@@ -393,8 +393,8 @@ def test_gpu_approximator_reconstruction_error(ops, with_scale):
         assert torch.all((blk / step - torch.round(blk / step)).abs() < 1e-4)
 
 
-@pytest.mark.parametrize("cfg,K", [("mxint", 320), ("int", 384), ("opt", 64)])
-def test_large_m_tile_kernel_vs_oracle(ops, cfg, K):
+@pytest.mark.parametrize("cfg,K,N", [("mxint", 320, 8192), ("int", 384, 8192), ("opt", 64, 8192), ("opt", 200, 8000)])
+def test_large_m_tile_kernel_vs_oracle(ops, cfg, K, N):
     """M = 4096, N = 8192 (16 x 32 tiles of 256 x 256: the large-M kernel of gemm_w4a8_m256.hip) against the oracle:
     MXINT blocks of 16, the INT configuration (per-token B_out blocks: row-block maxima from the pre-pass) and a bias;
     K = 320 / 384 / 64 give 5, 6 and 1 k-steps (ring wrap-around and the shortest pipeline)."""
@@ -402,7 +402,7 @@ def test_large_m_tile_kernel_vs_oracle(ops, cfg, K):
     from bench import INT_Q, MXINT_Q, OPT_Q, make_case
 
     qc = {"mxint": MXINT_Q, "int": INT_Q, "opt": OPT_Q}[cfg]
-    M, N, r = 4096, 8192, 32
+    M, r = 4096, 32  # (K = 200, N = 8000: ragged K and N - padded k-steps, guarded output columns)
     bias = cfg == "opt"
     case = make_case(M, K, N, r, seed=31, bias=bias, quantize_ab=cfg != "int")
     x, W, A, B = case[:4]
