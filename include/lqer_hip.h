@@ -176,6 +176,14 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
                      const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
                      size_t scratch_bytes, void* stream);
 
+/* lqer_linear_gemm with an explicit row stride of xaq (elements; a multiple of 8, >= the padded rank): Linears that
+ * share one input (q/k/v, gate/up; llama_decoder.py:246-248, :176) can run ONE lqer_quantize_act_xa over the
+ * concatenation of their A matrices (descriptor rank = sum of the padded ranks, a_t = the concatenated limb image)
+ * and hand each GEMM its columns of the result: xaq = xaq_cat + column offset, xaq_ld = total padded rank. */
+int lqer_linear_gemm_ld(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M, const void* w_packed,
+                        const void* xaq_bf16, int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q,
+                        void* y, int dtype, int64_t ldy, void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,7 @@ SIGNATURES = {
     "lqer_lowrank_xa": (_i, [_dp, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),
     "lqer_linear_gemm_scratch_bytes": (_sz, [_dp, _i64]),
     "lqer_linear_gemm": (_i, [_dp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),
+    "lqer_linear_gemm_ld": (_i, [_dp, _vp, _i64, _vp, _vp, _i64, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

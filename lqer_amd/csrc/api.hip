@@ -221,6 +221,13 @@ size_t lqer_linear_gemm_scratch_bytes(const lqer_linear_desc_t* d, int64_t m_max
 int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
                      const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
                      size_t scratch_bytes, void* stream) {
+  return lqer_linear_gemm_ld(d, xq, M, w_packed, xaq, d ? lqer_padded_r(d->rank) : 0, b_t, b_limbs, bias_q, y, dtype, ldy,
+                             scratch, scratch_bytes, stream);
+}
+
+int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
+                        int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy,
+                        void* scratch, size_t scratch_bytes, void* stream) {
   if (!d || !xq || !w_packed || !y || M < 0 || ldy < d->out_features) {
     set_error("linear_gemm: bad argument");
     return LQER_E_INVALID;
@@ -241,6 +248,12 @@ int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, con
   g.xq = (const bf16_t*)xq;
   g.wp = (const uint8_t*)w_packed;
   g.xaq = (const bf16_t*)xaq;
+  if (lowrank && (xaq_ld < lqer_padded_r(d->rank) || xaq_ld % 8 != 0 || ((uintptr_t)xaq & 15) != 0)) {
+    set_error("linear_gemm: xaq row stride %lld (elements) must be a multiple of 8 and at least the padded rank %lld, "
+              "xaq 16-byte aligned", (long long)xaq_ld, (long long)lqer_padded_r(d->rank));
+    return LQER_E_INVALID;
+  }
+  g.xaq_ld = (int)xaq_ld;
   g.bt = (const bf16_t*)b_t;
   g.bias = d->has_bias ? bias_q : nullptr;
   g.y = y;

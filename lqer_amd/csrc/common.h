@@ -191,7 +191,8 @@ struct QuantOut {
 struct GemmArgs {
   const bf16_t* xq;    // [Mp][Kp]
   const uint8_t* wp;   // packed panels
-  const bf16_t* xaq;   // [Mp][rp] or null
+  const bf16_t* xaq;   // [Mp][xaq_ld] (the Linear's rp columns start at the pointer) or null
+  int xaq_ld;          // row stride of xaq in elements: rp, or the total padded rank of a group sharing one input
   const bf16_t* bt;    // [limbs][Np][rp]
   const float* bias;   // [Np] or null
   void* y;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
     sp_b = *(const bf16x8*)(g.bt + (int64_t)(n0 + row) * g.rp + 8 * q);
 #pragma unroll
     for (int t = 0; t < MT; ++t)
-      if (t * 16 + row < g.M) sp_x[t] = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.rp + 8 * q);
+      if (t * 16 + row < g.M) sp_x[t] = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.xaq_ld + 8 * q);
   }
 
   auto load_panel = [&](int kt, SmPanel& p, bf16x8 (&x)[MT][2]) {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
           bf16x8 bb = zero, xv = zero;
           if (j0 < g.rp) {
             bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + row) * g.rp + j0);
-            if (t * 16 + row < g.M) xv = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.rp + j0);
+            if (t * 16 + row < g.M) xv = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.xaq_ld + j0);
           }
           s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, xv, s, 0, 0, 0);
         }

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+          const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa, acc[i], 0, 0, 0);
         }
       }
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
 #pragma unroll
     for (int ks = 0; ks < MAXKS; ++ks) {
       xa[u][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (ks < nks && row < Mp) xa[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)row * g.rp + ks * 16 + 8 * lh);
+      if (ks < nks && row < Mp) xa[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)row * g.xaq_ld + ks * 16 + 8 * lh);
     }
   }
   const int t_begin = sg * seg_tiles;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
       for (int l = 0; l < g.b_limbs; ++l)
         for (int ks = 0; ks < g.rp / 16; ++ks) {
           const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
-          const bf16x8 xv = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+          const bf16x8 xv = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
           t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xv, t, 0, 0, 0);
         }
       if constexpr (BOUT != 0) {

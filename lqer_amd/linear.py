@@ -40,6 +40,7 @@ class _LinearBase(nn.Linear):
         self._fmt = {}
         self._packed = None
         self._packed_only = False  # True: images came from a packed checkpoint, the dense parameters are not used
+        self._group = None         # SharedActivation of Linears fed by the same tensor (models.quantize_model)
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
 
@@ -66,6 +67,8 @@ class _LinearBase(nn.Linear):
         self._packed = None
         if self.is_ptq:
             self.w_is_quantized = False
+        if getattr(self, "_group", None) is not None:
+            self._group.invalidate()
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
@@ -192,6 +195,8 @@ class _LinearBase(nn.Linear):
                 x2 = x2.contiguous()
             M = x2.shape[0]
             y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+            if M > 0 and self._group is not None and self._group.forward_member(self, x, x2, y):
+                return y.reshape(*x.shape[:-1], N)
             if M > 0:
                 desc = self._desc()
                 sz = ops.linear_sizes(desc, M)
@@ -210,6 +215,100 @@ class _LinearBase(nn.Linear):
     def __repr__(self):
         return "{}(in_features={}, out_features={}, bias={}, is_ptq={}, rank={}, backend=hip/gfx950)".format(
             self.__class__.__name__, self.in_features, self.out_features, self.bias is not None, self.is_ptq, self.rank)
+
+
+class SharedActivation:
+    """Linears that receive the SAME input tensor (q/k/v, gate/up: llama_decoder.py:246-248, :176; opt_decoder.py
+    q/k/v): the activation is quantized once and one side GEMM over the concatenation of the members' A matrices
+    yields every member's x A.  Results are those of the members run one by one (same quantizers, same kernels for
+    the main GEMM; the side product's fp32 summation order may differ).
+
+    A member's forward uses the shared images only when it is handed the very tensor object the images were made
+    from, unmodified (object identity + version counter) - an equal-looking tensor at a recycled address never hits.
+    Requirements checked at construction: same in_features, same x / A_out quantizers with A_out blocks of 16,
+    rank > 0 for every member."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        m0 = self.members[0]
+        ok = all(isinstance(m, LinearFlexibleLqer) and m.rank > 0 and m.in_features == m0.in_features for m in self.members)
+        key = lambda f: (f.kind, f.width, f.block, f.exp_width, f.exp_bias)
+        ok = ok and all(key(m._fmt["x"]) == key(m0._fmt["x"]) and key(m._fmt["A_out"]) == key(m0._fmt["A_out"]) for m in self.members)
+        ok = ok and m0._fmt["A_out"].kind == _lib.Q_MXINT and m0._fmt["A_out"].block == 16 and len(self.members) > 1
+        self.enabled = bool(ok)
+        self._cat = None      # concatenated A^T limb image + member offsets
+        self._x = None        # the tensor the images below were made from (strong reference: its address stays taken)
+        self._ver = -1
+        self._buf = {}        # per (M, device): xq, xaq buffers
+        self._cur = None
+        if self.enabled:
+            for m in self.members:
+                m._group = self
+
+    def invalidate(self):
+        self._cat, self._x, self._cur = None, None, None
+
+    @torch.no_grad()
+    def _pack_cat(self, dev):
+        L = _lib.lib()
+        K = self.members[0].in_features
+        offs, cols = [], []
+        off = 0
+        for m in self.members:
+            rp = L.lqer_padded_r(m.rank)
+            a = torch.zeros(K, rp, dtype=m.A.dtype, device=dev)
+            a[:, : m.rank] = m.A.data.to(dev)
+            cols.append(a)
+            offs.append(off)
+            off += rp
+        a_cat = torch.cat(cols, dim=1).contiguous()
+        dummy_b = torch.zeros(off, 16, dtype=a_cat.dtype, device=dev)
+        a_t, _, a_limbs, _ = ops.pack_lowrank(a_cat, dummy_b)
+        self._cat = {"a_t": a_t, "a_limbs": a_limbs, "offs": offs, "rp_total": off}
+
+    @torch.no_grad()
+    def forward_member(self, mod, x, x2, y) -> bool:
+        """Run `mod`'s forward on the shared images; False = not applicable, the caller takes the ordinary route."""
+        if not self.enabled or any(m._packed_only for m in self.members):  # (a packed checkpoint carries no dense A)
+            return False
+        for m in self.members:  # every member packed (the group image needs the final A values)
+            if m._packed is None or m.w_is_quantized is False:
+                m._pack()
+        dev = x2.device
+        if self._cat is None:
+            self._pack_cat(dev)
+        L = _lib.lib()
+        M, K = x2.shape
+        m0 = self.members[0]
+        fresh = not (x is self._x and x._version == self._ver and self._cur is not None and self._cur["M"] == M)
+        if fresh:
+            gdesc = m0._desc()
+            gdesc.rank = self._cat["rp_total"]
+            Mp, Kp = L.lqer_padded_m(M), L.lqer_padded_k(K)
+            key = (M, dev)
+            if key not in self._buf:
+                nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(gdesc), M)
+                self._buf = {key: {"xq": torch.empty(Mp * Kp, dtype=torch.bfloat16, device=dev),
+                                   "xaq": torch.empty(Mp * self._cat["rp_total"], dtype=torch.bfloat16, device=dev),
+                                   "scr": torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev), "nscr": nscr}}
+            b = self._buf[key]
+            check(L.lqer_quantize_act_xa(C.byref(gdesc), x2.data_ptr(), ops.dtype_code(x2), M, x2.stride(0) if M > 1 else K,
+                                         self._cat["a_t"].data_ptr(), self._cat["a_limbs"], b["xq"].data_ptr(),
+                                         b["xaq"].data_ptr(), b["scr"].data_ptr(), b["nscr"], ops._stream(dev)),
+                  "lqer_quantize_act_xa (shared input)")
+            self._x, self._ver, self._cur = x, x._version, dict(b, M=M)
+        cur = self._cur
+        off = self._cat["offs"][self.members.index(mod)]
+        desc = mod._desc()
+        p = mod._packed
+        gs = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+        scr = ops.workspace(dev, max(gs, 16))
+        check(L.lqer_linear_gemm_ld(C.byref(desc), cur["xq"].data_ptr(), M, p["w"].data_ptr(),
+                                    cur["xaq"].data_ptr() + 2 * off, self._cat["rp_total"], p["b_t"].data_ptr(),
+                                    p["b_limbs"], ops._ptr(p.get("bias")), y.data_ptr(), ops.dtype_code(x2), mod.out_features,
+                                    scr.data_ptr(), gs, ops._stream(dev)),
+              "lqer_linear_gemm_ld (shared input)")
+        return True
 
 
 class LinearFlexible(_LinearBase):

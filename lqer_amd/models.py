@@ -21,7 +21,7 @@ from typing import Dict, Iterable, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .linear import get_quantized_layer_cls
+from .linear import LinearFlexibleLqer, SharedActivation, get_quantized_layer_cls
 
 # decoder-layer children that the reference quantizes, by model family
 _LLAMA_LIKE = {"self_attn": ("q_proj", "k_proj", "v_proj", "o_proj"), "mlp": ("gate_proj", "up_proj", "down_proj")}
@@ -50,8 +50,15 @@ def _layer_cfg(cfg: Optional[dict], layer_id: int, group: str, name: str) -> Opt
     return deepcopy(cfg["linear"])
 
 
-def quantize_model(model: nn.Module, q_config: dict, l_config: Optional[dict]) -> nn.Module:
-    """Replace the projections of every decoder layer in place; weights are carried over."""
+# projections of one decoder layer that are fed the same tensor (llama_decoder.py:246-248 q/k/v, :176 gate/up;
+# opt_decoder.py q/k/v)
+_SHARED_INPUTS = {"self_attn": (("q_proj", "k_proj", "v_proj"),), "mlp": (("gate_proj", "up_proj"),)}
+
+
+def quantize_model(model: nn.Module, q_config: dict, l_config: Optional[dict], share_inputs: bool = True) -> nn.Module:
+    """Replace the projections of every decoder layer in place; weights are carried over.  share_inputs: projections
+    fed by the same tensor quantize it once and share one side GEMM (linear.SharedActivation); per-projection results
+    are unchanged up to the fp32 summation order of the side product."""
     layers, table = _decoder_layers(model)
     for layer_id, layer in enumerate(layers):
         for group, names in table.items():
@@ -67,6 +74,11 @@ def quantize_model(model: nn.Module, q_config: dict, l_config: Optional[dict]) -
                 new.to(device=old.weight.device, dtype=old.weight.dtype)
                 new.load_state_dict(old.state_dict(), strict=False)  # A, B stay zero until loaded
                 setattr(parent, name, new)
+            if share_inputs:
+                for names2 in _SHARED_INPUTS.get(group, ()):
+                    mods = [getattr(parent, n, None) for n in names2]
+                    if all(isinstance(m, LinearFlexibleLqer) for m in mods):
+                        SharedActivation(mods)
     return model
 
 

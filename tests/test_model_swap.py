@@ -191,3 +191,47 @@ def test_packed_sizes_cpu():
     assert sz.a_t == 3 * one_limb and sz.b_t == 3 * one_limb  # the file keeps only the limbs in use (1 for MXINT8 A, B)
     dense = (4096 * 4096 + 2 * 4096 * 32) * 2
     assert (sz.w_packed + 2 * one_limb) / dense < 0.30
+
+
+@pytest.mark.gpu
+def test_shared_activation_groups_gpu():
+    """q/k/v and gate/up quantize their common input once (SharedActivation): same logits as the ungrouped model up to
+    the summation order of the side product, the shared images are really used, and a modified or different input is
+    never served from them."""
+    from lqer_amd import LinearFlexibleLqer
+    from lqer_amd.models import load_low_rank_dict, quantize_model
+
+    dev = torch.device("cuda:0")
+    qc, lc = {"linear": MXINT_Q}, {"linear": {"rank": 16}}
+    shared = quantize_model(_tiny_llama(), qc, lc, share_inputs=True)
+    plain = quantize_model(_tiny_llama(), qc, lc, share_inputs=False)
+    ab = _ab_dict(shared, 16)
+    load_low_rank_dict(shared, ab)
+    load_low_rank_dict(plain, ab)
+    shared, plain = shared.to(dev), plain.to(dev)
+    l0 = shared.model.layers[0]
+    grp = l0.self_attn.q_proj._group
+    assert grp is not None and grp.enabled and grp is l0.self_attn.k_proj._group is l0.self_attn.v_proj._group
+    assert l0.mlp.gate_proj._group is l0.mlp.up_proj._group and l0.mlp.down_proj._group is None
+    assert plain.model.layers[0].self_attn.q_proj._group is None
+    ids = torch.randint(0, 320, (2, 24), generator=torch.Generator().manual_seed(7)).to(dev)
+    with torch.no_grad():
+        a = shared(input_ids=ids).logits.float().cpu()
+        b = plain(input_ids=ids).logits.float().cpu()
+    assert (a - b).norm() / b.norm() <= 2e-5
+    # member by member: the same tensor object is served from the shared images, anything else is not
+    q, k = l0.self_attn.q_proj, l0.self_attn.k_proj
+    pq, pk = plain.model.layers[0].self_attn.q_proj, plain.model.layers[0].self_attn.k_proj
+    x = torch.randn(2, 9, 256, device=dev)
+    with torch.no_grad():
+        yq = q(x)
+        made_from = grp._x
+        yk = k(x)
+        assert grp._x is made_from is x  # k_proj reused q_proj's activation image
+        assert (yq - pq(x)).norm() / yq.norm() <= 2e-5 and (yk - pk(x)).norm() / yk.norm() <= 2e-5
+        x.mul_(2.0)  # in place: the version counter moves, the images are rebuilt
+        yk2 = k(x)
+        assert (yk2 - pk(x)).norm() / yk2.norm() <= 2e-5 and not torch.equal(yk2, yk)
+        x2 = x.clone()  # an equal tensor that is a different object is quantized afresh (and gives the same result)
+        yk3 = k(x2)
+        assert grp._x is x2 and torch.equal(yk3, yk2)
