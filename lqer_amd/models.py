@@ -10,8 +10,8 @@ keys (`model.layers.<i>.self_attn.q_proj.{weight,A,B}` ...), so HF checkpoints a
 
 Config expansion follows llama_decoder.py:423-482: `q_config["linear"]` / `l_config["linear"]` apply to every
 projection of every layer unless a `model_layer_<i>` entry overrides them.  The attention matmuls
-(`q_config["matmul"]`, reference quantized_functions/matmul.py) are not part of this path and stay in the
-model's own precision - SURVEY.md §8 f2.
+(`q_config["matmul"]`, reference quantized_functions/matmul.py) are switched on separately:
+lqer_amd.attention.enable_quantized_attention.
 """
 from __future__ import annotations
 

@@ -235,3 +235,57 @@ def test_shared_activation_groups_gpu():
         x2 = x.clone()  # an equal tensor that is a different object is quantized afresh (and gives the same result)
         yk3 = k(x2)
         assert grp._x is x2 and torch.equal(yk3, yk2)
+
+
+@pytest.mark.gpu
+def test_quantized_attention_end_to_end_gpu():
+    """enable_quantized_attention: both attention products of every layer go through matmul_flexible (reference
+    llama_decoder.py:259-297).  Logits against a CPU twin whose projections AND attention products run the oracle."""
+    import copy
+    import json
+    import os
+
+    from transformers import AttentionInterface
+    from transformers.masking_utils import AttentionMaskInterface, eager_mask
+
+    from lqer_amd import LinearFlexibleLqer
+    from lqer_amd import attention as A
+    from lqer_amd.models import load_low_rank_dict, quantize_model
+    from oracle import lqer_oracle as O
+
+    mm_cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matmul_config.json")))
+    qc = {"linear": MXINT_Q, "matmul": mm_cfg}
+    model = quantize_model(_tiny_llama(), qc, {"linear": {"rank": 16}})
+    load_low_rank_dict(model, _ab_dict(model, 16))
+    twin = copy.deepcopy(model)
+    for name, m in list(twin.named_modules()):
+        if isinstance(m, LinearFlexibleLqer):
+            parent = twin.get_submodule(name.rsplit(".", 1)[0])
+            setattr(parent, name.rsplit(".", 1)[1], _OracleLinear(m, MXINT_Q))
+
+    def oracle_attention(module, query, key, value, attention_mask, scaling, dropout=0.0, **kwargs):
+        k = A._repeat_kv(key, module.num_key_value_groups)
+        v = A._repeat_kv(value, module.num_key_value_groups)
+        b, h, s, d = query.shape
+        w = O.matmul_flexible(query.reshape(b * h, s, d), k.reshape(b * h, -1, d).transpose(1, 2), mm_cfg).reshape(b, h, s, -1) * scaling
+        if attention_mask is not None:
+            w = w + attention_mask
+        w = torch.softmax(w, dim=-1, dtype=torch.float32).to(query.dtype)
+        out = O.matmul_flexible(w.reshape(b * h, s, -1), v.reshape(b * h, -1, d), mm_cfg).reshape(b, h, s, d)
+        return out.transpose(1, 2).contiguous(), w
+
+    AttentionInterface.register("lqer_oracle_eager", oracle_attention)
+    AttentionMaskInterface.register("lqer_oracle_eager", eager_mask)
+    twin.set_attn_implementation("lqer_oracle_eager")
+    A.enable_quantized_attention(model, qc)
+    assert model.config._attn_implementation == A.IMPLEMENTATION
+    ids = torch.randint(0, 320, (2, 20), generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref = twin(input_ids=ids).logits
+        plain = copy.deepcopy(twin)
+        plain.set_attn_implementation("eager")
+        ref_plain = plain(input_ids=ids).logits
+        got = model.to("cuda:0")(input_ids=ids.to("cuda:0")).logits.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).norm() / ref.norm() <= 1e-4
+    assert (ref - ref_plain).norm() / ref.norm() > 1e-4  # the quantized attention products do change the logits
