@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) against the oracle and the golden vectors.
 Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -422,6 +424,22 @@ def test_large_m_tile_kernel_vs_oracle(ops, cfg, K, N):
     # rows are independent: the 128-row kernel (M = 2000 < 2048) must give the same bits for the same rows
     y2 = mod(xin[:2000].to(DEV)).float().cpu()
     assert torch.equal(y2, y[:2000])
+
+
+def test_randomised_parity_sweep(ops):
+    """tools/fuzz_parity.py with a fixed seed: 24 random (shape, rank, dtype, configuration) cases across the small-M,
+    128-row and 256-row kernels against the oracle."""
+    import random
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from tools import fuzz_parity as F
+
+    rng = random.Random(2024)
+    for i in range(24):
+        c = F.one_case(rng)
+        err, tol = F.run_case(*c, DEV)
+        assert err <= tol, (i, c, err, tol)
 
 
 def test_size_independent_properties_full_size(ops):
