@@ -41,6 +41,7 @@ class _LinearBase(nn.Linear):
         self._packed = None
         self._packed_only = False  # True: images came from a packed checkpoint, the dense parameters are not used
         self._group = None         # SharedActivation of Linears fed by the same tensor (models.quantize_model)
+        self._fw_cache = {}        # token count -> (descriptor, workspace bytes)
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
 
@@ -65,6 +66,7 @@ class _LinearBase(nn.Linear):
     def invalidate_packed(self) -> None:
         """Drop the packed images (called after weights change); the next forward re-packs."""
         self._packed = None
+        self._fw_cache = {}
         if self.is_ptq:
             self.w_is_quantized = False
         if getattr(self, "_group", None) is not None:
@@ -198,9 +200,15 @@ class _LinearBase(nn.Linear):
             if M > 0 and self._group is not None and self._group.forward_member(self, x, x2, y):
                 return y.reshape(*x.shape[:-1], N)
             if M > 0:
-                desc = self._desc()
-                sz = ops.linear_sizes(desc, M)
-                ws = ops.workspace(x.device, sz.workspace)
+                # descriptor and workspace size per token count, built once (decode-size forwards are host-bound)
+                ent = self._fw_cache.get(M)
+                if ent is None:
+                    desc = self._desc()
+                    ent = self._fw_cache[M] = (desc, ops.linear_sizes(desc, M).workspace)
+                    if len(self._fw_cache) > 64:
+                        self._fw_cache = {M: ent}
+                desc, ws_bytes = ent
+                ws = ops.workspace(x.device, ws_bytes)
                 p = self._packed
                 check(
                     _lib.lib().lqer_linear_forward(
