@@ -289,3 +289,50 @@ def test_quantized_attention_end_to_end_gpu():
     assert torch.isfinite(got).all()
     assert (got - ref).norm() / ref.norm() <= 1e-4
     assert (ref - ref_plain).norm() / ref.norm() > 1e-4  # the quantized attention products do change the logits
+
+
+def test_swap_structure_mistral_cpu():
+    """The reference also ships a Mistral decoder (models/mistral_decoder.py): same layer layout as Llama, so the
+    by-name swap and the shared-input groups apply unchanged."""
+    from transformers import MistralConfig, MistralForCausalLM
+
+    from lqer_amd import LinearFlexibleLqer
+    from lqer_amd.models import quantize_model
+
+    torch.manual_seed(0)
+    cfg = MistralConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                        num_key_value_heads=2, vocab_size=300, max_position_embeddings=64, sliding_window=32)
+    model = MistralForCausalLM(cfg).eval()
+    keys = set(model.state_dict().keys())
+    quantize_model(model, {"linear": MXINT_Q}, {"linear": {"rank": 16}})
+    l0 = model.model.layers[0]
+    assert all(isinstance(getattr(l0.self_attn, n), LinearFlexibleLqer) for n in ("q_proj", "k_proj", "v_proj", "o_proj"))
+    assert all(isinstance(getattr(l0.mlp, n), LinearFlexibleLqer) for n in ("gate_proj", "up_proj", "down_proj"))
+    assert l0.self_attn.k_proj.out_features == 64  # grouped-query attention: k/v are narrower than q
+    grp = l0.self_attn.q_proj._group
+    assert grp is not None and grp.enabled and len(grp.members) == 3  # different widths share one activation all the same
+    assert keys <= set(model.state_dict().keys())
+    assert "model.layers.1.mlp.down_proj.A" in model.state_dict()
+
+
+@pytest.mark.gpu
+def test_mistral_gqa_shared_groups_gpu():
+    """Grouped-query attention: q (128 wide) and k/v (64 wide) share one activation image; logits equal the
+    one-by-one model's up to the side product's summation order."""
+    from transformers import MistralConfig, MistralForCausalLM
+
+    from lqer_amd.models import load_low_rank_dict, quantize_model
+
+    def build(share):
+        torch.manual_seed(0)
+        cfg = MistralConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                            num_key_value_heads=2, vocab_size=300, max_position_embeddings=64, sliding_window=32)
+        m = quantize_model(MistralForCausalLM(cfg).eval(), {"linear": MXINT_Q}, {"linear": {"rank": 16}}, share_inputs=share)
+        load_low_rank_dict(m, _ab_dict(m, 16))
+        return m.to("cuda:0")
+
+    a, b = build(True), build(False)
+    ids = torch.randint(0, 300, (2, 16), generator=torch.Generator().manual_seed(2)).to("cuda:0")
+    with torch.no_grad():
+        la, lb = a(input_ids=ids).logits.float().cpu(), b(input_ids=ids).logits.float().cpu()
+    assert torch.isfinite(la).all() and (la - lb).norm() / lb.norm() <= 2e-5
