@@ -44,6 +44,11 @@ OPT_Q = dict(MXINT_Q, b_quantizer=_bfp(8, [1, 16], False))
 INT_Q = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=_bfp(8, [1, -1], True),
              w_quantizer=_bfp(4, [1, 128], False), b_quantizer=dict(name="passthrough"))
 
+# the INT templates as shipped (llama-7b-int.toml q_config.linear): pass-through fp16 activations ("W4A16"), A_out and
+# B_out falling back to the same pass-through (linear.py:115-124), A/B unquantized
+A16_Q = dict(INT_Q, x_quantizer=dict(name="passthrough", width=16, frac_width=12))
+UNQUANTIZED_AB = (INT_Q, A16_Q)
+
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 INT8_MFMA_PEAK_TOPS = 5000.0    # 2x bf16 per clock (same guide, "Matrix cores", I8 row)
 
@@ -56,6 +61,9 @@ WORKLOADS = {
            INT_Q, [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)], 5),
     "c5": ("OPT-6.7B 6 projections x 32 layers rank128 W4A8-MXINT16 M=2048 (BASELINE configs[4])", 2048, 128, True, OPT_Q,
            [(4096, 4096, 4), (4096, 16384, 1), (16384, 4096, 1)], 32),
+    "c4a16": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A16 (the reference's INT template as shipped) M=16384, per-GPU share",
+              16384, 64, False, A16_Q, [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)], 5),
+    "d1a16": ("LqerLinear 4096x4096 rank32 W4(block128)A16 M=1 (decode)", 1, 32, False, A16_Q, [(4096, 4096, 1)], 1),
     # decode sizes (HBM-bound on the packed weight; roofline quoted in GB/s): the small-M kernel
     "d1": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=1 (decode)", 1, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
     "d16": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=16 (decode)", 16, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
@@ -101,7 +109,7 @@ def cpu_baseline(M, K, N, r, q_config, reps=3):
 
     cores = min(os.cpu_count() or 1, int(os.environ.get("LQER_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
-    x, W, A, B = make_case(M, K, N, r, seed=0, quantize_ab=q_config is not INT_Q)
+    x, W, A, B = make_case(M, K, N, r, seed=0, quantize_ab=not any(q_config is c for c in UNQUANTIZED_AB))
     x = x.half().float()
     wq = O.get_quantizer(q_config["w_quantizer"])(W)
     O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)  # warm-up
@@ -154,7 +162,7 @@ def main():
     layers_here = layers  # weak scaling: every rank runs a full unit list of its own
     mods = []
     for i, (K, N, cnt) in enumerate(shapes):
-        case = make_case(M, K, N, r, seed=sweep.unit_seed(rank, i), bias=has_bias, quantize_ab=qc is not INT_Q)
+        case = make_case(M, K, N, r, seed=sweep.unit_seed(rank, i), bias=has_bias, quantize_ab=not any(qc is c for c in UNQUANTIZED_AB))
         x, W, A, B = case[:4]
         mod = lqer_amd.LinearFlexibleLqer(K, N, bias=has_bias, q_config=qc, l_config={"rank": r})
         sd = {"weight": W, "A": A, "B": B}
@@ -173,31 +181,38 @@ def main():
     launch_no = [0]
     EV_EVERY = 10  # bracket every 10th launch of the dominant kernel with HIP events (each pair costs ~12 us of gaps)
 
+    # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
+    plans = []
+    ws = ops.workspace(dev, max(ops.linear_sizes(mod._desc(), M).workspace for mod, *_ in mods))  # one buffer for all
+    for mod, xd, K, N, reps, y in mods:
+        desc = mod._desc()
+        p = mod._packed
+        Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
+        xl, al = ops.desc_limbs(desc)  # bf16 limbs of the activation / x A images (1, 1 unless pass-through)
+        xq = ws.data_ptr()
+        xaq = xq + ((Mp * Kp * 2 * xl + 255) // 256) * 256
+        rp = L.lqer_padded_r(r)
+        xscr = xaq + ((Mp * rp * 2 * al + 255) // 256) * 256
+        plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=p["a_t"].data_ptr(), a_limbs=p["a_limbs"], xq=xq, xaq=xaq,
+                          xscr=xscr, nscr=L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M), w=p["w"].data_ptr(),
+                          b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),
+                          gscr=L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M), K=K, N=N, reps=reps))
+
     def step(timed: bool):
-        for mod, xd, K, N, reps, y in mods:
-            desc = mod._desc()
-            p = mod._packed
-            sz = ops.linear_sizes(desc, M)
-            ws = ops.workspace(dev, sz.workspace)
-            Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
-            xq = ws.data_ptr()
-            xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256
-            rp = L.lqer_padded_r(r)
-            xscr = xaq + ((Mp * rp * 2 + 255) // 256) * 256
-            nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
-            for _ in range(reps):
+        for pl in plans:
+            K, N = pl["K"], pl["N"]
+            for _ in range(pl["reps"]):
                 # the two calls of lqer_linear_forward, issued separately so that the dominant kernel can be
                 # bracketed with HIP events on the launch stream
-                _lib.check(L.lqer_quantize_act_xa(C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"],
-                                                  xq, xaq, xscr, nscr, stream), "quantize_act_xa")
+                _lib.check(L.lqer_quantize_act_xa(pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"],
+                                                  pl["xq"], pl["xaq"], pl["xscr"], pl["nscr"], stream), "quantize_act_xa")
                 ev = timed and launch_no[0] % EV_EVERY == 0  # counts timed launches only: the first one is always sampled
                 launch_no[0] += int(timed)
                 if ev:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                _lib.check(L.lqer_linear_gemm(C.byref(desc), xq, M, p["w"].data_ptr(), xaq, p["b_t"].data_ptr(), p["b_limbs"],
-                                              ops._ptr(p.get("bias")), y.data_ptr(), _lib.F16, N, xscr,
-                                              L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M), stream), "linear_gemm")
+                _lib.check(L.lqer_linear_gemm(pl["dref"], pl["xq"], M, pl["w"], pl["xaq"], pl["b_t"], pl["b_limbs"],
+                                              pl["bias"], pl["y"], _lib.F16, N, pl["xscr"], pl["gscr"], stream), "linear_gemm")
                 if ev:
                     e1.record()
                     gemm_events.append((e0, e1, K, N))
@@ -229,7 +244,7 @@ def main():
         from oracle import lqer_oracle as O
 
         mod, xd, K, N, _, y = mods[0]
-        case = make_case(M, K, N, r, seed=sweep.unit_seed(0, 0), bias=has_bias, quantize_ab=qc is not INT_Q)
+        case = make_case(M, K, N, r, seed=sweep.unit_seed(0, 0), bias=has_bias, quantize_ab=not any(qc is c for c in UNQUANTIZED_AB))
         ref = O.lqer_linear_forward(case[0].half().float(), case[1].half().float(), case[4].half().float() if has_bias else None,
                                     case[2].half().float(), case[3].half().float(), qc)
         err = float((y.float().cpu() - ref).norm() / ref.norm())
@@ -244,7 +259,7 @@ def main():
         cal = []
         for _ in range(32):
             _lib.check(L.lqer_quantize_act_mxint(mods[0][1].data_ptr(), _lib.F16, 32, mods[0][2], mods[0][2],
-                                                 C.byref(mods[0][0]._fmt["x"]), ops.workspace(dev, 1 << 20).data_ptr(), stream), "cal")
+                                                 C.byref(ops.make_qfmt(MXINT_Q["x_quantizer"])), ops.workspace(dev, 1 << 20).data_ptr(), stream), "cal")
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
             c1.record()
@@ -275,7 +290,7 @@ def main():
             tot_by = 0.0
             for _, _, K, N in gemm_events:
                 Kp, Np, rp = -(-K // 64) * 64, -(-N // 256) * 256, -(-r // 16) * 16
-                tot_by += Np * Kp * 0.5625 + Np * rp * 2 + M * Kp * 2 + M * rp * 2 + M * N * 2 + (Np * 4 if has_bias else 0)
+                tot_by += Np * Kp * 0.5625 + Np * rp * 2 + M * Kp * 2 + M * rp * 2 + M * N * 2 + (Np * 4 if has_bias else 0)  # (one copy of every image: algorithmic)
             gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_lqer_gemm_smallm",
@@ -294,7 +309,10 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": desc_txt, "tokens_per_step_per_gpu": M, "rank": r,
-                       "formats": "x MXINT8/%s, W MXINT4/%s, A_out,B_out as x, y fp16" % (qc["x_quantizer"]["block_size"][-1], qc["w_quantizer"]["block_size"][-1]),
+                       "formats": "x %s, W MXINT4/%s, A_out,B_out as x, y fp16" % (
+                           "MXINT8/%s" % qc["x_quantizer"]["block_size"][-1] if qc["x_quantizer"]["name"] == "block_fp"
+                           else ("fp16 pass-through (fp16 MFMA main loop)" if mods[0][0]._x_f16 else "fp16 pass-through (2 bf16 limbs)"),
+                           qc["w_quantizer"]["block_size"][-1]),
                        "sharding": "independent Linear units per rank, no data-path collective"},
             "tokens_per_s": round(tokens_rank * world * args.steps / elapsed, 1),
             "roofline": roofline,

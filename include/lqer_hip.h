@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 1
+#define LQER_ABI_VERSION 2
 
 /* error codes */
 #define LQER_OK 0
@@ -47,6 +47,8 @@ extern "C" {
 /* quantizer kinds (reference quantizers/__init__.py:7-18) */
 #define LQER_Q_PASSTHROUGH 0
 #define LQER_Q_MXINT 1 /* "block_fp" */
+#define LQER_Q_PASSTHROUGH_F16 2 /* x_fmt only: pass-through fp16 activations multiplied natively (v_mfma_*_f16) - needs
+                                    lqer_f16_prepare to report both operands exact, see "pass-through activations" */
 
 /* Geometry of the packed operands (fixed by the kernels; exported so callers can size buffers). */
 #define LQER_K_ALIGN 64     /* K is zero-padded to a multiple of this                        */
@@ -61,7 +63,8 @@ extern "C" {
  * (block_fp.py:46-51; exp_width=8, exp_bias=127 in every template config). */
 typedef struct lqer_qfmt {
   int32_t kind;      /* LQER_Q_* */
-  int32_t width;
+  int32_t width;     /* passthrough (x / A_out): significand bits to carry - 8 bf16, 11 fp16, 24 fp32 - see
+                        "pass-through activations" below; ignored for passthrough b / B_out               */
   int32_t block;
   int32_t exp_width;
   int32_t exp_bias;
@@ -183,6 +186,31 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
 int lqer_linear_gemm_ld(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M, const void* w_packed,
                         const void* xaq_bf16, int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q,
                         void* y, int dtype, int64_t ldy, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- pass-through activations ("A16": x_quantizer = passthrough, reference quantizers/passthrough.py:1, every
+ * experiments/configs/template/ *-int.toml) ------------------------------------------------------------------
+ * The kernels multiply exact bf16 operands.  A pass-through activation is therefore carried as the sum of
+ * L = ceil(x_fmt.width / 8) bf16 limbs (1 for a bf16 tensor, 2 for fp16, 3 for fp32) laid side by side along k:
+ * xq is [Mp][L*Kp], and w_packed / a_t must hold L copies of the packed image along k.  Likewise a pass-through
+ * A_out hands x A on as LA limbs (2 when a_out_fmt.width <= 16, else 3): xaq is [Mp][LA*rp] and b_t holds LA
+ * copies along r.  lqer_linear_sizes reports the enlarged sizes; pack into a buffer of the single-copy size (the
+ * sizes of a descriptor whose x / A_out formats are block_fp) and expand with lqer_replicate_rows:
+ *   w_packed: rows = Np/16,  row_bytes = (Kp/64)*LQER_PANEL_BYTES, copies = L
+ *   a_t:      rows = 3*rp,   row_bytes = Kp*2,                      copies = L
+ *   b_t:      rows = 3*Np,   row_bytes = rp*2,                      copies = LA
+ * Every product stays exact and accumulation is fp32, as in the reference's F.linear on 16-bit tensors. */
+int lqer_desc_limbs(const lqer_linear_desc_t* desc, int* act_limbs, int* xa_limbs);
+/* fp16 tensors have a faster exact route: x_fmt.kind = LQER_Q_PASSTHROUGH_F16.  The activation image is then the
+ * fp16 tensor itself ([Mp][Kp], one copy of w_packed), the main loops expand the weights to fp16 and run the fp16 MFMA
+ * (products exact, fp32 accumulation - the reference's F.linear on fp16 tensors), and the side GEMM reads A as ONE
+ * fp16 image a_t = [rp][Kp] fp16 written by this call from the limb image of lqer_pack_lowrank.  Allowed only when
+ * this call leaves flags[0] (a weight block scale outside the fp16 range 2^-24 .. 2^13) and flags[1] (an element of
+ * A that is not an fp16 number) at zero (device int32[2]); otherwise use LQER_Q_PASSTHROUGH with width 11.
+ * A_out / xaq / b_t are as for LQER_Q_PASSTHROUGH.  Calls take dtype = LQER_F16. */
+int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r,
+                     void* a_t_f16, int32_t* flags, void* stream);
+/* dst[row] = src[row] repeated `copies` times (device to device, stream-ordered; dst != src). */
+int lqer_replicate_rows(const void* src, void* dst, int64_t rows, int64_t row_bytes, int copies, void* stream);
 
 #ifdef __cplusplus
 }

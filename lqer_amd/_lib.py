@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F32, F16, BF16 = 0, 1, 2
-Q_PASSTHROUGH, Q_MXINT = 0, 1
+Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16 = 0, 1, 2
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
 
 
@@ -64,6 +64,9 @@ SIGNATURES = {
     "lqer_linear_gemm_scratch_bytes": (_sz, [_dp, _i64]),
     "lqer_linear_gemm": (_i, [_dp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),
     "lqer_linear_gemm_ld": (_i, [_dp, _vp, _i64, _vp, _vp, _i64, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),
+    "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
+    "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -32,6 +32,7 @@ static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
     return false;
   }
   if (f->kind == LQER_Q_PASSTHROUGH) return true;
+  if (f->kind == LQER_Q_PASSTHROUGH_F16 && strcmp(name, "x_quantizer") == 0) return true;
   if (f->kind != LQER_Q_MXINT) {
     set_error("%s: quantizer kind %d is not implemented on the HIP path", name, f->kind);
     return false;
@@ -48,6 +49,34 @@ static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// bf16 limbs of a pass-through tensor: fmt.width = significand bits to carry (8 per limb); block_fp images need one
+static int limbs_of(const lqer_qfmt_t& f) {
+  if (f.kind != LQER_Q_PASSTHROUGH) return 1;
+  return f.width <= 8 ? 1 : (f.width <= 16 ? 2 : 3);
+}
+static int act_limbs(const lqer_linear_desc_t* d) { return limbs_of(d->x_fmt); }
+static bool x_is_f16(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_PASSTHROUGH_F16; }
+static bool need_f16(const lqer_linear_desc_t* d, int dtype, const char* what) {
+  if (x_is_f16(d) && dtype != LQER_F16) {
+    set_error("%s: x_quantizer LQER_Q_PASSTHROUGH_F16 takes fp16 tensors (dtype %d given)", what, dtype);
+    return false;
+  }
+  return true;
+}
+// the side product x A is an fp32 sum: two limbs at least
+static int xa_limbs(const lqer_linear_desc_t* d) {
+  if (d->a_out_fmt.kind != LQER_Q_PASSTHROUGH) return 1;
+  return d->a_out_fmt.width <= 16 ? 2 : 3;
+}
+static bool passthrough_width_ok(const lqer_qfmt_t& f, const char* name) {
+  if (f.kind == LQER_Q_PASSTHROUGH && (f.width < 1 || f.width > 24)) {
+    set_error("%s: a passthrough format must say how many significand bits to carry in `width` (8 = bf16, 11 = fp16, "
+              "16, 24 = fp32), got %d", name, f.width);
+    return false;
+  }
+  return true;
+}
 
 }  // namespace lqer
 
@@ -116,9 +145,12 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
   }
   const size_t Kp = lqer_padded_k(d->in_features), Np = lqer_padded_n(d->out_features);
   const size_t rp = lqer_padded_r(d->rank), Mp = lqer_padded_m(m_max);
-  out->w_packed = (Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES;
-  out->a_t = 3 * rp * Kp * 2;
-  out->b_t = 3 * Np * rp * 2;
+  if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (d->rank > 0 && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
+    return LQER_E_INVALID;
+  const size_t xl = act_limbs(d), al = xa_limbs(d);  // pass-through activations: images repeated per limb
+  out->w_packed = (Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES * xl;
+  out->a_t = 3 * rp * Kp * 2 * xl;
+  out->b_t = 3 * Np * rp * 2 * al;
   out->bias_q = Np * 4;
   size_t side = 0;
   if (rp) {
@@ -126,7 +158,7 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
     const size_t b = d->b_out_fmt.kind == LQER_Q_MXINT ? gemm_scratch_bytes(m_max, d->out_features, make_qp(d->b_out_fmt)) : 0;
     side = align_up(a > b ? a : b, 256);  // the two scratch uses never overlap in time
   }
-  out->workspace = align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256) + side;
+  out->workspace = align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256) + side;
   return LQER_OK;
 }
 
@@ -187,12 +219,14 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
     return LQER_E_INVALID;
   }
   if (!fmt_ok(&d->a_out_fmt, "A_out_quantizer", 9)) return LQER_E_UNSUPPORTED;
+  if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")) return LQER_E_INVALID;
   if (a_limbs < 0 || a_limbs > 3) {
     set_error("lowrank_xa: a_limbs %d outside [0,3]", a_limbs);
     return LQER_E_INVALID;
   }
-  return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, (const bf16_t*)a_t, a_limbs, d->rank,
-                             make_qp(d->a_out_fmt), (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
+  return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, x_is_f16(d) ? 0 : act_limbs(d), (const bf16_t*)a_t, a_limbs, d->rank,
+                             make_qp(d->a_out_fmt), d->a_out_fmt.kind == LQER_Q_PASSTHROUGH ? xa_limbs(d) : 0,
+                             (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
@@ -208,7 +242,16 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
                                            (float*)scratch, scratch_bytes, (hipStream_t)stream);
     if (rc != LQER_E_UNSUPPORTED) return rc;
   }
-  int rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
+  int rc;
+  if (x_is_f16(d)) {
+    if (!need_f16(d, dtype, "quantize_act_xa")) return LQER_E_INVALID;
+    rc = copy_act_f16_dispatch(x, M, d->in_features, ldx, (bf16_t*)xq, (hipStream_t)stream);
+  } else if (d->x_fmt.kind == LQER_Q_PASSTHROUGH) {
+    if (!passthrough_width_ok(d->x_fmt, "x_quantizer")) return LQER_E_INVALID;
+    rc = split_act_dispatch(x, dtype, M, d->in_features, ldx, act_limbs(d), (bf16_t*)xq, (hipStream_t)stream);
+  } else {
+    rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
+  }
   if (rc || d->rank <= 0) return rc;
   return lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, scratch, scratch_bytes, stream);
 }
@@ -221,8 +264,8 @@ size_t lqer_linear_gemm_scratch_bytes(const lqer_linear_desc_t* d, int64_t m_max
 int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
                      const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
                      size_t scratch_bytes, void* stream) {
-  return lqer_linear_gemm_ld(d, xq, M, w_packed, xaq, d ? lqer_padded_r(d->rank) : 0, b_t, b_limbs, bias_q, y, dtype, ldy,
-                             scratch, scratch_bytes, stream);
+  return lqer_linear_gemm_ld(d, xq, M, w_packed, xaq, d ? lqer_padded_r(d->rank) * xa_limbs(d) : 0, b_t, b_limbs, bias_q, y,
+                             dtype, ldy, scratch, scratch_bytes, stream);
 }
 
 int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
@@ -248,7 +291,10 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
   g.xq = (const bf16_t*)xq;
   g.wp = (const uint8_t*)w_packed;
   g.xaq = (const bf16_t*)xaq;
-  if (lowrank && (xaq_ld < lqer_padded_r(d->rank) || xaq_ld % 8 != 0 || ((uintptr_t)xaq & 15) != 0)) {
+  if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (lowrank && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
+    return LQER_E_INVALID;
+  const int xl = act_limbs(d), al = lowrank ? xa_limbs(d) : 1;
+  if (lowrank && (xaq_ld < lqer_padded_r(d->rank) * al || xaq_ld % 8 != 0 || ((uintptr_t)xaq & 15) != 0)) {
     set_error("linear_gemm: xaq row stride %lld (elements) must be a multiple of 8 and at least the padded rank %lld, "
               "xaq 16-byte aligned", (long long)xaq_ld, (long long)lqer_padded_r(d->rank));
     return LQER_E_INVALID;
@@ -261,8 +307,10 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
   g.M = (int)M;
   g.N = d->out_features;
   g.Np = (int)lqer_padded_n(d->out_features);
-  g.Kp = (int)lqer_padded_k(d->in_features);
-  g.rp = (int)lqer_padded_r(d->rank);
+  if (!need_f16(d, dtype, "linear_gemm")) return LQER_E_INVALID;
+  g.x_f16 = x_is_f16(d) ? 1 : 0;
+  g.Kp = (int)lqer_padded_k(d->in_features) * xl;  // limbs side by side along k, weight image repeated to match
+  g.rp = (int)lqer_padded_r(d->rank) * al;
   g.b_limbs = b_limbs;
   g.w_mbits = d->w_fmt.width - 1;
   if (lowrank) g.bout = make_qp(d->b_out_fmt);
@@ -289,13 +337,50 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   unsigned char* ws = (unsigned char*)workspace;
   void* xq = ws;
   const size_t rp = lqer_padded_r(d->rank);
-  void* xaq = ws + align_up(Mp * Kp * 2, 256);
-  void* xa_scratch = ws + align_up(Mp * Kp * 2, 256) + align_up(Mp * rp * 2, 256);
+  const size_t xl = act_limbs(d), al = xa_limbs(d);
+  void* xaq = ws + align_up(Mp * Kp * 2 * xl, 256);
+  void* xa_scratch = ws + align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256);
   rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, xa_scratch,
                             lqer_lowrank_xa_scratch_bytes(d, M), stream);
   if (rc) return rc;
   return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch,
                           lqer_linear_gemm_scratch_bytes(d, M), stream);
+}
+
+int lqer_desc_limbs(const lqer_linear_desc_t* d, int* act, int* xa) {
+  if (!d || !passthrough_width_ok(d->x_fmt, "x_quantizer") || (d->rank > 0 && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer"))) {
+    if (!d) set_error("desc_limbs: null descriptor");
+    return LQER_E_INVALID;
+  }
+  if (act) *act = act_limbs(d);
+  if (xa) *xa = d->rank > 0 ? xa_limbs(d) : 1;
+  return LQER_OK;
+}
+
+int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r, void* a_t_f16,
+                     int32_t* flags, void* stream) {
+  if (!w_packed || !flags || N <= 0 || K <= 0 || r < 0 || (r > 0 && (!a_t_limbs || !a_t_f16 || a_limbs < 0 || a_limbs > 3))) {
+    set_error("f16_prepare: bad argument");
+    return LQER_E_INVALID;
+  }
+  return f16_prepare_dispatch(w_packed, N, K, a_t_limbs, a_limbs, r, a_t_f16, flags, (hipStream_t)stream);
+}
+
+int lqer_replicate_rows(const void* src, void* dst, int64_t rows, int64_t row_bytes, int copies, void* stream) {
+  if (!src || !dst || rows < 0 || row_bytes < 0 || copies < 1) {
+    set_error("replicate_rows: bad argument");
+    return LQER_E_INVALID;
+  }
+  if (rows == 0 || row_bytes == 0) return LQER_OK;
+  for (int c = 0; c < copies; ++c) {
+    const hipError_t e = hipMemcpy2DAsync((char*)dst + (size_t)c * row_bytes, (size_t)copies * row_bytes, src, (size_t)row_bytes,
+                                          (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) {
+      set_error("replicate_rows: %s", hipGetErrorString(e));
+      return LQER_E_LAUNCH;
+    }
+  }
+  return LQER_OK;
 }
 
 }  // extern "C"

@@ -48,8 +48,17 @@ __device__ __forceinline__ float load_elem<LQER_BF16>(const void* p, int64_t i) 
   return __uint_as_float(((uint32_t)((const bf16_t*)p)[i]) << 16);
 }
 
+// Internal fourth element type of the GEMM kernels: fp16 output AND fp16 activations multiplied natively
+// (x_quantizer = LQER_Q_PASSTHROUGH_F16: the activation image holds fp16 bits, the weights are expanded to fp16 and
+// the main loop runs v_mfma_*_f16).  Everything else about it is LQER_F16.
+constexpr int LQER_F16X = 3;
+
 template <int DT>
 __device__ __forceinline__ void store_elem(void* p, int64_t i, float v);
+template <>
+__device__ __forceinline__ void store_elem<LQER_F16X>(void* p, int64_t i, float v) {
+  ((_Float16*)p)[i] = (_Float16)v;
+}
 template <>
 __device__ __forceinline__ void store_elem<LQER_F32>(void* p, int64_t i, float v) {
   ((float*)p)[i] = v;
@@ -178,6 +187,47 @@ __device__ __forceinline__ bf16x8 expand_frag(uint32_t word, uint32_t scale_bits
 }
 
 
+// The same with fp16 results (v_cvt_scalef32_pk_f16_fp8): exact while code * 2^scale stays inside the fp16 range,
+// subnormals included (checked once per weight image, pack.hip::weight_f16_ok).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16>
+__device__ __forceinline__ bf16x8 expand_frag_t(uint32_t word, uint32_t scale_bits) {
+  if constexpr (!F16) {
+    return expand_frag(word, scale_bits);
+  } else {
+    const float scale = __uint_as_float(scale_bits);
+    constexpr uint32_t LUT_LO = 0x44403800u, LUT_HI = 0x4E4C4A48u;
+    const uint32_t t = word >> 4;
+    uint32_t fe = __builtin_amdgcn_perm(LUT_HI, LUT_LO, word & 0x07070707u);
+    uint32_t fo = __builtin_amdgcn_perm(LUT_HI, LUT_LO, t & 0x07070707u);
+    fe |= (word << 4) & 0x80808080u;
+    fo |= word & 0x80808080u;
+    u32x4 r;
+    r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(fe, scale, false));
+    r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(fe, scale, true));
+    r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(fo, scale, false));
+    r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(fo, scale, true));
+    return __builtin_bit_cast(bf16x8, r);
+  }
+}
+
+// MFMA on 16-bit fragments held as raw bits: bf16 (every MXINT image) or fp16 (LQER_F16X main loops)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+
 // ---- cross-file declarations ----------------------------------------------------------------------
 struct QuantOut {
   float* deq;      // [rows, cols] or null
@@ -198,6 +248,7 @@ struct GemmArgs {
   void* y;
   int64_t ldy;
   int M, N, Np, Kp, rp, b_limbs;
+  int x_f16;           // xq holds fp16 bits (pass-through fp16 activations): LQER_F16X kernels
   int w_mbits;
   QP bout;
   int tiles_m, tiles_n;
@@ -213,8 +264,12 @@ int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, floa
 int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r, void* a_t,
                           void* b_t, int32_t* flags, hipStream_t st);
 int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, hipStream_t st);
-int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,
-                        const QP& q, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st);
+int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, const bf16_t* a_t, int a_limbs, int64_t r,
+                        const QP& q, int xa_limbs, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st);
+int copy_act_f16_dispatch(const void* x, int64_t M, int64_t K, int64_t ldx, bf16_t* xq, hipStream_t st);
+int f16_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, const void* a_limbs_img, int a_limbs, int64_t r, void* a_f16,
+                         int32_t* flags, hipStream_t st);
+int split_act_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, int limbs, bf16_t* xq, hipStream_t st);
 size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp);
 int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, bf16_t* xq,
                             const bf16_t* a_t, int a_limbs, int64_t r, const QP& qa, bf16_t* xaq, float* scratch,

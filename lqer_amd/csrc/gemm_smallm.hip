@@ -35,6 +35,7 @@ struct SmPanel {
 
 template <int DT, bool LOWRANK, int BOUT, int MT>
 __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
+  constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image and fp16 weight fragments in the main loop (gemm_w4a8.hip)
   __shared__ __attribute__((aligned(16))) float red[(SM_NW - 1) * MT * 4 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -82,12 +83,12 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
   };
   auto compute_panel = [&](const SmPanel& p, const bf16x8 (&x)[MT][2]) {
     const uint32_t w0 = hi ? p.cw[1] : p.cw[0], w1 = hi ? p.cw[3] : p.cw[2];
-    const bf16x8 wb0 = expand_frag(w0, ((p.ex >> sh0) & 0xffu) << 23);
-    const bf16x8 wb1 = expand_frag(w1, ((p.ex >> sh1) & 0xffu) << 23);
+    const bf16x8 wb0 = expand_frag_t<XF16>(w0, ((p.ex >> sh0) & 0xffu) << 23);
+    const bf16x8 wb1 = expand_frag_t<XF16>(w1, ((p.ex >> sh1) & 0xffu) << 23);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0, x[t][0], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1, x[t][1], acc[t], 0, 0, 0);
+      acc[t] = mfma_16x16x32<XF16>(wb0, x[t][0], acc[t]);
+      acc[t] = mfma_16x16x32<XF16>(wb1, x[t][1], acc[t]);
     }
   };
 
@@ -204,7 +205,7 @@ static int launch_smallm(const GemmArgs& g, bool lowrank, int bout, hipStream_t 
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st) {
   switch (dtype) {
     case LQER_F32: return launch_smallm<LQER_F32>(g, lowrank, bout, st);
-    case LQER_F16: return launch_smallm<LQER_F16>(g, lowrank, bout, st);
+    case LQER_F16: return g.x_f16 ? launch_smallm<LQER_F16X>(g, lowrank, bout, st) : launch_smallm<LQER_F16>(g, lowrank, bout, st);
     case LQER_BF16: return launch_smallm<LQER_BF16>(g, lowrank, bout, st);
   }
   set_error("unknown dtype %d", dtype);

@@ -125,6 +125,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 
 template <int DT, bool LOWRANK, int BOUT>  // BOUT: 0 pass-through, 1 blocks of 16 (max in registers), 2 any block (max from the pre-pass)
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
+  constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image, weights expanded to fp16, v_mfma_f32_32x32x16_f16
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
           "s"(a_rs), "s"(w_rs), "s"(m0a0), "s"(m0a1), "s"(m0w), "s"(m0w8), "s"(a_soff), "s"(w_soff), "s"(wave)  // 30..38
         : "memory", "scc");  // (s_cmp inside)
     STAMP(1);  // LDS reads + DMA issue + waits
-    bf16x8 wb_first = expand_frag(wr[0], (we & 0xffu) << 23);
+    bf16x8 wb_first = expand_frag_t<XF16>(wr[0], (we & 0xffu) << 23);
     asm volatile("s_barrier" : "+v"(wb_first)::"memory");
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -347,9 +348,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     for (int ks = 0; ks < 4; ++ks) {
       // biased exponent byte ks -> fp32 bits of the block scale 2^(e - mbits)
       const uint32_t sc = ((we >> (8 * ks)) & 0xffu) << 23;
-      const bf16x8 wb = ks == 0 ? wb_first : expand_frag(wr[ks], sc);
+      const bf16x8 wb = ks == 0 ? wb_first : expand_frag_t<XF16>(wr[ks], sc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, xa[ks][i], acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16<XF16>(wb, xa[ks][i], acc[i]);
     }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(5);  // COMPUTE section issue
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const float v0 = acc[i][4 * q + 2 * h], v1 = acc[i][4 * q + 2 * h + 1];
-          if constexpr (DT == LQER_F16) {
+          if constexpr (DT == LQER_F16 || DT == LQER_F16X) {
             typedef __attribute__((ext_vector_type(2))) _Float16 h2;
             h2 hv = {(_Float16)v0, (_Float16)v1};
             pk[q][h] = __builtin_bit_cast(uint32_t, hv);
@@ -626,7 +627,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   g.tiles_n = g.Np / BN;
   switch (dtype) {
     case LQER_F32: return launch_gemm<LQER_F32>(g, lowrank, bout, st);
-    case LQER_F16: return launch_gemm<LQER_F16>(g, lowrank, bout, st);
+    case LQER_F16: return g.x_f16 ? launch_gemm<LQER_F16X>(g, lowrank, bout, st) : launch_gemm<LQER_F16>(g, lowrank, bout, st);
     case LQER_BF16: return launch_gemm<LQER_BF16>(g, lowrank, bout, st);
   }
   set_error("unknown dtype %d", dtype);

@@ -42,6 +42,7 @@ __device__ __forceinline__ float pair32_max(float v) {
 
 template <int DT, bool LOWRANK, int BOUT>
 __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
+  constexpr bool XF16 = DT == LQER_F16X;  // (gemm_w4a8.hip)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -247,17 +248,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
 #undef LQER_OUTS
 #undef LQER_INS
     auto scale_bits = [&](int j) { return ((we >> (8 * (2 * P + j))) & 0xffu) << 23; };  // exponent byte -> 2^(e - mbits)
-    bf16x8 wb0 = expand_frag(wr[0], scale_bits(0));
+    bf16x8 wb0 = expand_frag_t<XF16>(wr[0], scale_bits(0));
     asm volatile("s_barrier" : "+v"(wb0)::"memory");
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     // ---- COMPUTE(h)
     {
-      const bf16x8 wb1 = expand_frag(wr[1], scale_bits(1));
+      const bf16x8 wb1 = expand_frag_t<XF16>(wr[1], scale_bits(1));
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb0, xa[0][i], acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) acc[i] = mfma_32x32x16<XF16>(wb0, xa[0][i], acc[i]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, xa[1][i], acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) acc[i] = mfma_32x32x16<XF16>(wb1, xa[1][i], acc[i]);
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const float v0 = acc[i][4 * q + 2 * h], v1 = acc[i][4 * q + 2 * h + 1];
-          if constexpr (DT == LQER_F16) {
+          if constexpr (DT == LQER_F16 || DT == LQER_F16X) {
             typedef __attribute__((ext_vector_type(2))) _Float16 h2;
             h2 hv = {(_Float16)v0, (_Float16)v1};
             pk[q][h] = __builtin_bit_cast(uint32_t, hv);
@@ -381,7 +382,7 @@ bool m256_eligible(const GemmArgs& g) {
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st) {
   switch (dtype) {
     case LQER_F32: return m256::launch<LQER_F32>(g, lowrank, bout, st);
-    case LQER_F16: return m256::launch<LQER_F16>(g, lowrank, bout, st);
+    case LQER_F16: return g.x_f16 ? m256::launch<LQER_F16X>(g, lowrank, bout, st) : m256::launch<LQER_F16>(g, lowrank, bout, st);
     case LQER_BF16: return m256::launch<LQER_BF16>(g, lowrank, bout, st);
   }
   set_error("unknown dtype %d", dtype);

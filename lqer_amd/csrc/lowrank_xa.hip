@@ -51,7 +51,7 @@ size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp) {
 // them (the k order inside a window is a free permutation as long as both operands use the same one).  Every A^T
 // fragment (fetched from L2) feeds RG MFMAs: with one row group per wave the A^T stream, rp/32 times the activation
 // stream, is the bound.
-template <int NT, int RG>
+template <int NT, int RG, bool XF16 = false>  // XF16: fp16 activation image and fp16 A^T (LQER_Q_PASSTHROUGH_F16)
 __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t Kp,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
                                                     float* __restrict__ part) {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
 #pragma unroll
         for (int u = 0; u < RG; ++u)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[u][i], af[i], acc[u][t], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) acc[u][t] = mfma_32x32x16<XF16>(xf[u][i], af[i], acc[u][t]);
       }
     }
   }
@@ -173,6 +173,49 @@ __global__ __launch_bounds__(256) void k_xa_reduce4(const float* __restrict__ pa
     w[i] = exact_bf16_bits(ldexpf(m0v, e - q.mbits)) | (exact_bf16_bits(ldexpf(m1v, e - q.mbits)) << 16);
   }
   *(uint2*)(xaq + idx * 4) = make_uint2(w[0], w[1]);
+}
+
+// A_out_quantizer = passthrough (reference quantizers/passthrough.py:1; the *-int.toml templates leave A_out at the
+// x quantizer's pass-through, linear.py:120-124): the fp32 sum is handed on as LA bf16 limbs laid side by side,
+// xaq [rows][LA * rp], limb l of column n at l * rp + n (16 significand bits with two limbs - the reference keeps
+// 11 (fp16 tensors) or 8 (bf16) here -, all 24 with three); B^T is repeated LA times along r to match.
+template <int LA>
+__global__ __launch_bounds__(256) void k_xa_reduce_limbs(const float* __restrict__ part, XaPlan plan, int rp,
+                                                         bf16_t* __restrict__ xaq) {
+  const int64_t total = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
+  const int64_t chunk_stride = (int64_t)plan.row_groups * XA_ROWS * rp;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const float* src = part + idx * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int c = 0;
+  for (; c + 8 <= plan.nchunk; c += 8) {  // ascending, 8 loads in flight, as in k_xa_reduce4
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(src + (c + u) * chunk_stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+  }
+  for (; c < plan.nchunk; ++c) {
+    const float4 v = *(const float4*)(src + c * chunk_stride);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  const int rq = rp / 4;
+  const int64_t row = idx / rq;
+  const int n0 = (int)(idx - row * rq) * 4;
+  float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int l = 0; l < LA; ++l) {
+    uint32_t w[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16_t b0 = f32_to_bf16_rne(v[2 * i]), b1 = f32_to_bf16_rne(v[2 * i + 1]);
+      v[2 * i] -= __uint_as_float((uint32_t)b0 << 16);
+      v[2 * i + 1] -= __uint_as_float((uint32_t)b1 << 16);
+      w[i] = (uint32_t)b0 | ((uint32_t)b1 << 16);
+    }
+    *(uint2*)(xaq + row * (LA * rp) + l * rp + n0) = make_uint2(w[0], w[1]);
+  }
 }
 
 // Generic block length (not 4 * 2^g): one lane per block, serial.
@@ -396,16 +439,22 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
   return check_launch("quantize_act_xa");
 }
 
-int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_t, int a_limbs, int64_t r,
-                        const QP& q, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st) {
-  const int64_t Kp = lqer_padded_k(K);
+// x_limbs: the activation image holds that many bf16 limbs side by side ([Mp][x_limbs * Kp], act_limbs.hip) and a_t
+// is repeated as often along k; xa_limbs: limbs of the result when A_out is a pass-through (0 otherwise).
+// x_limbs = 0: xq holds fp16 bits and a_t is ONE fp16 image [rp][Kp] (pack.hip::a_f16_dispatch) - v_mfma_*_f16.
+int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, const bf16_t* a_t, int a_limbs, int64_t r,
+                        const QP& q, int xa_limbs, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st) {
+  const bool x_f16 = x_limbs == 0;
+  if (x_f16) x_limbs = 1, a_limbs = 1;
+  const int64_t Kp = lqer_padded_k(K) * x_limbs;
   const int rp = (int)lqer_padded_r(r);
-  if (q.kind != LQER_Q_MXINT || q.mbits > 8) {
-    set_error("A_out_quantizer must be block_fp with width <= 9 on the HIP path (got kind %d width %d)", q.kind,
-              q.mbits + 1);
+  const bool pass = q.kind == LQER_Q_PASSTHROUGH;
+  if (pass ? (xa_limbs != 2 && xa_limbs != 3) : (q.kind != LQER_Q_MXINT || q.mbits > 8)) {
+    set_error("A_out_quantizer must be block_fp with width <= 9, or passthrough with 2 or 3 limbs, on the HIP path (got "
+              "kind %d width %d)", q.kind, q.mbits + 1);
     return LQER_E_UNSUPPORTED;
   }
-  const int L = (q.block <= 0 || q.block >= rp) ? rp : q.block;
+  const int L = pass ? 4 : ((q.block <= 0 || q.block >= rp) ? rp : q.block);
   if (rp % L != 0 || L % 2 != 0) {
     set_error("A_out_quantizer block %d does not tile the padded rank %d", q.block, rp);
     return LQER_E_UNSUPPORTED;
@@ -426,16 +475,26 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, const bf16_t* a_
   const int rgw = nt <= 4 ? 2 : 1;
   const int wave_rows = (plan.row_groups + rgw - 1) / rgw;
   const unsigned grid = (unsigned)((wave_rows * plan.nchunk + 3) / 4);
-#define XA_CASE(NT, RG)                                                                   \
-  case NT:                                                                                \
-    k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);  \
+#define XA_CASE(NT, RG)                                                                           \
+  case NT:                                                                                        \
+    if (x_f16)                                                                                    \
+      k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);  \
+    else                                                                                          \
+      k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);        \
     break;
   switch (nt) {
     XA_CASE(1, 2) XA_CASE(2, 2) XA_CASE(3, 2) XA_CASE(4, 2) XA_CASE(5, 1) XA_CASE(6, 1) XA_CASE(7, 1) XA_CASE(8, 1)
   }
 #undef XA_CASE
   const int G = L / 4;
-  if ((G & (G - 1)) == 0 && G <= 64) {
+  if (pass) {
+    const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
+    const unsigned grid2 = (unsigned)((items + 255) / 256);
+    if (xa_limbs == 2)
+      k_xa_reduce_limbs<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq);
+    else
+      k_xa_reduce_limbs<3><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq);
+  } else if (L % 4 == 0 && (G & (G - 1)) == 0 && G <= 64) {
     const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
     const unsigned grid2 = (unsigned)((items + 255) / 256);
     switch (G) {

@@ -194,6 +194,51 @@ int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, in
   return LQER_E_INVALID;
 }
 
+// ---- fp16 fast path of pass-through fp16 activations (LQER_Q_PASSTHROUGH_F16) -----------------------------------
+// The main loops then expand the weights to fp16 (code * 2^(eb - 127), eb the stored exponent byte) and the side GEMM
+// reads A as ONE fp16 image.  Both must be exact: flags[0] is raised when a weight block's scale leaves the fp16
+// range (subnormals included: 2^-24 .. 2^13 keeps 7 * scale finite), flags[1] when an element of A is not an fp16
+// number.  The caller falls back to bf16 limbs (act_limbs.hip) if either is set.
+__global__ __launch_bounds__(256) void k_w_f16_range(const uint8_t* __restrict__ wp, int64_t panels, int32_t* __restrict__ flags) {
+  bool bad = false;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < panels * 16; idx += (int64_t)gridDim.x * 256) {
+    const uint32_t e4 = *(const uint32_t*)(wp + (idx >> 4) * LQER_PANEL_BYTES + 512 + (idx & 15) * 4);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int eb = (int)((e4 >> (8 * b)) & 0xffu);
+      bad |= eb < 127 - 24 || eb > 127 + 13;
+    }
+  }
+  if (bad) atomicOr(flags, 1);
+}
+
+__global__ __launch_bounds__(256) void k_a_f16(const bf16_t* __restrict__ limbs, int a_limbs, int64_t total, _Float16* __restrict__ out,
+                                               int32_t* __restrict__ flags) {
+  bool bad = false;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    float v = 0.f;
+    for (int l = a_limbs - 1; l >= 0; --l) v += __uint_as_float((uint32_t)limbs[l * total + idx] << 16);  // exact: limbs of one fp32
+    const _Float16 h = (_Float16)v;
+    bad |= (float)h != v;
+    out[idx] = h;
+  }
+  if (bad) atomicOr(flags + 1, 1);
+}
+
+int f16_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, const void* a_limbs_img, int a_limbs, int64_t r, void* a_f16,
+                         int32_t* flags, hipStream_t st) {
+  const int64_t Kp = lqer_padded_k(K), Np = lqer_padded_n(N), rp = lqer_padded_r(r);
+  (void)hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st);
+  const int64_t panels = (Np / 16) * (Kp / 64);
+  k_w_f16_range<<<(unsigned)((panels * 16 + 255) / 256 < 4096 ? (panels * 16 + 255) / 256 : 4096), 256, 0, st>>>((const uint8_t*)w_packed, panels, flags);
+  if (r > 0) {
+    const int64_t total = rp * Kp;
+    k_a_f16<<<(unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096), 256, 0, st>>>((const bf16_t*)a_limbs_img, a_limbs, total,
+                                                                                                   (_Float16*)a_f16, flags);
+  }
+  return check_launch("f16_prepare");
+}
+
 int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, hipStream_t st) {
   const int64_t Np = lqer_padded_n(N);
   const unsigned grid = (unsigned)((Np + 255) / 256);

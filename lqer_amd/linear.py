@@ -28,6 +28,8 @@ import torch.nn as nn
 from . import _lib, ops
 from ._lib import LinearDesc, QFmt, check
 
+_SIG_BITS = {torch.float32: 24, torch.float16: 11, torch.bfloat16: 8}  # significand bits incl. the hidden one
+
 
 class _LinearBase(nn.Linear):
     def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
@@ -42,6 +44,8 @@ class _LinearBase(nn.Linear):
         self._packed_only = False  # True: images came from a packed checkpoint, the dense parameters are not used
         self._group = None         # SharedActivation of Linears fed by the same tensor (models.quantize_model)
         self._fw_cache = {}        # token count -> (descriptor, workspace bytes)
+        self._x_f16 = False        # pass-through fp16 activations on the fp16 MFMA route (decided when the images are built)
+        self.a16_native = True     # False: keep pass-through fp16 activations on the bf16-limb route
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
 
@@ -57,16 +61,74 @@ class _LinearBase(nn.Linear):
         return 0
 
     def _desc(self) -> LinearDesc:
+        """The C descriptor.  Pass-through x / A_out formats (the *-int.toml templates) carry the number of significand
+        bits the HIP path must preserve: those of the module's dtype for x (8 bf16, 11 fp16, 24 fp32 = 1, 2, 3 bf16
+        limbs), 16 for x A under a 16-bit dtype (the reference keeps 11 or 8 there), 24 under fp32."""
         f = self._fmt
         none = QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+        dt = self.weight.dtype
+        if dt not in _SIG_BITS:
+            raise TypeError(f"lqer_amd: unsupported dtype {dt} (float32 / float16 / bfloat16)")
+
+        def eff(role, bits):
+            q = f.get(role, none)
+            if q.kind == _lib.Q_PASSTHROUGH and role == "x" and self._x_f16:
+                return QFmt(_lib.Q_PASSTHROUGH_F16, bits, q.block, q.exp_width, q.exp_bias)
+            return QFmt(q.kind, bits, q.block, q.exp_width, q.exp_bias) if q.kind == _lib.Q_PASSTHROUGH else q
+
         return LinearDesc(self.in_features, self.out_features, self.rank, int(self.bias is not None),
-                          f["x"], f["w"], f.get("b", none), f.get("A_out", none), f.get("B_out", none))
+                          eff("x", _SIG_BITS[dt]), f["w"], f.get("b", none), eff("A_out", 24 if dt == torch.float32 else 16),
+                          f.get("B_out", none))
+
+    def _limbs(self):
+        """(activation limbs, x A limbs) of the packed images - 1, 1 unless x / A_out are pass-through."""
+        return ops.desc_limbs(self._desc())
+
+    def _replicate(self, p: dict) -> dict:
+        """Single-copy packed images -> the images the kernels read (no-op for block_fp x / A_out).  Pass-through fp16
+        activations take the fp16 MFMA route when the weight block scales and A are exact in fp16 (the activation image
+        is then the fp16 tensor itself, A one fp16 image, one copy of W); otherwise, and for bf16 / fp32 tensors, the
+        activation is split into bf16 limbs and the images are repeated once per limb."""
+        self._x_f16 = False
+        self._fw_cache = {}
+        if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native):
+            ok, a16 = ops.f16_prepare(p["w"], self.out_features, self.in_features, p.get("a_t"), int(p.get("a_limbs", 0)), self.rank)
+            if ok:
+                self._x_f16 = True
+                p = dict(p)
+                if self.rank > 0:
+                    p["a_t_limbs"], p["a_t"], p["a_limbs"], p["a_limbs_orig"] = p["a_t"], a16, 1, p["a_limbs"]
+        xl, al = self._limbs()
+        if xl == 1 and al == 1:
+            return p
+        L = _lib.lib()
+        Kp, Np = L.lqer_padded_k(self.in_features), L.lqer_padded_n(self.out_features)
+        q = dict(p)
+        q["w"] = ops.replicate_rows(p["w"], Np // 16, (Kp // 64) * 576, xl)
+        if self.rank > 0:
+            rp = L.lqer_padded_r(self.rank)
+            q["a_t"] = ops.replicate_rows(p["a_t"], 3 * rp, Kp * 2, xl)
+            q["b_t"] = ops.replicate_rows(p["b_t"], 3 * Np, rp * 2, al)
+        return q
+
+    def _single_copy(self, name: str) -> torch.Tensor:
+        """Copy 0 of a repeated image, as flat bytes (inverse of _replicate)."""
+        xl, al = self._limbs()
+        L = _lib.lib()
+        Kp, Np = L.lqer_padded_k(self.in_features), L.lqer_padded_n(self.out_features)
+        rp = L.lqer_padded_r(self.rank) if self.rank > 0 else 0
+        rows, rb, c = {"w": (Np // 16, (Kp // 64) * 576, xl), "a_t": (3 * rp, Kp * 2, xl), "b_t": (3 * Np, rp * 2, al)}[name]
+        if name == "a_t" and "a_t_limbs" in self._packed:  # fp16 route: the limb image is kept next to the fp16 one
+            return self._packed["a_t_limbs"].reshape(-1).view(torch.uint8)
+        flat = self._packed[name].reshape(-1).view(torch.uint8)
+        return flat if c == 1 else flat.view(rows, c, rb)[:, 0].contiguous().reshape(-1)
 
     # -- derived buffers -------------------------------------------------------------------------
     def invalidate_packed(self) -> None:
         """Drop the packed images (called after weights change); the next forward re-packs."""
         self._packed = None
         self._fw_cache = {}
+        self._x_f16 = False
         if self.is_ptq:
             self.w_is_quantized = False
         if getattr(self, "_group", None) is not None:
@@ -79,13 +141,26 @@ class _LinearBase(nn.Linear):
             self.invalidate_packed()
 
     def _apply(self, fn, recurse=True):
+        keep = getattr(self, "_packed_only", False) and self._packed is not None
+        dt_before = self.weight.dtype
+        singles = None
+        if keep and (self._fmt["x"].kind == _lib.Q_PASSTHROUGH or self._limbs() != (1, 1)):
+            # pass-through formats: the images depend on the dtype (limb copies, fp16 route) - go back to one copy first
+            singles = {k: self._single_copy(k) for k in ("w", "a_t", "b_t") if k in self._packed}
+            singles["a_limbs"] = int(self._packed.get("a_limbs_orig", self._packed.get("a_limbs", 0)))
         out = super()._apply(fn, recurse)
         if getattr(self, "_packed_only", False):
             # images loaded from a packed checkpoint are the only copy of the operands: keep them, follow the module
-            # to its new device (dtype casts do not concern them)
+            # to its new device (dtype casts concern them only through the pass-through activation formats)
             dev = self.weight.device
+            self._fw_cache = {}
             if dev.type == "cuda" and self._packed is not None:
-                self._packed = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in self._packed.items()}
+                p = dict(self._packed)
+                if singles is not None and self.weight.dtype != dt_before:
+                    p.update(singles)
+                    p.pop("a_t_limbs", None), p.pop("a_limbs_orig", None)
+                    p = self._replicate({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in p.items()})
+                self._packed = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in p.items()}
         else:
             self.invalidate_packed()
         return out
@@ -97,7 +172,7 @@ class _LinearBase(nn.Linear):
         """Quantizer settings the packed images depend on: [kind, width, block, exp_width, exp_bias] per role."""
         out = []
         for role in ("x", "w", "b", "A_out", "B_out"):
-            f = self._fmt.get(role)
+            f = self._fmt.get(role)  # (as configured: the limb counts of pass-through formats follow the loading dtype)
             out += [-1] * 5 if f is None else [f.kind, f.width, f.block, f.exp_width, f.exp_bias]
         return out
 
@@ -113,13 +188,13 @@ class _LinearBase(nn.Linear):
         of A^T and B^T, the quantized bias, and an int32 header (version, K, N, rank, limb counts, formats)."""
         self.pack()
         p = self._packed
-        al, bl = int(p.get("a_limbs", 0)), int(p.get("b_limbs", 0))
-        out = {"w": p["w"].reshape(-1).view(torch.uint8)}
+        al, bl = int(p.get("a_limbs_orig", p.get("a_limbs", 0))), int(p.get("b_limbs", 0))
+        out = {"w": self._single_copy("w")}  # (a Linear with pass-through activations holds one copy per limb: store one)
         if self.rank > 0:
             Kp, Np = _lib.lib().lqer_padded_k(self.in_features), _lib.lib().lqer_padded_n(self.out_features)
             rp = _lib.lib().lqer_padded_r(self.rank)
-            out["a_t"] = p["a_t"].reshape(-1).view(torch.uint8)[: al * rp * Kp * 2].clone()
-            out["b_t"] = p["b_t"].reshape(-1).view(torch.uint8)[: bl * Np * rp * 2].clone()
+            out["a_t"] = self._single_copy("a_t")[: al * rp * Kp * 2].clone()
+            out["b_t"] = self._single_copy("b_t")[: bl * Np * rp * 2].clone()
         if self.bias is not None:
             out["bias_q"] = p["bias"].reshape(-1).view(torch.uint8)
         hdr = [self.PACKED_FORMAT_VERSION, self.in_features, self.out_features, self.rank, al, bl,
@@ -139,7 +214,10 @@ class _LinearBase(nn.Linear):
             raise RuntimeError("packed checkpoint was written with different quantizer settings or bias layout")
         al, bl = hdr[4], hdr[5]
         L = _lib.lib()
-        sz = ops.linear_sizes(self._desc(), 1)
+        single = self._desc()  # single-copy sizes: those of block_fp activation formats
+        single.x_fmt = QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
+        single.a_out_fmt = QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
+        sz = ops.linear_sizes(single, 1)
         dev = torch.device(device)
 
         def full(name, nbytes):
@@ -157,7 +235,7 @@ class _LinearBase(nn.Linear):
             p["a_t"], p["b_t"], p["a_limbs"], p["b_limbs"] = full("a_t", sz.a_t), full("b_t", sz.b_t), al, bl
         if self.bias is not None:
             p["bias"] = full("bias_q", sz.bias_q).view(torch.float32)
-        self._packed = p
+        self._packed = self._replicate(p)
         self._packed_only = True
         self.w_is_quantized = True
 
@@ -178,7 +256,7 @@ class _LinearBase(nn.Linear):
         # the parameter now carries w_quantizer(W) (|w| <= 1e-8 kept as is, block_fp.py:79-80)
         wq = ops.quantize_mxint(W, f["w"], want=("deq",))["deq"]
         self.weight.data.copy_(wq.to(W.dtype))
-        self._packed = p
+        self._packed = self._replicate(p)
         self.w_is_quantized = True
 
     # -- forward -------------------------------------------------------------------------------
@@ -192,6 +270,9 @@ class _LinearBase(nn.Linear):
             K, N = self.in_features, self.out_features
             if x.shape[-1] != K:
                 raise RuntimeError(f"expected last dim {K}, got {tuple(x.shape)}")
+            if self._fmt["x"].kind == _lib.Q_PASSTHROUGH and x.dtype != self.weight.dtype:
+                # the packed images hold one copy per bf16 limb of the module's dtype (F.linear raises here as well)
+                raise RuntimeError(f"expected input dtype {self.weight.dtype} (pass-through x_quantizer), got {x.dtype}")
             x2 = x.reshape(-1, K)
             if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < K):
                 x2 = x2.contiguous()
@@ -243,6 +324,7 @@ class SharedActivation:
         key = lambda f: (f.kind, f.width, f.block, f.exp_width, f.exp_bias)
         ok = ok and all(key(m._fmt["x"]) == key(m0._fmt["x"]) and key(m._fmt["A_out"]) == key(m0._fmt["A_out"]) for m in self.members)
         ok = ok and m0._fmt["A_out"].kind == _lib.Q_MXINT and m0._fmt["A_out"].block == 16 and len(self.members) > 1
+        ok = ok and m0._fmt["x"].kind == _lib.Q_MXINT  # (pass-through activations: every member splits x itself)
         self.enabled = bool(ok)
         self._cat = None      # concatenated A^T limb image + member offsets
         self._x = None        # the tensor the images below were made from (strong reference: its address stays taken)

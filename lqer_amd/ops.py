@@ -120,6 +120,40 @@ def pack_weight(W: torch.Tensor, fmt: QFmt) -> torch.Tensor:
     return packed
 
 
+def replicate_rows(src: torch.Tensor, rows: int, row_bytes: int, copies: int) -> torch.Tensor:
+    """[rows][row_bytes] -> [rows][copies * row_bytes] (every row repeated): the packed images of a Linear with
+    pass-through activations hold one copy per bf16 limb of the activation (include/lqer_hip.h)."""
+    if copies == 1:
+        return src
+    _need_gpu(src)
+    flat = src.reshape(-1).view(torch.uint8)
+    if flat.numel() < rows * row_bytes:
+        raise ValueError(f"replicate_rows: {flat.numel()} B < {rows} x {row_bytes} B")
+    dst = torch.empty(rows * row_bytes * copies, dtype=torch.uint8, device=src.device)
+    check(_lib.lib().lqer_replicate_rows(flat.data_ptr(), dst.data_ptr(), rows, row_bytes, copies, _stream(src.device)), "lqer_replicate_rows")
+    return dst.view(src.dtype)
+
+
+def f16_prepare(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: Optional[torch.Tensor], a_limbs: int, r: int):
+    """Eligibility of the fp16 fast path of pass-through fp16 activations (include/lqer_hip.h, lqer_f16_prepare):
+    returns (ok, a_t_f16) - ok is False when a weight block scale or an element of A is outside fp16.  Synchronises."""
+    _need_gpu(w_packed)
+    L = _lib.lib()
+    dev = w_packed.device
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    a16 = torch.empty(L.lqer_padded_r(r) * L.lqer_padded_k(K), dtype=torch.float16, device=dev) if r > 0 else None
+    check(L.lqer_f16_prepare(w_packed.data_ptr(), N, K, _ptr(a_t_limbs), a_limbs, r, _ptr(a16), flags.data_ptr(), _stream(dev)), "lqer_f16_prepare")
+    fl = flags.tolist()
+    return (fl[0] == 0 and fl[1] == 0), a16
+
+
+def desc_limbs(desc: LinearDesc) -> Tuple[int, int]:
+    """(bf16 limbs of the activation image, of the x A image): 1, 1 unless x / A_out are pass-through."""
+    a, b = C.c_int(1), C.c_int(1)
+    check(_lib.lib().lqer_desc_limbs(C.byref(desc), C.byref(a), C.byref(b)), "lqer_desc_limbs")
+    return a.value, b.value
+
+
 def unpack_weight(packed: torch.Tensor, N: int, K: int, fmt: QFmt) -> torch.Tensor:
     _need_gpu(packed)
     out = torch.empty(N, K, dtype=torch.float32, device=packed.device)

@@ -171,6 +171,11 @@ def main():
         b_quantizer=dict(name="passthrough"),
     )
     introw_q = dict(int_q, w_quantizer=bfp_cfg(4, [1, -1], False))
+    # the *-int.toml templates as shipped: pass-through ("A16") activations, A_out / B_out falling back to them
+    # (experiments/configs/template/llama-7b-int.toml, opt-6.7b-int.toml)
+    a16_q = dict(int_q, x_quantizer=dict(name="passthrough", width=16, frac_width=12))
+    a16row_q = dict(a16_q, w_quantizer=bfp_cfg(4, [1, -1], False))
+    a16mix_q = dict(a16_q, B_out_quantizer=bfp_cfg(8, [1, 16], True))  # pass-through x and A_out, block_fp B_out
     abq = dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[16, 1], skip_first_dim=False)
 
     cases = [
@@ -183,6 +188,9 @@ def main():
         ("int128", (9, 256), 256, 96, 64, False, int_q, None, True),
         ("introw", (9, 256), 256, 96, 64, False, introw_q, None, False),
         ("ragged", (5, 72), 72, 40, 16, True, mxint_q, abq, False),
+        ("a16", (9, 256), 256, 96, 64, False, a16_q, None, True),
+        ("a16row", (2, 5, 176), 176, 64, 16, True, a16row_q, None, False),
+        ("a16mix", (70, 128), 128, 160, 32, False, a16mix_q, None, False),
     ]
     f = {}
     for name, xs, K, N, r, has_b, qc, abc, use_s in cases:

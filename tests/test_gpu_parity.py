@@ -153,7 +153,7 @@ def _module_from_case(g, cfgs, name, dtype=torch.float32):
     return mod.to(DEV).to(dtype), t
 
 
-FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw"]
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw", "a16", "a16row", "a16mix"]
 
 
 @pytest.mark.parametrize("name", FWD_CASES)
@@ -424,6 +424,101 @@ def test_large_m_tile_kernel_vs_oracle(ops, cfg, K, N):
     # rows are independent: the 128-row kernel (M = 2000 < 2048) must give the same bits for the same rows
     y2 = mod(xin[:2000].to(DEV)).float().cpu()
     assert torch.equal(y2, y[:2000])
+
+
+@pytest.mark.parametrize("dtype,tol,native", [(torch.float16, 1e-3, True), (torch.float16, 1e-3, False), (torch.bfloat16, 5e-3, True),
+                                              (torch.float32, 2e-5, True)])
+@pytest.mark.parametrize("M,K,N", [(1, 1024, 768), (40, 1024, 768), (300, 1000, 700), (4096, 256, 8192)])
+def test_passthrough_activations_vs_oracle(ops, dtype, tol, native, M, K, N):
+    """The reference's INT templates as shipped (llama-7b-int.toml: x_quantizer = passthrough, i.e. W4A16; A_out and
+    B_out fall back to it; A, B unquantized) through the three GEMM kernels (M = 1 / 40: small-M, 300: 128-row tiles,
+    4096 x 8192: 256-row tiles).  fp16 tensors run the fp16 MFMA main loops (native) or, like bf16 (1) and fp32 (3),
+    travel as exact bf16 limbs (2)."""
+    import lqer_amd
+    from bench import A16_Q, make_case
+
+    r = 64
+    x, W, A, B = make_case(M, K, N, r, seed=5, quantize_ab=False)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=A16_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).to(dtype)
+    mod.a16_native = native
+    xin = x.to(dtype)
+    y = mod(xin.to(DEV))
+    assert y.dtype == dtype
+    assert mod._x_f16 == (native and dtype == torch.float16)
+    assert mod._limbs() == {torch.bfloat16: (1, 2), torch.float16: (1, 2) if native else (2, 2), torch.float32: (3, 3)}[dtype]
+    ref = O.lqer_linear_forward(xin.float(), W.to(dtype).float(), None, A.to(dtype).float(), B.to(dtype).float(), A16_Q)
+    err = (y.float().cpu() - ref).norm() / ref.norm()
+    assert err <= tol, float(err)
+    if dtype != torch.float32:
+        # exact products + fp32 accumulation: the output is the correctly rounded oracle value except where summation
+        # order moves a sum across a rounding boundary - a 1-limb (8-bit) activation would miss most elements
+        want = ref.to(dtype)
+        miss = (y.cpu() != want)
+        assert miss.float().mean() <= 0.02, float(miss.float().mean())
+        assert (y.cpu().float() - want.float()).abs().max() <= 2.0 ** (-9 if dtype == torch.float16 else -6) * ref.abs().max()
+    with pytest.raises(RuntimeError, match="pass-through x_quantizer"):
+        mod(xin.to(DEV).to(torch.float32 if dtype != torch.float32 else torch.float16))
+
+
+def test_passthrough_fp16_route_falls_back_when_a_weight_scale_leaves_fp16(ops):
+    """A weight block whose scale is below 2^-24 cannot be expanded to fp16: the module must notice at pack time and
+    take the bf16-limb route (same results), never approximate."""
+    import lqer_amd
+    from bench import A16_Q, make_case
+
+    M, K, N, r = 70, 512, 300, 32
+    x, W, A, B = make_case(M, K, N, r, seed=12, quantize_ab=False)
+    W[3, 128:256] = 0.0
+    W[3, 130], W[3, 200] = 2.0 ** -23, -(2.0 ** -24)  # block of 128 with max 2^-23: exponent -23, code scale 2^-26 < 2^-24
+    outs = []
+    for tiny in (True, False):
+        Wt = W.clone()
+        if not tiny:
+            Wt[3, 128:256] = 0.0
+        mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=A16_Q, l_config={"rank": r})
+        mod.load_state_dict({"weight": Wt, "A": A, "B": B})
+        mod = mod.to(DEV).half()
+        y = mod(x.half().to(DEV)).float().cpu()
+        ref = O.lqer_linear_forward(x.half().float(), Wt.half().float(), None, A.half().float(), B.half().float(), A16_Q)
+        assert (y - ref).norm() / ref.norm() <= 1e-3
+        outs.append(mod._x_f16)
+    assert outs == [False, True]
+
+
+def test_passthrough_packed_checkpoint_single_copy(ops, tmp_path):
+    """A packed checkpoint of a W4A16 Linear stores ONE copy of every image (the per-limb copies are rebuilt at load)
+    and reproduces the forward bit for bit, also when loaded into a module of another dtype (other limb counts)."""
+    import lqer_amd
+    from bench import A16_Q, make_case
+
+    M, K, N, r = 33, 320, 300, 32
+    x, W, A, B = make_case(M, K, N, r, seed=9, quantize_ab=False)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=A16_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W.half().float(), "A": A.half().float(), "B": B.half().float()})
+    mod = mod.to(DEV).half()
+    Kp, Np = 320, 512
+    for native in (False, True):
+        mod.invalidate_packed()
+        mod.a16_native = native
+        y = mod(x.half().to(DEV))
+        st = mod.packed_state()
+        assert st["w"].numel() == (Np // 16) * (Kp // 64) * 576
+        assert mod._packed["w"].numel() == (1 if native else 2) * st["w"].numel() and mod._x_f16 == native
+        for dt in (torch.float16, torch.float32):
+            m2 = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=A16_Q, l_config={"rank": r}).to(dt)
+            m2.a16_native = native
+            m2.load_packed_state({k: v.cpu() for k, v in st.items()}, DEV)
+            m2 = m2.to(DEV)
+            y2 = m2(x.half().to(DEV).to(dt))
+            if dt == torch.float16:
+                assert torch.equal(y2, y)
+            else:
+                assert (y2 - y.float()).norm() / y.float().norm() <= 5e-4  # (fp32 output against its fp16 rounding)
+        # a dtype cast of the packed-only module rebuilds the images for the new element type
+        m3 = m2.half()
+        assert m3._x_f16 == native and torch.equal(m3(x.half().to(DEV)), y)
 
 
 def test_randomised_parity_sweep(ops):
