@@ -191,6 +191,8 @@ def main():
         xl, al = ops.desc_limbs(desc)  # bf16 limbs of the activation / x A images (1, 1 unless pass-through)
         xq = ws.data_ptr()
         xaq = xq + ((Mp * Kp * 2 * xl + 255) // 256) * 256
+        if mod._x_f16 and K % 64 == 0 and M % 256 == 0:
+            xq = xd.data_ptr()  # fp16 route: a dense, aligned fp16 tensor is its own activation image (include/lqer_hip.h)
         rp = L.lqer_padded_r(r)
         xscr = xaq + ((Mp * rp * 2 * al + 255) // 256) * 256
         plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=p["a_t"].data_ptr(), a_limbs=p["a_limbs"], xq=xq, xaq=xaq,
@@ -306,7 +308,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "f16" if mods[0][0]._x_f16 else "bf16",  # the arithmetic type of the main loop's MFMA operands
             "data": "synthetic",
             "config": {"workload": desc_txt, "tokens_per_step_per_gpu": M, "rank": r,
                        "formats": "x %s, W MXINT4/%s, A_out,B_out as x, y fp16" % (

@@ -57,6 +57,11 @@ static int limbs_of(const lqer_qfmt_t& f) {
 }
 static int act_limbs(const lqer_linear_desc_t* d) { return limbs_of(d->x_fmt); }
 static bool x_is_f16(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_PASSTHROUGH_F16; }
+// LQER_Q_PASSTHROUGH_F16: a dense fp16 tensor whose extents are already the padded ones IS the activation image
+static bool f16_image_is_input(const lqer_linear_desc_t* d, const void* x, int64_t M, int64_t ldx) {
+  return x_is_f16(d) && ldx == d->in_features && d->in_features % LQER_K_ALIGN == 0 && M % LQER_M_ALIGN == 0 &&
+         ((uintptr_t)x & 15) == 0;
+}
 static bool need_f16(const lqer_linear_desc_t* d, int dtype, const char* what) {
   if (x_is_f16(d) && dtype != LQER_F16) {
     set_error("%s: x_quantizer LQER_Q_PASSTHROUGH_F16 takes fp16 tensors (dtype %d given)", what, dtype);
@@ -245,7 +250,16 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
   int rc;
   if (x_is_f16(d)) {
     if (!need_f16(d, dtype, "quantize_act_xa")) return LQER_E_INVALID;
-    rc = copy_act_f16_dispatch(x, M, d->in_features, ldx, (bf16_t*)xq, (hipStream_t)stream);
+    if (xq == x) {  // the tensor itself is the image: nothing to write
+      if (!f16_image_is_input(d, x, M, ldx)) {
+        set_error("quantize_act_xa: xq == x needs a dense fp16 tensor with K %% %d == 0, M %% %d == 0, 16-byte aligned",
+                  LQER_K_ALIGN, LQER_M_ALIGN);
+        return LQER_E_INVALID;
+      }
+      rc = LQER_OK;
+    } else {
+      rc = copy_act_f16_dispatch(x, M, d->in_features, ldx, (bf16_t*)xq, (hipStream_t)stream);
+    }
   } else if (d->x_fmt.kind == LQER_Q_PASSTHROUGH) {
     if (!passthrough_width_ok(d->x_fmt, "x_quantizer")) return LQER_E_INVALID;
     rc = split_act_dispatch(x, dtype, M, d->in_features, ldx, act_limbs(d), (bf16_t*)xq, (hipStream_t)stream);
@@ -338,6 +352,7 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   void* xq = ws;
   const size_t rp = lqer_padded_r(d->rank);
   const size_t xl = act_limbs(d), al = xa_limbs(d);
+  if (dtype == LQER_F16 && f16_image_is_input(d, x, M, ldx)) xq = const_cast<void*>(x);  // no copy (never written)
   void* xaq = ws + align_up(Mp * Kp * 2 * xl, 256);
   void* xa_scratch = ws + align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256);
   rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, xa_scratch,

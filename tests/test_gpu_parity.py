@@ -460,6 +460,10 @@ def test_passthrough_activations_vs_oracle(ops, dtype, tol, native, M, K, N):
         assert (y.cpu().float() - want.float()).abs().max() <= 2.0 ** (-9 if dtype == torch.float16 else -6) * ref.abs().max()
     with pytest.raises(RuntimeError, match="pass-through x_quantizer"):
         mod(xin.to(DEV).to(torch.float32 if dtype != torch.float32 else torch.float16))
+    # a strided view takes the copying route (the dense, aligned fp16 tensor above was its own activation image)
+    wide = torch.zeros(M, K + 64, dtype=dtype, device=DEV)
+    wide[:, :K] = xin.to(DEV)
+    assert torch.equal(mod(wide[:, :K]), y)
 
 
 def test_passthrough_fp16_route_falls_back_when_a_weight_scale_leaves_fp16(ops):

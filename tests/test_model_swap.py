@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from bench import MXINT_Q, OPT_Q
+from bench import A16_Q, MXINT_Q, OPT_Q
 
 
 def _tiny_llama():
@@ -81,15 +81,16 @@ class _OracleLinear(nn.Module):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("family", ["llama", "opt"])
+@pytest.mark.parametrize("family", ["llama", "opt", "llama-a16"])
 def test_end_to_end_logits_vs_oracle(family):
     from lqer_amd import LinearFlexibleLqer
     from lqer_amd.models import load_low_rank_dict, quantize_model
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    qc = MXINT_Q if family == "llama" else OPT_Q
-    model = quantize_model(_tiny_llama() if family == "llama" else _tiny_opt(), {"linear": qc}, {"linear": {"rank": 16}})
+    # llama-a16: the reference's INT template (llama-7b-int.toml) - pass-through activations, W4 in blocks of 128
+    qc = {"llama": MXINT_Q, "opt": OPT_Q, "llama-a16": A16_Q}[family]
+    model = quantize_model(_tiny_opt() if family == "opt" else _tiny_llama(), {"linear": qc}, {"linear": {"rank": 16}})
     load_low_rank_dict(model, _ab_dict(model, 16))
     # CPU twin whose projections run the oracle, built from the same parameters before they are quantized in place
     import copy
@@ -106,6 +107,21 @@ def test_end_to_end_logits_vs_oracle(family):
     assert torch.isfinite(got).all()
     err = (got - ref).norm() / ref.norm()
     assert err <= 1e-4, float(err)  # fp32 model: only accumulation order differs, layer after layer
+    if family == "llama-a16":
+        # the same model in fp16: every projection takes the fp16 MFMA route; the bf16-limb route computes the same
+        # exact products in another summation order, so the logits agree to fp16 rounding noise
+        outs = []
+        for native in (True, False):
+            m16 = copy.deepcopy(model).half()
+            for m in m16.modules():
+                if isinstance(m, LinearFlexibleLqer):
+                    m.a16_native = native
+            with torch.no_grad():
+                outs.append(m16(input_ids=ids.to("cuda:0")).logits.float().cpu())
+            assert all(m._x_f16 == native for m in m16.modules() if isinstance(m, LinearFlexibleLqer))
+        assert torch.isfinite(outs[0]).all()
+        assert (outs[0] - outs[1]).norm() / outs[1].norm() <= 3e-3
+        assert (outs[0] - got).norm() / got.norm() <= 5e-2  # (fp16 model against the fp32 one: norms, softmax in fp16)
 
 
 def test_packed_checkpoint_header_mismatch_cpu(tmp_path):
