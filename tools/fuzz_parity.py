@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: LinearFlexibleLqer forward on the GPU vs the CPU oracle over random shapes, ranks, dtypes
 and quantizer configurations (MXINT blocks of 16, OPT-style bias blocks, the INT configuration, pass-through B_out,
-no side path).  Shapes are drawn to reach all three GEMM kernels (small-M, 128-row tiles, 256-row tiles).
+the INT templates as shipped = pass-through activations on the fp16 or the bf16-limb route, no side path).  Shapes are drawn to reach all three GEMM kernels (small-M, 128-row tiles, 256-row tiles).
 usage: python tools/fuzz_parity.py [cases] [seed]"""
 import os, random, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lqer_amd
-from bench import INT_Q, MXINT_Q, OPT_Q, make_case
+from bench import A16_Q, INT_Q, MXINT_Q, OPT_Q, make_case
 from oracle import lqer_oracle as O
 
 
@@ -22,7 +22,7 @@ def one_case(rng):
     K = rng.choice([16, 48, 64, 100, 176, 256, 320, 520, 1000])
     N = rng.choice([16, 40, 160, 256, 300, 1024, 1500]) if kind != "m256" else rng.choice([8192, 16384 + 256])
     r = rng.choice([0, 8, 16, 32, 48, 64, 128])
-    cfgname = rng.choice(["mxint", "opt", "int", "bout_pass"])
+    cfgname = rng.choice(["mxint", "opt", "int", "bout_pass", "a16", "a16", "a16mix"])
     dtype = rng.choice([torch.float16, torch.float16, torch.bfloat16, torch.float32])
     if kind == "m256":
         K = rng.choice([64, 128, 200, 320])
@@ -32,9 +32,10 @@ def one_case(rng):
 
 
 def run_case(M, K, N, r, cfgname, dtype, dev):
-    qc = {"mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q, "bout_pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"})}[cfgname]
+    qc = {"mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q, "bout_pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"}),
+          "a16": A16_Q, "a16mix": dict(A16_Q, B_out_quantizer=MXINT_Q["x_quantizer"])}[cfgname]
     bias = cfgname == "opt"
-    case = make_case(M, K, N, max(r, 1), seed=M * 7919 + K * 31 + N, bias=bias, quantize_ab=cfgname != "int")
+    case = make_case(M, K, N, max(r, 1), seed=M * 7919 + K * 31 + N, bias=bias, quantize_ab=cfgname not in ("int", "a16", "a16mix"))
     x, W, A, B = case[:4]
     b = case[4] if bias else None
     if r == 0:
@@ -49,6 +50,7 @@ def run_case(M, K, N, r, cfgname, dtype, dev):
         sd["bias"] = b
     mod.load_state_dict(sd)
     mod = mod.to(dev).to(dtype)
+    mod.a16_native = (M + K + N) % 3 != 0  # pass-through fp16 activations: mostly the fp16 route, sometimes bf16 limbs
     xin = x.to(dtype)
     y = mod(xin.to(dev)).float().cpu()
     cast = lambda t: None if t is None else t.to(dtype).float()
