@@ -59,3 +59,62 @@ def test_layer_partition_matches_reference_rule():
     units = sweep.projection_units([(4096, 4096, 4), (4096, 11008, 2), (11008, 4096, 1)], parts[0] if False else range(2))
     assert len(units) == 14 and units[0] == (0, 4096, 4096, 0)
     assert sweep.unit_seed(0, 1) != sweep.unit_seed(1, 1) != sweep.unit_seed(1, 0)
+
+
+def _approx_worker(rank, world, port, q):
+    """The sharded approximator's ownership + exchange on CPU: a stand-in for the (GPU-only) factorization writes
+    rank-tagged values, so the result shows who computed what and that everybody received everything."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch.nn as nn
+
+        from bench import MXINT_Q
+        from lqer_amd import LinearFlexibleLqer
+        from lqer_amd.approximate import approximate_model
+
+        class Layer(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.q_proj = LinearFlexibleLqer(32, 48, bias=False, q_config=MXINT_Q, l_config={"rank": 16})
+                self.o_proj = LinearFlexibleLqer(48, 32, bias=False, q_config=MXINT_Q, l_config={"rank": 16})
+
+        class Model(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.layers = nn.ModuleList([Layer() for _ in range(3)])
+
+        calls = []
+
+        def fake_factors(W, w_cfg, r, a_cfg, b_cfg, scale):
+            calls.append(tuple(W.shape))
+            return torch.full((W.shape[1], r), float(rank + 1)), torch.full((r, W.shape[0]), float(-(rank + 1)))
+
+        model = Model()
+        out = approximate_model(model, factors_fn=fake_factors)
+        q.put((rank, len(calls), {k: float(v.flatten()[0]) for k, v in out.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_approximator_two_ranks_gloo():
+    from lqer_amd.approximate import module_owners
+
+    names = [f"model.layers.{l}.self_attn.{p}" for l in range(5) for p in ("q_proj", "k_proj")] + ["lm_head"]
+    own = module_owners(names, 2)  # ceil(5 / 2) = 3 consecutive layers on rank 0, the rest on rank 1
+    assert [own[f"model.layers.{l}.self_attn.q_proj"] for l in range(5)] == [0, 0, 0, 1, 1] and own["lm_head"] == 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_approx_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [n for _, n, _ in res] == [4, 2]  # 3 layers: two on rank 0 (4 modules), one on rank 1 (2 modules)
+    assert res[0][2] == res[1][2]  # every rank ends with the same full dictionary
+    d = res[0][2]
+    assert d["layers.0.q_proj.A"] == 1.0 and d["layers.1.o_proj.B"] == -1.0 and d["layers.2.q_proj.A"] == 2.0 and d["layers.2.o_proj.B"] == -2.0
