@@ -610,3 +610,43 @@ def test_edge_shapes_and_errors(ops):
     # non-contiguous rows
     xb = torch.randn(5, 128, device=DEV)
     assert torch.equal(mod(xb[:, :64]), mod(xb[:, :64].contiguous()))
+
+
+def test_passthrough_abi_errors(ops):
+    """The C ABI refuses what it cannot do exactly: a pass-through format without its significand width, the fp16
+    route with another element type, xq == x for a tensor that is not its own padded image."""
+    import ctypes as C
+
+    from lqer_amd import _lib
+    from lqer_amd._lib import LinearDesc, LinearSizes, QFmt
+
+    L = _lib.lib()
+    mx = QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
+    w4 = QFmt(_lib.Q_MXINT, 4, 128, 8, 127)
+    none = QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+    sz = LinearSizes()
+    d = LinearDesc(256, 256, 16, 0, QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127), w4, none, mx, mx)
+    assert L.lqer_linear_sizes(C.byref(d), 8, C.byref(sz)) != 0 and b"significand" in L.lqer_last_error()
+    one = LinearSizes()
+    assert L.lqer_linear_sizes(C.byref(LinearDesc(256, 256, 16, 0, mx, w4, none, mx, mx)), 8, C.byref(one)) == 0
+    for width, copies in ((8, 1), (11, 2), (24, 3)):
+        d = LinearDesc(256, 256, 16, 0, QFmt(_lib.Q_PASSTHROUGH, width, 0, 8, 127), w4, none, mx, mx)
+        assert L.lqer_linear_sizes(C.byref(d), 8, C.byref(sz)) == 0
+        assert (sz.w_packed, sz.a_t, sz.b_t) == (copies * one.w_packed, copies * one.a_t, one.b_t)
+    d = LinearDesc(256, 256, 16, 0, mx, w4, none, QFmt(_lib.Q_PASSTHROUGH, 16, 0, 8, 127), mx)
+    assert L.lqer_linear_sizes(C.byref(d), 8, C.byref(sz)) == 0 and sz.b_t == 2 * one.b_t
+    # fp16 route: fp16 tensors only; xq == x only for a dense, aligned tensor with padded extents
+    d = LinearDesc(256, 256, 0, 0, QFmt(_lib.Q_PASSTHROUGH_F16, 11, 0, 8, 127), w4, none, none, none)
+    x = torch.zeros(300, 256, dtype=torch.float16, device=DEV)
+    xq = torch.zeros(512 * 256, dtype=torch.float16, device=DEV)
+    args = (x.data_ptr(), None, 0, xq.data_ptr(), None, None, 0, None)
+    assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.BF16, 300, 256, None, 0, xq.data_ptr(), None, None, 0, None) != 0
+    assert b"fp16 tensors" in L.lqer_last_error()
+    assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.F16, 300, 256, None, 0, x.data_ptr(), None, None, 0, None) != 0
+    assert b"xq == x" in L.lqer_last_error()  # 300 rows: not a multiple of 256
+    assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.F16, 256, 256, None, 0, x.data_ptr(), None, None, 0, None) == 0
+    assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.F16, 300, 256, None, 0, xq.data_ptr(), None, None, 0, None) == 0
+    torch.cuda.synchronize()
+    bad = QFmt(_lib.Q_PASSTHROUGH_F16, 11, 0, 8, 127)
+    d = LinearDesc(256, 256, 16, 0, mx, w4, none, bad, mx)  # the fp16 kind is an x format only
+    assert L.lqer_lowrank_xa(C.byref(d), xq.data_ptr(), 8, xq.data_ptr(), 1, xq.data_ptr(), xq.data_ptr(), 1 << 16, None) != 0
