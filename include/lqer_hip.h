@@ -207,7 +207,7 @@ int lqer_desc_limbs(const lqer_linear_desc_t* desc, int* act_limbs, int* xa_limb
  * this call leaves flags[0] (a weight block scale outside the fp16 range 2^-24 .. 2^13) and flags[1] (an element of
  * A that is not an fp16 number) at zero (device int32[2]); otherwise use LQER_Q_PASSTHROUGH with width 11.
  * A_out / xaq / b_t are as for LQER_Q_PASSTHROUGH.  Calls take dtype = LQER_F16.  A dense tensor (ldx == K) with
- * K % LQER_K_ALIGN == 0, M % LQER_M_ALIGN == 0 and 16-byte alignment already is its image: lqer_linear_forward
+ * K % LQER_K_ALIGN == 0, M % LQER_M_ALIGN == 0 (or M <= 64) and 16-byte alignment already is its image: lqer_linear_forward
  * then skips the copy, and the split API accepts xq == x in lqer_quantize_act_xa / lqer_linear_gemm. */
 int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r,
                      void* a_t_f16, int32_t* flags, void* stream);

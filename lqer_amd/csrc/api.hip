@@ -58,8 +58,11 @@ static int limbs_of(const lqer_qfmt_t& f) {
 static int act_limbs(const lqer_linear_desc_t* d) { return limbs_of(d->x_fmt); }
 static bool x_is_f16(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_PASSTHROUGH_F16; }
 // LQER_Q_PASSTHROUGH_F16: a dense fp16 tensor whose extents are already the padded ones IS the activation image
+// (M a multiple of the row padding: the tile kernels read whole row tiles; M <= 64: the small-M kernel and the side
+// GEMM never read past row M - 1 - unless B_out blocks other than 16 send a decode-size call to the tile kernel)
 static bool f16_image_is_input(const lqer_linear_desc_t* d, const void* x, int64_t M, int64_t ldx) {
-  return x_is_f16(d) && ldx == d->in_features && d->in_features % LQER_K_ALIGN == 0 && M % LQER_M_ALIGN == 0 &&
+  const bool smallm = M <= 64 && !(d->rank > 0 && d->b_out_fmt.kind == LQER_Q_MXINT && d->b_out_fmt.block != 16);
+  return x_is_f16(d) && ldx == d->in_features && d->in_features % LQER_K_ALIGN == 0 && (M % LQER_M_ALIGN == 0 || smallm) &&
          ((uintptr_t)x & 15) == 0;
 }
 static bool need_f16(const lqer_linear_desc_t* d, int dtype, const char* what) {
@@ -252,7 +255,7 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
     if (!need_f16(d, dtype, "quantize_act_xa")) return LQER_E_INVALID;
     if (xq == x) {  // the tensor itself is the image: nothing to write
       if (!f16_image_is_input(d, x, M, ldx)) {
-        set_error("quantize_act_xa: xq == x needs a dense fp16 tensor with K %% %d == 0, M %% %d == 0, 16-byte aligned",
+        set_error("quantize_act_xa: xq == x needs a dense fp16 tensor with K %% %d == 0, M %% %d == 0 or M <= 64, 16-byte aligned",
                   LQER_K_ALIGN, LQER_M_ALIGN);
         return LQER_E_INVALID;
       }

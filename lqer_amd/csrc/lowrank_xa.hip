@@ -13,7 +13,10 @@ namespace lqer {
 
 constexpr int XA_ROWS = 32;       // token rows per wave
 constexpr int XA_MAX_TILES = 8;   // rp <= 256
-constexpr int XA_TARGET_WAVES = 2048;
+#ifndef LQER_XA_TARGET
+#define LQER_XA_TARGET 2048
+#endif
+constexpr int XA_TARGET_WAVES = LQER_XA_TARGET;
 #ifndef LQER_QX_K
 #define LQER_QX_K 256
 #endif
@@ -52,7 +55,7 @@ size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp) {
 // fragment (fetched from L2) feeds RG MFMAs: with one row group per wave the A^T stream, rp/32 times the activation
 // stream, is the bound.
 template <int NT, int RG, bool XF16 = false>  // XF16: fp16 activation image and fp16 A^T (LQER_Q_PASSTHROUGH_F16)
-__global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t Kp,
+__global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t M, int64_t Kp,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
                                                     float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
 #pragma unroll
   for (int u = 0; u < RG; ++u) {
     const int rg = wr * RG + u < plan.row_groups ? wr * RG + u : plan.row_groups - 1;  // a clamped duplicate is not stored
-    xrow[u] = xq + ((int64_t)rg * XA_ROWS + r) * Kp + 32 * h;
+    const int64_t row = (int64_t)rg * XA_ROWS + r;  // rows past M repeat the last one (never read beyond the tensor: the
+    xrow[u] = xq + (row < M ? row : M - 1) * Kp + 32 * h;  // image may be the caller's own fp16 tensor); their results are unused
   }
   // the next window's activation loads are issued before this window's MFMAs (the stream from HBM is the bound)
   bf16x8 xn[RG][4];
@@ -478,9 +482,9 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
 #define XA_CASE(NT, RG)                                                                           \
   case NT:                                                                                        \
     if (x_f16)                                                                                    \
-      k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);  \
+      k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);  \
     else                                                                                          \
-      k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, Kp, a_t, a_limbs, rp, plan, scratch);        \
+      k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);     \
     break;
   switch (nt) {
     XA_CASE(1, 2) XA_CASE(2, 2) XA_CASE(3, 2) XA_CASE(4, 2) XA_CASE(5, 1) XA_CASE(6, 1) XA_CASE(7, 1) XA_CASE(8, 1)

@@ -643,7 +643,8 @@ def test_passthrough_abi_errors(ops):
     assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.BF16, 300, 256, None, 0, xq.data_ptr(), None, None, 0, None) != 0
     assert b"fp16 tensors" in L.lqer_last_error()
     assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.F16, 300, 256, None, 0, x.data_ptr(), None, None, 0, None) != 0
-    assert b"xq == x" in L.lqer_last_error()  # 300 rows: not a multiple of 256
+    assert b"xq == x" in L.lqer_last_error()  # 300 rows: neither a multiple of 256 nor a decode size
+    assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.F16, 33, 256, None, 0, x.data_ptr(), None, None, 0, None) == 0
     assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.F16, 256, 256, None, 0, x.data_ptr(), None, None, 0, None) == 0
     assert L.lqer_quantize_act_xa(C.byref(d), x.data_ptr(), _lib.F16, 300, 256, None, 0, xq.data_ptr(), None, None, 0, None) == 0
     torch.cuda.synchronize()
