@@ -314,8 +314,8 @@ class SharedActivation:
 
     A member's forward uses the shared images only when it is handed the very tensor object the images were made
     from, unmodified (object identity + version counter) - an equal-looking tensor at a recycled address never hits.
-    Requirements checked at construction: same in_features, same x / A_out quantizers with A_out blocks of 16,
-    rank > 0 for every member."""
+    Requirements checked at construction: same in_features, same block_fp x / A_out quantizers, A_out blocks of 16 or
+    one block per row with equal power-of-two ranks (a multiple of 16), rank > 0 for every member."""
 
     def __init__(self, members):
         self.members = list(members)
@@ -323,7 +323,18 @@ class SharedActivation:
         ok = all(isinstance(m, LinearFlexibleLqer) and m.rank > 0 and m.in_features == m0.in_features for m in self.members)
         key = lambda f: (f.kind, f.width, f.block, f.exp_width, f.exp_bias)
         ok = ok and all(key(m._fmt["x"]) == key(m0._fmt["x"]) and key(m._fmt["A_out"]) == key(m0._fmt["A_out"]) for m in self.members)
-        ok = ok and m0._fmt["A_out"].kind == _lib.Q_MXINT and m0._fmt["A_out"].block == 16 and len(self.members) > 1
+        # A_out blocks must not straddle two members' columns of the concatenated x A: blocks of 16 (the padded ranks are
+        # multiples of 16), or one block per member row (block_size [1, -1], the INT configurations) with equal ranks -
+        # the group then quantizes in blocks of one member's padded rank
+        ao = m0._fmt["A_out"] if ok else None
+        self._aout_block = 16
+        if ok and ao.kind == _lib.Q_MXINT and ao.block != 16:
+            rps = {(m.rank + 15) // 16 * 16 for m in self.members}
+            whole = ao.block <= 0 or all(ao.block >= m.rank for m in self.members)
+            rp0 = next(iter(rps))
+            ok = whole and len(rps) == 1 and all(m.rank == rp0 for m in self.members) and (rp0 & (rp0 - 1)) == 0
+            self._aout_block = rp0
+        ok = ok and ao.kind == _lib.Q_MXINT and len(self.members) > 1
         ok = ok and m0._fmt["x"].kind == _lib.Q_MXINT  # (pass-through activations: every member splits x itself)
         self.enabled = bool(ok)
         self._cat = None      # concatenated A^T limb image + member offsets
@@ -374,6 +385,7 @@ class SharedActivation:
         if fresh:
             gdesc = m0._desc()
             gdesc.rank = self._cat["rp_total"]
+            gdesc.a_out_fmt.block = self._aout_block  # (one block per member row -> blocks of a member's rank)
             Mp, Kp = L.lqer_padded_m(M), L.lqer_padded_k(K)
             key = (M, dev)
             if key not in self._buf:

@@ -254,6 +254,45 @@ def test_shared_activation_groups_gpu():
 
 
 @pytest.mark.gpu
+def test_shared_activation_groups_int_config_gpu():
+    """The INT configuration (one activation block per token, one A_out block per row) also shares q/k/v and gate/up:
+    the group re-quantizes x A in blocks of one member's rank, i.e. exactly each member's own row block."""
+    from bench import INT_Q
+    from lqer_amd.models import load_low_rank_dict, quantize_model
+
+    dev = torch.device("cuda:0")
+    qc, lc = {"linear": INT_Q}, {"linear": {"rank": 16}}
+    shared = quantize_model(_tiny_llama(), qc, lc, share_inputs=True)
+    plain = quantize_model(_tiny_llama(), qc, lc, share_inputs=False)
+    ab = _ab_dict(shared, 16)
+    load_low_rank_dict(shared, ab)
+    load_low_rank_dict(plain, ab)
+    shared, plain = shared.to(dev), plain.to(dev)
+    grp = shared.model.layers[0].self_attn.q_proj._group
+    assert grp is not None and grp.enabled and grp._aout_block == 16
+    ids = torch.randint(0, 320, (2, 24), generator=torch.Generator().manual_seed(7)).to(dev)
+    with torch.no_grad():
+        a = shared(input_ids=ids).logits.float().cpu()
+        b = plain(input_ids=ids).logits.float().cpu()
+    assert grp._x is not None  # the shared images were used
+    assert (a - b).norm() / b.norm() <= 5e-5
+    # rank 48 is not a power of two and rank 24 is not a multiple of 16: one block per row cannot be cut per member
+    for r in (48, 24):
+        odd = quantize_model(_tiny_llama(), qc, {"linear": {"rank": r}}, share_inputs=True)
+        assert odd.model.layers[0].self_attn.q_proj._group is None
+    r64 = quantize_model(_tiny_llama(), qc, {"linear": {"rank": 64}}, share_inputs=True)
+    g64 = r64.model.layers[0].mlp.gate_proj._group
+    assert g64 is not None and g64._aout_block == 64
+    load_low_rank_dict(r64, _ab_dict(r64, 64))
+    p64 = quantize_model(_tiny_llama(), qc, {"linear": {"rank": 64}}, share_inputs=False)
+    load_low_rank_dict(p64, _ab_dict(p64, 64))
+    with torch.no_grad():
+        a = r64.to(dev)(input_ids=ids).logits.float().cpu()
+        b = p64.to(dev)(input_ids=ids).logits.float().cpu()
+    assert (a - b).norm() / b.norm() <= 5e-5
+
+
+@pytest.mark.gpu
 def test_quantized_attention_end_to_end_gpu():
     """enable_quantized_attention: both attention products of every layer go through matmul_flexible (reference
     llama_decoder.py:259-297).  Logits against a CPU twin whose projections AND attention products run the oracle."""
