@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, metavar="G",
+                    help="capture G consecutive steps in one hipGraph and replay it steps/G times (launch-bound decode sizes; "
+                         "G ~ the number of Linears a model pushes a token through)")
     ap.add_argument("--check", action="store_true", help="also verify y against the CPU oracle (rank 0)")
     args = ap.parse_args()
 
@@ -195,12 +198,16 @@ def main():
             xq = xd.data_ptr()  # fp16 route: a dense, aligned fp16 tensor is its own activation image (include/lqer_hip.h)
         rp = L.lqer_padded_r(r)
         xscr = xaq + ((Mp * rp * 2 * al + 255) // 256) * 256
+        nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
+        gscr = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+        if L.lqer_decode_partials(C.byref(desc), M):
+            xaq, gscr = None, nscr  # decode route: the GEMM reduces the partial tiles of x A left in the scratch itself
         plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=p["a_t"].data_ptr(), a_limbs=p["a_limbs"], xq=xq, xaq=xaq,
-                          xscr=xscr, nscr=L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M), w=p["w"].data_ptr(),
+                          xscr=xscr, nscr=nscr, w=p["w"].data_ptr(),
                           b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),
-                          gscr=L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M), K=K, N=N, reps=reps))
+                          gscr=gscr, K=K, N=N, reps=reps))
 
-    def step(timed: bool):
+    def step(timed: bool, stream=stream):
         for pl in plans:
             K, N = pl["K"], pl["N"]
             for _ in range(pl["reps"]):
@@ -222,17 +229,38 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
+    graph = None
+    if args.graph:
+        # launch-bound steps (decode sizes: three ~3 us kernels): capture one step in a hipGraph and replay it.  The
+        # kernels cannot be bracketed with events inside a graph, so the roofline sample is taken from ungraphed
+        # launches after the timed region.
+        if args.steps % args.graph:
+            sys.exit("--steps must be a multiple of --graph")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(args.graph):
+                step(False, torch.cuda.current_stream(dev).cuda_stream)
+        graph.replay()
+        torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    if graph is not None:
+        for _ in range(args.steps // args.graph):
+            graph.replay()
+    else:
+        for _ in range(args.steps):
+            step(True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if graph is not None:
+        for _ in range(min(args.steps, 4 * EV_EVERY)):
+            step(True)
+        torch.cuda.synchronize()
     elapsed = sweep.max_over_ranks(elapsed, dev)
     checksums = sweep.gather_checksums(float(mods[0][5].float().sum().item()), dev)
 
@@ -317,6 +345,7 @@ def main():
                            qc["w_quantizer"]["block_size"][-1]),
                        "sharding": "independent Linear units per rank, no data-path collective"},
             "tokens_per_s": round(tokens_rank * world * args.steps / elapsed, 1),
+            "launch": ("hipGraph replay, %d steps per graph" % args.graph) if graph is not None else "direct launches",
             "roofline": roofline,
             "rank_checksums": [round(c, 3) for c in checksums],
         }

@@ -179,6 +179,14 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
                      const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
                      size_t scratch_bytes, void* stream);
 
+/* Decode sizes (launch-bound: each kernel runs ~3 us).  Returns 1 when, for this descriptor and token count, the
+ * re-quantized side product never has to be materialised: M <= 64, x and A_out block_fp in blocks of 16 (width <= 9),
+ * padded rank <= 64, B_out pass-through or in blocks of 16.  Then lqer_quantize_act_xa may be called with
+ * xaq_bf16 == NULL - it leaves the split-K partial tiles of x A in `scratch` and skips the reduce launch - and
+ * lqer_linear_gemm with xaq_bf16 == NULL and the SAME scratch buffer (scratch_bytes = lqer_lowrank_xa_scratch_bytes):
+ * the GEMM sums the tiles in the same fixed order and applies A_out itself.  lqer_linear_forward does this on its own. */
+int lqer_decode_partials(const lqer_linear_desc_t* desc, int64_t M);
+
 /* lqer_linear_gemm with an explicit row stride of xaq (elements; a multiple of 8, >= the padded rank): Linears that
  * share one input (q/k/v, gate/up; llama_decoder.py:246-248, :176) can run ONE lqer_quantize_act_xa over the
  * concatenation of their A matrices (descriptor rank = sum of the padded ranks, a_t = the concatenated limb image)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "lqer_linear_gemm_ld": (_i, [_dp, _vp, _i64, _vp, _vp, _i64, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),
     "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
+    "lqer_decode_partials": (_i, [_dp, _i64]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
 }
 

@@ -65,6 +65,15 @@ static bool f16_image_is_input(const lqer_linear_desc_t* d, const void* x, int64
   return x_is_f16(d) && ldx == d->in_features && d->in_features % LQER_K_ALIGN == 0 && (M % LQER_M_ALIGN == 0 || smallm) &&
          ((uintptr_t)x & 15) == 0;
 }
+// Decode sizes with the fused-quantizer formats: the small-M GEMM reduces the split-K partial tiles of x A itself
+// (lqer_quantize_act_xa / lqer_linear_gemm with xaq == NULL), one launch less on a launch-bound path.
+static bool decode_partials_ok(const lqer_linear_desc_t* d, int64_t M) {
+  if (!d || d->rank <= 0 || M <= 0 || M > 64) return false;
+  if (d->x_fmt.kind != LQER_Q_MXINT || d->a_out_fmt.kind != LQER_Q_MXINT) return false;
+  if (!xa_fused_partials_ok(make_qp(d->x_fmt), make_qp(d->a_out_fmt), d->rank)) return false;
+  const lqer_qfmt_t& bo = d->b_out_fmt;  // the small-M kernel: B_out pass-through or blocks of 16
+  return bo.kind == LQER_Q_PASSTHROUGH || (bo.kind == LQER_Q_MXINT && bo.block == 16);
+}
 static bool need_f16(const lqer_linear_desc_t* d, int dtype, const char* what) {
   if (x_is_f16(d) && dtype != LQER_F16) {
     set_error("%s: x_quantizer LQER_Q_PASSTHROUGH_F16 takes fp16 tensors (dtype %d given)", what, dtype);
@@ -243,6 +252,18 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
     set_error("quantize_act_xa: bad argument");
     return LQER_E_INVALID;
   }
+  if (d->rank > 0 && a_t && !xaq) {  // partial tiles only: the GEMM reduces them (decode sizes)
+    if (!decode_partials_ok(d, M)) {
+      set_error("quantize_act_xa: xaq == NULL needs M <= 64, x / A_out block_fp in blocks of 16 (width <= 9), padded rank <= 64 "
+                "and B_out pass-through or in blocks of 16");
+      return LQER_E_INVALID;
+    }
+    const int rc = quant_xa_fused_dispatch(x, dtype, M, d->in_features, ldx, make_qp(d->x_fmt), (bf16_t*)xq, (const bf16_t*)a_t,
+                                           a_limbs, d->rank, make_qp(d->a_out_fmt), nullptr, (float*)scratch, scratch_bytes,
+                                           (hipStream_t)stream);
+    if (rc == LQER_E_UNSUPPORTED) set_error("quantize_act_xa: scratch too small for the partial tiles");
+    return rc == LQER_E_UNSUPPORTED ? LQER_E_WORKSPACE : rc;
+  }
   if (d->rank > 0 && a_t && xaq) {
     if (!fmt_ok(&d->x_fmt, "x_quantizer", 9) || !fmt_ok(&d->a_out_fmt, "A_out_quantizer", 9)) return LQER_E_UNSUPPORTED;
     const int rc = quant_xa_fused_dispatch(x, dtype, M, d->in_features, ldx, make_qp(d->x_fmt), (bf16_t*)xq,
@@ -293,8 +314,9 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
     return LQER_E_INVALID;
   }
   const bool lowrank = d->rank > 0;
-  if (lowrank && (!xaq || !b_t)) {
-    set_error("linear_gemm: rank %d but no side-path operands", d->rank);
+  const bool from_partials = lowrank && !xaq && b_t && scratch && decode_partials_ok(d, M);
+  if (lowrank && ((!xaq && !from_partials) || !b_t)) {
+    set_error("linear_gemm: rank %d but no side-path operands (xaq == NULL: only the decode route, see lqer_decode_partials)", d->rank);
     return LQER_E_INVALID;
   }
   if (!fmt_ok(&d->w_fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
@@ -311,7 +333,7 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
   if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (lowrank && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
     return LQER_E_INVALID;
   const int xl = act_limbs(d), al = lowrank ? xa_limbs(d) : 1;
-  if (lowrank && (xaq_ld < lqer_padded_r(d->rank) * al || xaq_ld % 8 != 0 || ((uintptr_t)xaq & 15) != 0)) {
+  if (lowrank && !from_partials && (xaq_ld < lqer_padded_r(d->rank) * al || xaq_ld % 8 != 0 || ((uintptr_t)xaq & 15) != 0)) {
     set_error("linear_gemm: xaq row stride %lld (elements) must be a multiple of 8 and at least the padded rank %lld, "
               "xaq 16-byte aligned", (long long)xaq_ld, (long long)lqer_padded_r(d->rank));
     return LQER_E_INVALID;
@@ -331,6 +353,15 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
   g.b_limbs = b_limbs;
   g.w_mbits = d->w_fmt.width - 1;
   if (lowrank) g.bout = make_qp(d->b_out_fmt);
+  if (from_partials) {
+    xa_fused_plan(M, d->in_features, d->rank, &g.xa_nchunk, &g.xa_cstride);
+    if (scratch_bytes < (size_t)g.xa_nchunk * g.xa_cstride * sizeof(float)) {
+      set_error("linear_gemm: scratch %zu B does not hold the partial tiles of x A", scratch_bytes);
+      return LQER_E_WORKSPACE;
+    }
+    g.xa_part = (const float*)scratch;
+    g.aout = make_qp(d->a_out_fmt);
+  }
   return gemm_dispatch(g, dtype, lowrank, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
@@ -358,6 +389,12 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   if (dtype == LQER_F16 && f16_image_is_input(d, x, M, ldx)) xq = const_cast<void*>(x);  // no copy (never written)
   void* xaq = ws + align_up(Mp * Kp * 2 * xl, 256);
   void* xa_scratch = ws + align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256);
+  if (decode_partials_ok(d, M) && a_t && b_t) {  // two launches: the GEMM sums the partial tiles of x A itself
+    const size_t nscr = lqer_lowrank_xa_scratch_bytes(d, M);
+    rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, nullptr, xa_scratch, nscr, stream);
+    if (rc) return rc;
+    return lqer_linear_gemm(d, xq, M, w_packed, nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch, nscr, stream);
+  }
   rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, xa_scratch,
                             lqer_lowrank_xa_scratch_bytes(d, M), stream);
   if (rc) return rc;
@@ -374,6 +411,8 @@ int lqer_desc_limbs(const lqer_linear_desc_t* d, int* act, int* xa) {
   if (xa) *xa = d->rank > 0 ? xa_limbs(d) : 1;
   return LQER_OK;
 }
+
+int lqer_decode_partials(const lqer_linear_desc_t* d, int64_t M) { return decode_partials_ok(d, M) ? 1 : 0; }
 
 int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r, void* a_t_f16,
                      int32_t* flags, void* stream) {

@@ -249,6 +249,13 @@ struct GemmArgs {
   int64_t ldy;
   int M, N, Np, Kp, rp, b_limbs;
   int x_f16;           // xq holds fp16 bits (pass-through fp16 activations): LQER_F16X kernels
+  // decode sizes (small-M kernel only): instead of xaq, the split-K partial tiles of x A left by the fused quantize
+  // kernel - part[c][m][rp] fp32, c < xa_nchunk, chunk stride xa_cstride floats - summed in ascending c and
+  // re-quantized (A_out, blocks of 16) by the GEMM itself: one launch less on a launch-bound path
+  const float* xa_part;
+  int xa_nchunk;
+  int64_t xa_cstride;
+  QP aout;
   int w_mbits;
   QP bout;
   int tiles_m, tiles_n;
@@ -273,7 +280,9 @@ int split_act_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t l
 size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp);
 int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, bf16_t* xq,
                             const bf16_t* a_t, int a_limbs, int64_t r, const QP& qa, bf16_t* xaq, float* scratch,
-                            size_t scratch_bytes, hipStream_t st);
+                            size_t scratch_bytes, hipStream_t st);  // xaq == nullptr: leave the partial tiles in scratch
+bool xa_fused_partials_ok(const QP& qx, const QP& qa, int64_t r);  // formats the GEMM can reduce itself (decode sizes)
+void xa_fused_plan(int64_t M, int64_t K, int64_t r, int* nchunk, int64_t* cstride);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
 bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: at least two rounds of 256 x 256 tiles

@@ -37,6 +37,7 @@ template <int DT, bool LOWRANK, int BOUT, int MT>
 __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
   constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image and fp16 weight fragments in the main loop (gemm_w4a8.hip)
   __shared__ __attribute__((aligned(16))) float red[(SM_NW - 1) * MT * 4 * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t xaq_l[LOWRANK ? MT * 16 * 64 : 8];  // [token][rp <= 64]: x A after A_out (partials mode)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int row = lane & 15, q = lane >> 4;  // weight row / token within the tile; k group
@@ -58,11 +59,58 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
   bf16x8 sp_b = zero8, sp_x[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) sp_x[t] = zero8;
+  const bool from_partials = LOWRANK && g.xa_part != nullptr;
   if (LOWRANK && wave == 0 && g.b_limbs > 0 && 8 * q < g.rp) {
     sp_b = *(const bf16x8*)(g.bt + (int64_t)(n0 + row) * g.rp + 8 * q);
+    if (!from_partials) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-      if (t * 16 + row < g.M) sp_x[t] = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.xaq_ld + 8 * q);
+      for (int t = 0; t < MT; ++t)
+        if (t * 16 + row < g.M) sp_x[t] = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.xaq_ld + 8 * q);
+    }
+  }
+  if constexpr (LOWRANK) {
+    if (from_partials) {
+      // x A = sum over the split-K chunks, ascending (the order of k_xa_reduce4: same bits as the three-launch route),
+      // then A_out in blocks of 16 = 4 consecutive lanes; the bf16 image goes to LDS for wave 0's epilogue (it is read
+      // after the combine barrier below).  One lane per 4 rank entries; M * rp / 4 <= 1024 items on 512 lanes.
+      const int total = g.M * g.rp / 4;
+      for (int base = 0; base < total; base += 64 * SM_NW) {
+        const int item = base + (int)threadIdx.x;
+        const bool live = item < total;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+          const float* src = g.xa_part + (int64_t)item * 4;
+          int c = 0;
+          for (; c + 8 <= g.xa_nchunk; c += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(src + (c + u) * g.xa_cstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum.x += v[u].x, sum.y += v[u].y, sum.z += v[u].z, sum.w += v[u].w;
+          }
+          for (; c < g.xa_nchunk; ++c) {
+            const float4 v = *(const float4*)(src + c * g.xa_cstride);
+            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+          }
+        }
+        float amax = fmaxf(fmaxf(fabsf(sum.x), fabsf(sum.y)), fmaxf(fabsf(sum.z), fabsf(sum.w)));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        if (live) {
+          const bool any = amax > 0.f;
+          const int e = any ? block_exponent(amax, g.aout) : 0;
+          const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+          uint32_t w[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float m0v = any ? mxint_mantissa(v[2 * i], e, g.aout) : 0.f;
+            const float m1v = any ? mxint_mantissa(v[2 * i + 1], e, g.aout) : 0.f;
+            w[i] = exact_bf16_bits(ldexpf(m0v, e - g.aout.mbits)) | (exact_bf16_bits(ldexpf(m1v, e - g.aout.mbits)) << 16);
+          }
+          *(uint2*)(xaq_l + item * 4) = make_uint2(w[0], w[1]);
+        }
+      }
+    }
   }
 
   auto load_panel = [&](int kt, SmPanel& p, bf16x8 (&x)[MT][2]) {
@@ -140,6 +188,7 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if constexpr (LOWRANK) {
       const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (from_partials && 8 * q < g.rp && t * 16 + row < g.M) sp_x[t] = *(const bf16x8*)(xaq_l + (t * 16 + row) * g.rp + 8 * q);
       if (g.b_limbs > 0) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_b, sp_x[t], s, 0, 0, 0);  // prefetched
       for (int l = 0; l < g.b_limbs; ++l)
         for (int ks = (l == 0 ? 1 : 0); ks * 32 < g.rp; ++ks) {
@@ -147,7 +196,9 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
           bf16x8 bb = zero, xv = zero;
           if (j0 < g.rp) {
             bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + row) * g.rp + j0);
-            if (t * 16 + row < g.M) xv = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.xaq_ld + j0);
+            if (t * 16 + row < g.M)
+              xv = from_partials ? *(const bf16x8*)(xaq_l + (t * 16 + row) * g.rp + j0)
+                                 : *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.xaq_ld + j0);
           }
           s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, xv, s, 0, 0, 0);
         }

@@ -400,6 +400,19 @@ __global__ __launch_bounds__(QX_K) void k_quant_xa16(const void* __restrict__ x,
   }
 }
 
+// Decode sizes: the small-M GEMM can sum the fused kernel's partial tiles and apply A_out itself (gemm_smallm.hip) when
+// A_out blocks are 16 wide - the reduce launch is then skipped.
+bool xa_fused_partials_ok(const QP& qx, const QP& qa, int64_t r) {
+  const int rp = (int)lqer_padded_r(r);
+  return qx.kind == LQER_Q_MXINT && qx.block == 16 && qx.mbits <= 8 && rp <= 64 && qa.kind == LQER_Q_MXINT && qa.mbits <= 8 &&
+         qa.block == 16;
+}
+void xa_fused_plan(int64_t M, int64_t K, int64_t r, int* nchunk, int64_t* cstride) {
+  const int64_t Kp = lqer_padded_k(K);
+  *nchunk = (int)((Kp + QX_K - 1) / QX_K);
+  *cstride = ((M + XA_ROWS - 1) / XA_ROWS) * XA_ROWS * lqer_padded_r(r);
+}
+
 // Fused activation quantize + side path.  Returns LQER_E_UNSUPPORTED (without launching) when the shape or
 // formats are outside what the fused kernel covers; the caller then runs the two separate steps.
 int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, bf16_t* xq,
@@ -431,6 +444,7 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
     default: set_error("unknown dtype %d", dtype); return LQER_E_INVALID;
   }
 #undef QX_LAUNCH
+  if (!xaq) return check_launch("quantize_act_xa");  // the consumer reduces the partial tiles itself
   const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
   const unsigned grid2 = (unsigned)((items + 255) / 256);
   switch (G) {

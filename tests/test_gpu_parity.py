@@ -651,3 +651,55 @@ def test_passthrough_abi_errors(ops):
     bad = QFmt(_lib.Q_PASSTHROUGH_F16, 11, 0, 8, 127)
     d = LinearDesc(256, 256, 16, 0, mx, w4, none, bad, mx)  # the fp16 kind is an x format only
     assert L.lqer_lowrank_xa(C.byref(d), xq.data_ptr(), 8, xq.data_ptr(), 1, xq.data_ptr(), xq.data_ptr(), 1 << 16, None) != 0
+
+
+@pytest.mark.parametrize("M,r,bout", [(1, 32, "mx"), (16, 32, "mx"), (17, 64, "mx"), (64, 64, "pass"), (33, 16, "mx")])
+def test_decode_route_reduces_partials_in_the_gemm(ops, M, r, bout):
+    """Decode sizes: lqer_linear_forward runs two launches (the small-M GEMM sums the split-K partial tiles of x A and
+    applies A_out itself).  Same bits as the three-launch split API with a materialised xaq; and not offered for
+    formats or sizes it does not cover."""
+    import ctypes as C
+
+    import lqer_amd
+    from bench import INT_Q, MXINT_Q, make_case
+    from lqer_amd import _lib
+
+    K, N = 1024, 768
+    qc = MXINT_Q if bout == "mx" else dict(MXINT_Q, B_out_quantizer={"name": "passthrough"})
+    x, W, A, B = make_case(M, K, N, r, seed=21)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).half()
+    xd = x.half().to(DEV)
+    y = mod(xd)  # lqer_linear_forward: the decode route
+    L = _lib.lib()
+    desc = mod._desc()
+    assert L.lqer_decode_partials(C.byref(desc), M) == 1 and L.lqer_decode_partials(C.byref(desc), 65) == 0
+    p = mod._packed
+    Mp, Kp, rp = L.lqer_padded_m(M), L.lqer_padded_k(K), L.lqer_padded_r(r)
+    xq = torch.empty(Mp * Kp, dtype=torch.bfloat16, device=DEV)
+    xaq = torch.empty(Mp * rp, dtype=torch.bfloat16, device=DEV)
+    nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
+    scr = torch.empty(nscr, dtype=torch.uint8, device=DEV)
+    y3 = torch.empty_like(y)
+    _lib.check(L.lqer_quantize_act_xa(C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], xq.data_ptr(),
+                                      xaq.data_ptr(), scr.data_ptr(), nscr, None), "xa")
+    _lib.check(L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, p["w"].data_ptr(), xaq.data_ptr(), p["b_t"].data_ptr(), p["b_limbs"],
+                                  None, y3.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, None), "gemm")
+    torch.cuda.synchronize()
+    assert torch.equal(y3, y)
+    # the split API with xaq == NULL is the same two-launch route
+    y2 = torch.empty_like(y)
+    _lib.check(L.lqer_quantize_act_xa(C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], xq.data_ptr(),
+                                      None, scr.data_ptr(), nscr, None), "xa partials")
+    _lib.check(L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, p["w"].data_ptr(), None, p["b_t"].data_ptr(), p["b_limbs"],
+                                  None, y2.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, None), "gemm from partials")
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y)
+    # not offered: per-token blocks (INT configuration), more than 64 tokens
+    di = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=INT_Q, l_config={"rank": r})._desc()
+    assert L.lqer_decode_partials(C.byref(di), M) == 0
+    assert L.lqer_quantize_act_xa(C.byref(di), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], xq.data_ptr(),
+                                  None, scr.data_ptr(), nscr, None) != 0
+    assert L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), 65, p["w"].data_ptr(), None, p["b_t"].data_ptr(), p["b_limbs"],
+                              None, y2.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, None) != 0
