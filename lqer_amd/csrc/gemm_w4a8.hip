@@ -123,7 +123,9 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 #define STAMP(i)
 #endif
 
-template <int DT, bool LOWRANK, int BOUT>  // BOUT: 0 pass-through, 1 blocks of 16 (max in registers), 2 any block (max from the pre-pass)
+// BOUT: 0 pass-through, 1 blocks of 16 (max in registers), 2 any block (max from the pre-pass).  STAGED: the side product's
+// operands go through LDS (below) - a separate instantiation, so that the direct route keeps its own register allocation.
+template <int DT, bool LOWRANK, int BOUT, bool STAGED = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image, weights expanded to fp16, v_mfma_f32_32x32x16_f16
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -195,6 +197,46 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   const uint32_t fw_addr = lds0 + OFF_R + (nw >> 4) * LQER_PANEL_BYTES + (nw & 15) * 32 + lh * 16;
   const uint32_t fe_addr = lds0 + OFF_R + (nw >> 4) * LQER_PANEL_BYTES + (nw & 15) * 4;  // + 512
 
+  // ---- side path, first half: fetch before the ring prefetch -----------------------------------------------------
+  // acc = Q_Bout(xAq @ B) + bias opens the accumulators.  The tile's rows of xAq are staged through LDS - 64 rank
+  // entries per pass, in the ring slot that is not yet a prefetch target (slot DEPTH), in the activation tile's own
+  // swizzled layout - and this wave's B^T fragments of a pass are fetched in one batch: one memory latency per pass
+  // instead of one per 16-deep slice, no 8-fold refetch of xAq by the 8 waves.  The loads of pass 0 are issued BEFORE
+  // the ring prefetch (loads return in order: their results can then be awaited while the prefetch is in flight), and
+  // the staging writes / fragment reads are asm statements, invisible to the waitcnt pass (see above).
+  constexpr int STG = STAGED ? BM * 8 / 512 : 1;  // staged 16-byte chunks per thread and pass
+  u32x4 stg[STG];
+  bf16x8 sb[STAGED ? 2 : 1][STAGED ? 4 : 1];  // B^T fragments of one limb of the pass, double-buffered
+  const uint32_t stage = lds0 + OFF_A + (NSLOT - 1) * A_SLOT;
+  const bf16_t* const bt_row = STAGED ? g.bt + (int64_t)(n0 + wn * 32 + l31) * g.rp + 8 * lh : nullptr;
+  auto side_fetch_b = [&](int p0, int l, auto buf_c) {  // limb l of this wave's B^T fragments -> sb[buf]
+    constexpr int BUF = decltype(buf_c)::value;
+    if constexpr (STAGED) {
+      const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (l < g.b_limbs && ks * 16 < cols) sb[BUF][ks] = *(const bf16x8*)(bt_row + (int64_t)l * g.Np * g.rp + p0 + ks * 16);
+    }
+  };
+  auto side_fetch = [&](int p0) {
+    if constexpr (!STAGED) return;
+    const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;  // a multiple of 16
+    const int cpr = cols >> 3;                          // 16-byte chunks per row
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = tid + 512 * j;
+      if (c < BM * cpr) {
+        const int row = c / cpr, ch = c - row * cpr;
+        stg[j] = *(const u32x4*)(g.xaq + (int64_t)(m0 + row) * g.xaq_ld + p0 + 8 * ch);
+      }
+    }
+    side_fetch_b(p0, 0, std::integral_constant<int, 0>{});
+  };
+  // (a side product of at most two 16-deep slices - rank <= 32 with one limb - is cheaper fetched directly: the two
+  // barriers of the staged route cost more than they save there; launch_gemm picks the instantiation)
+  constexpr bool side_staged = LOWRANK && STAGED;
+  if constexpr (side_staged) side_fetch(0);
+
   // prologue loads: steps 0 .. DEPTH-1
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue_loads(d, d);  // (past the end of K: dropped by the buffer range check)
@@ -207,15 +249,54 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 
   // ---- low-rank prologue: acc = Q_Bout(xAq @ B) + bias ----------------------------------------
   if constexpr (LOWRANK) {
-    for (int l = 0; l < g.b_limbs; ++l) {
-      for (int ks = 0; ks < g.rp / 16; ++ks) {
-        const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+    if constexpr (!side_staged) {
+      for (int l = 0; l < g.b_limbs; ++l) {
+        for (int ks = 0; ks < g.rp / 16; ++ks) {
+          const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa, acc[i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) {
+            const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa, acc[i], 0, 0, 0);
+          }
         }
       }
+    }
+    if constexpr (side_staged)
+    for (int p0 = 0; p0 < g.rp; p0 += 64) {
+      const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;
+      const int cpr = cols >> 3;
+      if (p0) {
+        asm volatile("s_barrier" ::: "memory");  // the previous pass's fragment reads are done (lgkmcnt(0) below)
+        side_fetch(p0);
+      }
+#pragma unroll
+      for (int j = 0; j < STG; ++j) {
+        const int c = tid + 512 * j;
+        if (c < BM * cpr) {
+          const int row = c / cpr, ch = c - row * cpr;
+          lds_write128(stage + swz(row, ch), stg[j]);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      auto limb = [&](int l, auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
+        if (l >= g.b_limbs) return;
+        side_fetch_b(p0, l + 1, std::integral_constant<int, BUF ^ 1>{});  // the next limb's fragments, under this limb's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks * 16 < cols) {
+            const uint32_t fa = stage + swz(l31, 2 * ks + lh);  // m tile i: + i * 4096 (row + 32 keeps the swizzle)
+            bf16x8 x0 = lds_read128<0>(fa), x1 = lds_read128<4096>(fa), x2 = lds_read128<8192>(fa), x3 = lds_read128<12288>(fa);
+            lds_wait(x0, x1, x2, x3);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x3, acc[3], 0, 0, 0);
+          }
+      };
+      limb(0, std::integral_constant<int, 0>{});
+      limb(1, std::integral_constant<int, 1>{});
+      limb(2, std::integral_constant<int, 0>{});
     }
     if constexpr (BOUT != 0) {
       const int mb = g.bout.mbits;
@@ -555,14 +636,27 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
     }                                                                                                           \
     k_lqer_gemm<DT, LR, BO><<<grid, 512, GEMM_LDS, st>>>(g);                                                    \
   } while (0)
+#define LQER_GEMM_LAUNCH_STAGED(BO)                                                                             \
+  do {                                                                                                          \
+    static bool attr_done = false;                                                                              \
+    if (!attr_done) {                                                                                           \
+      (void)hipFuncSetAttribute((const void*)k_lqer_gemm<DT, true, BO, true>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);                          \
+      attr_done = true;                                                                                         \
+    }                                                                                                           \
+    k_lqer_gemm<DT, true, BO, true><<<grid, 512, GEMM_LDS, st>>>(g);                                            \
+  } while (0)
+  const bool staged = lowrank && g.rp * g.b_limbs > 32;  // more than two 16-deep slices of side product
   if (!lowrank)
     LQER_GEMM_LAUNCH(false, 0);
-  else if (bout == 1)
-    LQER_GEMM_LAUNCH(true, 1);
-  else if (bout == 2)
-    LQER_GEMM_LAUNCH(true, 2);
-  else
-    LQER_GEMM_LAUNCH(true, 0);
+  else if (bout == 1) {
+    if (staged) LQER_GEMM_LAUNCH_STAGED(1); else LQER_GEMM_LAUNCH(true, 1);
+  } else if (bout == 2) {
+    if (staged) LQER_GEMM_LAUNCH_STAGED(2); else LQER_GEMM_LAUNCH(true, 2);
+  } else {
+    if (staged) LQER_GEMM_LAUNCH_STAGED(0); else LQER_GEMM_LAUNCH(true, 0);
+  }
+#undef LQER_GEMM_LAUNCH_STAGED
 #undef LQER_GEMM_LAUNCH
   return check_launch("lqer_gemm");
 }

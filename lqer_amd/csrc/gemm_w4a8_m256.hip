@@ -104,6 +104,32 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
   const uint32_t fw_addr = lds0 + OFF_R + (nw >> 4) * LQER_PANEL_BYTES + (nw & 15) * 32 + lh * 16;
   const uint32_t fe_addr = lds0 + OFF_R + (nw >> 4) * LQER_PANEL_BYTES + (nw & 15) * 4;  // + 512
 
+  // side path, first half (gemm_w4a8.hip): the loads of pass 0 - the tile's rows of xAq, to be staged through the free
+  // ring slot, and this wave's B^T fragments - are issued before the ring prefetch
+  constexpr int STG = BM * 8 / 512;  // staged 16-byte chunks per thread and pass
+  u32x4 stg[STG];
+  bf16x8 sb[3][4];
+  const uint32_t stage = lds0 + OFF_A + (NSLOT - 1) * A_SLOT;
+  const bf16_t* const bt_row = LOWRANK ? g.bt + (int64_t)(n0 + wn * 32 + l31) * g.rp + 8 * lh : nullptr;
+  auto side_fetch = [&](int p0) {
+    const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;  // a multiple of 16
+    const int cpr = cols >> 3;                          // 16-byte chunks per row
+#pragma unroll
+    for (int j = 0; j < STG; ++j) {
+      const int c = tid + 512 * j;
+      if (c < BM * cpr) {
+        const int row = c / cpr, ch = c - row * cpr;
+        stg[j] = *(const u32x4*)(g.xaq + (int64_t)(m0 + row) * g.xaq_ld + p0 + 8 * ch);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (l < g.b_limbs && ks * 16 < cols) sb[l][ks] = *(const bf16x8*)(bt_row + (int64_t)l * g.Np * g.rp + p0 + ks * 16);
+  };
+  if constexpr (LOWRANK) side_fetch(0);
+
   // prologue loads: steps 0 .. DEPTH-1 (both halves)
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
@@ -115,17 +141,50 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
   // ---- low-rank prologue: acc = Q_Bout(xAq @ B) + bias, one 32 x 32 accumulator at a time -------------------------
   f32x16 acc[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    f32x16 t;
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = 0.f;
-    if constexpr (LOWRANK) {
-      for (int l = 0; l < g.b_limbs; ++l)
-        for (int ks = 0; ks < g.rp / 16; ++ks) {
-          const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
-          const bf16x8 xv = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
-          t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xv, t, 0, 0, 0);
+    for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+  if constexpr (LOWRANK) {
+    // xAq @ B for the whole tile first (8 independent accumulators per fragment), 64 rank entries per pass
+    for (int p0 = 0; p0 < g.rp; p0 += 64) {
+      const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;
+      const int cpr = cols >> 3;
+      if (p0) {
+        asm volatile("s_barrier" ::: "memory");  // the previous pass's fragment reads are done
+        side_fetch(p0);
+      }
+#pragma unroll
+      for (int j = 0; j < STG; ++j) {
+        const int c = tid + 512 * j;
+        if (c < BM * cpr) {
+          const int row = c / cpr, ch = c - row * cpr;
+          asm volatile("ds_write_b128 %0, %1" ::"v"(stage + swz(row, ch)), "v"(stg[j]) : "memory");
         }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (l < g.b_limbs && ks * 16 < cols) {
+            const uint32_t fa = stage + swz(l31, 2 * ks + lh);  // m tile i: + i * 4096 (row + 32 keeps the swizzle)
+            bf16x8 xv[8];
+            asm volatile(
+                "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\t"
+                "ds_read_b128 %3, %8 offset:12288\n\tds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %8 offset:20480\n\t"
+                "ds_read_b128 %6, %8 offset:24576\n\tds_read_b128 %7, %8 offset:28672\n\ts_waitcnt lgkmcnt(0)"
+                : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3]), "=&v"(xv[4]), "=&v"(xv[5]), "=&v"(xv[6]), "=&v"(xv[7])
+                : "v"(fa)
+                : "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[l][ks], xv[i], acc[i], 0, 0, 0);
+          }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x16 t = acc[i];
+    if constexpr (LOWRANK) {
       if constexpr (BOUT != 0) {
         const int mb = g.bout.mbits;
 #pragma unroll

@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--r", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--bout", type=int, default=1, help="1: B_out MXINT8/16, 0: passthrough")
+    ap.add_argument("--bout", type=int, default=1, help="1: B_out MXINT8/16, 0: passthrough, 2: MXINT8, one block per row (pre-pass)")
+    ap.add_argument("--blimbs", type=int, default=1, help="bf16 limbs of B (1: MXINT8 values, 2: fp16 values)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, K, N, r = a.M, a.K, a.N, a.r
@@ -47,14 +48,17 @@ def main():
     y = torch.empty(M, N, dtype=torch.float16, device=dev)
     f8 = _lib.QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
     f4 = _lib.QFmt(_lib.Q_MXINT, 4, 16, 8, 127)
-    fb = f8 if a.bout else _lib.QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+    fb = {0: _lib.QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127), 1: f8, 2: _lib.QFmt(_lib.Q_MXINT, 8, -1, 8, 127)}[a.bout]
     desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, fb)
     libs = [(p, load(p)) for p in a.libs]
     st = torch.cuda.current_stream().cuda_stream
 
+    nscr = libs[0][1].lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+    scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
+
     def run(L):
         rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr() if r else None,
-                                bt.data_ptr() if r else None, 1, None, y.data_ptr(), _lib.F16, N, None, 0, st)
+                                bt.data_ptr() if r else None, a.blimbs, None, y.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
 
     times = {p: [] for p, _ in libs}
