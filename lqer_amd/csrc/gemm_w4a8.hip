@@ -646,7 +646,10 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
     }                                                                                                           \
     k_lqer_gemm<DT, true, BO, true><<<grid, 512, GEMM_LDS, st>>>(g);                                            \
   } while (0)
-  const bool staged = lowrank && g.rp * g.b_limbs > 32;  // more than two 16-deep slices of side product
+#ifndef LQER_STAGE_MIN
+#define LQER_STAGE_MIN 32
+#endif
+  const bool staged = lowrank && g.rp * g.b_limbs > LQER_STAGE_MIN;  // more than two 16-deep slices of side product
   if (!lowrank)
     LQER_GEMM_LAUNCH(false, 0);
   else if (bout == 1) {
