@@ -236,6 +236,22 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // barriers of the staged route cost more than they save there; launch_gemm picks the instantiation)
   constexpr bool side_staged = LOWRANK && STAGED;
   if constexpr (side_staged) side_fetch(0);
+  // direct route (at most two 16-deep slices: rank <= 32 with one limb, or rank 16 with two): both slices' operands
+  // are requested here, ahead of the ring prefetch, instead of one slice at a time behind it
+  constexpr bool side_direct = LOWRANK && !STAGED;
+  bf16x8 db[side_direct ? 2 : 1], dx[side_direct ? 2 : 1][side_direct ? 4 : 1];
+  const bool two_limbs = g.b_limbs > 1;  // (then rank 16: slice s = limb s; else slice s = rank entries 16 s ..)
+  if constexpr (side_direct) {
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int l = two_limbs ? sl : 0, ks = two_limbs ? 0 : sl;
+      if (l < g.b_limbs && ks * 16 < g.rp) {
+        db[sl] = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dx[sl][i] = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
+      }
+    }
+  }
 
   // prologue loads: steps 0 .. DEPTH-1
 #pragma unroll
@@ -249,15 +265,13 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 
   // ---- low-rank prologue: acc = Q_Bout(xAq @ B) + bias ----------------------------------------
   if constexpr (LOWRANK) {
-    if constexpr (!side_staged) {
-      for (int l = 0; l < g.b_limbs; ++l) {
-        for (int ks = 0; ks < g.rp / 16; ++ks) {
-          const bf16x8 bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
+    if constexpr (side_direct) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const bf16x8 xa = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa, acc[i], 0, 0, 0);
-          }
+      for (int sl = 0; sl < 2; ++sl) {
+        const int l = two_limbs ? sl : 0, ks = two_limbs ? 0 : sl;
+        if (l < g.b_limbs && ks * 16 < g.rp) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(db[sl], dx[sl][i], acc[i], 0, 0, 0);
         }
       }
     }
