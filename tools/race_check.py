@@ -4,12 +4,15 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lqer_amd
-from bench import make_case, MXINT_Q
-K = N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-M, r = 2048, 32
-x, W, A, B = make_case(M, K, N, r, seed=1)
+from bench import make_case, A16_Q, INT_Q, MXINT_Q
+# usage: race_check.py [K [N [M [rank [mxint|int|a16]]]]]   (rank > 32 or the int / a16 configurations: staged side-path prologue)
+arg = lambda i, d: type(d)(sys.argv[i]) if len(sys.argv) > i else d
+K = arg(1, 4096)
+N, M, r, cfg = arg(2, K), arg(3, 2048), arg(4, 32), arg(5, "mxint")
+qc = {"mxint": MXINT_Q, "int": INT_Q, "a16": A16_Q}[cfg]
+x, W, A, B = make_case(M, K, N, r, seed=1, quantize_ab=cfg == "mxint")
 x = x.half().cuda()
-mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
 mod.load_state_dict({"weight": W, "A": A, "B": B})
 mod = mod.cuda().half()
 y0 = mod(x).clone()
