@@ -151,9 +151,11 @@ int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fm
 
 /* y[M,N] (row stride ldy, same dtype as x) from x[M,K] (row stride ldx).  a_limbs / b_limbs =
  * the limb counts reported by lqer_pack_lowrank.  workspace >= lqer_linear_sizes(...).workspace
- * for m_max >= M.  Four stream-ordered launches: activation quantize, rank-r side GEMM (split-K
- * partials, then a fixed-order reduce with the A_out re-quantization), fused W4 x A8 GEMM with the
- * B side GEMM, B_out re-quantization, bias and add in its prologue.                            */
+ * for m_max >= M.  Two to four stream-ordered launches, no host synchronisation: the activation quantizer (fused
+ * with the split-K partials of the rank-r side GEMM when x blocks are 16 and the padded rank <= 64; nothing at all for
+ * a dense fp16 tensor on the LQER_Q_PASSTHROUGH_F16 route), a fixed-order reduce of the partials with the A_out
+ * re-quantization (taken over by the GEMM at decode sizes, lqer_decode_partials), a pre-pass for B_out blocks other
+ * than 16 columns, and the fused W4 GEMM with the B side GEMM, B_out re-quantization, bias and add in its prologue. */
 int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype, int64_t M,
                         int64_t ldx, const void* w_packed, const void* a_t, const void* b_t,
                         int a_limbs, int b_limbs, const float* bias_q, void* y, int64_t ldy,
