@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(16))) float f16v;
 typedef __attribute__((ext_vector_type(16))) int i16v;
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(int iters, unsigned long long* cyc, float* sink) {
+__global__ __launch_bounds__(512) void k(int iters, unsigned long long* cyc, float* sink) {
   s8 a = {1, 2, 3, 4, 5, 6, 7, (short)threadIdx.x}, b = {1, 1, 2, 2, 3, 3, 4, 4};
   f16v f[4];
   i16v q[4];
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned long long* cyc, flo
   float s = 0;
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 16; ++j) s += f[i][j] + (float)q[i][j];
-  sink[blockIdx.x * 256 + threadIdx.x] = s;
+  sink[blockIdx.x * 512 + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
@@ -40,20 +40,21 @@ int main() {
   unsigned long long* c;
   float* sink;
   hipMalloc(&c, 8);
-  hipMalloc(&sink, 256 * 256 * 4);
+  hipMalloc(&sink, 256 * 512 * 4);
   const int iters = 20000;
   const char* names[4] = {"v_mfma_f32_32x32x16_bf16", "v_mfma_i32_32x32x16_i8 ", "v_mfma_i32_32x32x32_i8 ", "v_mfma_f32_32x32x16_f16 "};
-  for (int kind = 0; kind < 4; ++kind) {
-    for (int rep = 0; rep < 2; ++rep) {
-      if (kind == 0) k<0><<<256, 256>>>(iters, c, sink);
-      if (kind == 1) k<1><<<256, 256>>>(iters, c, sink);
-      if (kind == 2) k<2><<<256, 256>>>(iters, c, sink);
-      if (kind == 3) k<3><<<256, 256>>>(iters, c, sink);
-      hipDeviceSynchronize();
+  for (int threads = 256; threads <= 512; threads += 256)
+    for (int kind = 0; kind < 4; ++kind) {
+      for (int rep = 0; rep < 2; ++rep) {
+        if (kind == 0) k<0><<<256, threads>>>(iters, c, sink);
+        if (kind == 1) k<1><<<256, threads>>>(iters, c, sink);
+        if (kind == 2) k<2><<<256, threads>>>(iters, c, sink);
+        if (kind == 3) k<3><<<256, threads>>>(iters, c, sink);
+        hipDeviceSynchronize();
+      }
+      unsigned long long h;
+      hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
+      printf("%s  %5.1f cycles per instruction and wave, %d wave(s) per SIMD\n", names[kind], (double)h / (4.0 * iters), threads / 256);
     }
-    unsigned long long h;
-    hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
-    printf("%s  %.1f shader-clock ticks per instruction (one wave per SIMD; s_memtime units)\n", names[kind], (double)h / (4.0 * iters));
-  }
   return 0;
 }
