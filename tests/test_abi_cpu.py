@@ -71,6 +71,37 @@ def test_sizes_and_argument_errors_without_gpu(lib):
     assert lib.lqer_linear_forward(C.byref(d), None, 1, 8, 4096, None, None, None, 1, 1, None, None, 4096, None, 0, None) == -4
 
 
+def test_passthrough_descriptors_host_logic():
+    """Sizes, limb counts and the decode-route predicate are host arithmetic: checked without a GPU.  Pass-through
+    activations travel as 1 / 2 / 3 bf16 limbs (width 8 / 11 / 24) with the packed images repeated per limb; the fp16
+    route (kind 2) keeps one copy; a pass-through A_out doubles or triples b_t."""
+    from lqer_amd import _lib
+
+    L = _lib.lib()
+    mx, w4 = _lib.QFmt(_lib.Q_MXINT, 8, 16, 8, 127), _lib.QFmt(_lib.Q_MXINT, 4, 128, 8, 127)
+    none = _lib.QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+    one, sz = _lib.LinearSizes(), _lib.LinearSizes()
+    assert L.lqer_linear_sizes(C.byref(_lib.LinearDesc(1000, 700, 48, 0, mx, w4, none, mx, mx)), 100, C.byref(one)) == 0
+    a, b = C.c_int(0), C.c_int(0)
+    for kind, width, xa_width, want in ((0, 8, 16, (1, 2)), (0, 11, 16, (2, 2)), (0, 24, 24, (3, 3)), (2, 11, 16, (1, 2))):
+        d = _lib.LinearDesc(1000, 700, 48, 0, _lib.QFmt(kind, width, 0, 8, 127), w4, none, _lib.QFmt(0, xa_width, 0, 8, 127), none)
+        assert L.lqer_desc_limbs(C.byref(d), C.byref(a), C.byref(b)) == 0 and (a.value, b.value) == want
+        assert L.lqer_linear_sizes(C.byref(d), 100, C.byref(sz)) == 0
+        assert (sz.w_packed, sz.a_t, sz.b_t) == (want[0] * one.w_packed, want[0] * one.a_t, want[1] * one.b_t)
+        assert sz.workspace > one.workspace or want == (1, 2)
+    d = _lib.LinearDesc(1000, 700, 48, 0, _lib.QFmt(0, 0, 0, 8, 127), w4, none, mx, mx)
+    assert L.lqer_linear_sizes(C.byref(d), 100, C.byref(sz)) != 0 and b"significand" in L.lqer_last_error()
+    # decode route: M <= 64, blocks of 16 for x and A_out, padded rank <= 64, B_out pass-through or blocks of 16
+    ok = _lib.LinearDesc(4096, 4096, 32, 0, mx, w4, none, mx, mx)
+    assert [L.lqer_decode_partials(C.byref(ok), m) for m in (0, 1, 64, 65)] == [0, 1, 1, 0]
+    row = _lib.QFmt(_lib.Q_MXINT, 8, -1, 8, 127)
+    for bad in (_lib.LinearDesc(4096, 4096, 80, 0, mx, w4, none, mx, mx), _lib.LinearDesc(4096, 4096, 32, 0, row, w4, none, mx, mx),
+                _lib.LinearDesc(4096, 4096, 32, 0, mx, w4, none, row, mx), _lib.LinearDesc(4096, 4096, 32, 0, mx, w4, none, mx, row),
+                _lib.LinearDesc(4096, 4096, 0, 0, mx, w4, none, mx, mx)):
+        assert L.lqer_decode_partials(C.byref(bad), 8) == 0
+    assert L.lqer_decode_partials(C.byref(_lib.LinearDesc(4096, 4096, 32, 0, mx, w4, none, mx, none)), 8) == 1
+
+
 def test_make_qfmt_schema():
     from lqer_amd import _lib, ops
 
