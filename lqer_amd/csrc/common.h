@@ -285,7 +285,7 @@ bool xa_fused_partials_ok(const QP& qx, const QP& qa, int64_t r);  // formats th
 void xa_fused_plan(int64_t M, int64_t K, int64_t r, int* nchunk, int64_t* cstride);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
-bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: at least two rounds of 256 x 256 tiles
+bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) rounds with 256 x 256 tiles
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);

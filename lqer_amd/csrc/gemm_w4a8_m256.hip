@@ -432,10 +432,19 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
 
 }  // namespace m256
 
-// at least two rounds of 256 x 256 tiles on the 256 CUs, and rows to fill them
+// A 256 x 256 tile costs about 1.9 tiles of 128 x 256 (one weight expand per 8 MFMAs instead of 4, half the per-tile
+// fixed work), but both kernels run in whole rounds of one tile per CU: take the large tiles only when they still need
+// less time after rounding up - e.g. 16384 x 5120: 5 rounds against 10, 4096 x 4096: 1 against 2, but 2048 x 11008:
+// 2 (344 tiles) against 3 (688) keeps the small tiles (measured: 157 vs 178 us).
+#ifndef LQER_M256_MIN_M
+#define LQER_M256_MIN_M 512
+#endif
 bool m256_eligible(const GemmArgs& g) {
-  const int64_t tiles = (int64_t)((g.M + m256::BM - 1) / m256::BM) * (g.Np / m256::BN);
-  return g.M >= 2048 && tiles >= 512;
+  constexpr int64_t CUS = 256;
+  const int64_t t256 = (int64_t)((g.M + m256::BM - 1) / m256::BM) * (g.Np / m256::BN);
+  const int64_t t128 = (int64_t)((g.M + 127) / 128) * (g.Np / m256::BN);
+  const int64_t r256 = (t256 + CUS - 1) / CUS, r128 = (t128 + CUS - 1) / CUS;
+  return g.M >= LQER_M256_MIN_M && r256 * 19 < r128 * 10;
 }
 
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st) {

@@ -421,9 +421,10 @@ def test_large_m_tile_kernel_vs_oracle(ops, cfg, K, N):
                                 B.half().float(), qc)
     err = (y - ref).norm() / ref.norm()
     assert err <= 1e-3, float(err)
-    # rows are independent: the 128-row kernel (M = 2000 < 2048) must give the same bits for the same rows
-    y2 = mod(xin[:2000].to(DEV)).float().cpu()
-    assert torch.equal(y2, y[:2000])
+    # rows are independent: the 128-row kernel (M = 300: one round of either tile size, the small tiles are chosen) must
+    # give the same bits for the same rows
+    y2 = mod(xin[:300].to(DEV)).float().cpu()
+    assert torch.equal(y2, y[:300])
 
 
 @pytest.mark.parametrize("dtype,tol,native", [(torch.float16, 1e-3, True), (torch.float16, 1e-3, False), (torch.bfloat16, 5e-3, True),
