@@ -54,7 +54,11 @@ size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp) {
 // them (the k order inside a window is a free permutation as long as both operands use the same one).  Every A^T
 // fragment (fetched from L2) feeds RG MFMAs: with one row group per wave the A^T stream, rp/32 times the activation
 // stream, is the bound.
-template <int NT, int RG, bool XF16 = false>  // XF16: fp16 activation image and fp16 A^T (LQER_Q_PASSTHROUGH_F16)
+// XF16: fp16 activation image and fp16 A^T (LQER_Q_PASSTHROUGH_F16).  AFPF: the A^T fragments of the next window are
+// requested one window ahead as well (a_limbs * NT <= 4 fragment sets = 64 registers; used for rank <= 64): without it
+// every 64-k window waits one L2 latency for them, which - not the activation stream - bounds the kernel at large M
+// (16384 x 13824, rank 64, two limbs: 358 -> 326 us for quantizer + side GEMM; no gain at rank 128, where it is off).
+template <int NT, int RG, bool XF16 = false, bool AFPF = false>
 __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t M, int64_t Kp,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
                                                     float* __restrict__ part) {
@@ -86,6 +90,28 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
   for (int u = 0; u < RG; ++u)
 #pragma unroll
     for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k_begin + 8 * i);
+  constexpr int PAIRS = AFPF ? 4 : 1;  // (limb, tile) fragment sets held one window ahead
+  constexpr int LMAX = AFPF ? 4 / NT : 1;
+  bf16x8 afn[PAIRS][4];
+  auto load_af = [&](int64_t k0) {
+    if constexpr (AFPF) {
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int n = t * 32 + r;
+          if (l < a_limbs && n < rp) {
+            const bf16_t* arow = a_t + ((int64_t)l * rp + n) * Kp + k0 + 32 * h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) afn[l * NT + t][i] = *(const bf16x8*)(arow + 8 * i);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) afn[l * NT + t][i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+          }
+        }
+    }
+  };
+  load_af(k_begin);
   for (int64_t k0 = k_begin; k0 < k_end; k0 += 64) {
     bf16x8 xf[RG][4];
 #pragma unroll
@@ -97,6 +123,25 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
       for (int u = 0; u < RG; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k0 + 64 + 8 * i);
+    }
+    if constexpr (AFPF) {
+      bf16x8 afc[PAIRS][4];
+#pragma unroll
+      for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) afc[p][i] = afn[p][i];
+      if (k0 + 64 < k_end) load_af(k0 + 64);
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (l < a_limbs) {
+#pragma unroll
+            for (int u = 0; u < RG; ++u)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[u][t] = mfma_32x32x16<XF16>(xf[u][i], afc[l * NT + t][i], acc[u][t]);
+          }
+      continue;
     }
     for (int l = 0; l < a_limbs; ++l) {
 #pragma unroll
@@ -493,12 +538,17 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
   const int rgw = nt <= 4 ? 2 : 1;
   const int wave_rows = (plan.row_groups + rgw - 1) / rgw;
   const unsigned grid = (unsigned)((wave_rows * plan.nchunk + 3) / 4);
-#define XA_CASE(NT, RG)                                                                           \
-  case NT:                                                                                        \
-    if (x_f16)                                                                                    \
-      k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);  \
-    else                                                                                          \
-      k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);     \
+#define XA_CASE(NT, RG)                                                                                      \
+  case NT:                                                                                                   \
+    if (NT <= 2 && a_limbs * NT <= 4 && plan.kc > 64) { /* A^T fragments one window ahead */                 \
+      if (x_f16)                                                                                             \
+        k_xa_partial<NT, RG, true, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);  \
+      else                                                                                                   \
+        k_xa_partial<NT, RG, false, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch); \
+    } else if (x_f16)                                                                                        \
+      k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);          \
+    else                                                                                                     \
+      k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);                \
     break;
   switch (nt) {
     XA_CASE(1, 2) XA_CASE(2, 2) XA_CASE(3, 2) XA_CASE(4, 2) XA_CASE(5, 1) XA_CASE(6, 1) XA_CASE(7, 1) XA_CASE(8, 1)
