@@ -56,16 +56,18 @@ def _register() -> None:
 def enable_quantized_attention(model: nn.Module, q_config: dict) -> nn.Module:
     """Route every decoder layer's attention through matmul_flexible.  q_config["matmul"] applies to both products of
     every layer unless `model_layer_<i>` / `model_layer` carry `self_attn: {matmul_0, matmul_1}` overrides
-    (llama_decoder.py:423-482).  Model families without the attention-interface hook raise."""
-    from .models import _decoder_layers
+    (llama_decoder.py:423-482); OPT models read q_config["bmm"] and `bmm_0` / `bmm_1` instead, as the reference's OPT
+    decoder does (opt_decoder.py:125,190,329-339).  Model families without the attention-interface hook raise."""
+    from .models import _OPT, _decoder_layers
 
     _register()
-    layers, _ = _decoder_layers(model)
-    base = q_config["matmul"]
+    layers, table = _decoder_layers(model)
+    op = "bmm" if table is _OPT else "matmul"
+    base = q_config[op]
     for i, layer in enumerate(layers):
         attn = layer.self_attn
         cfgs = []
-        for name in ("matmul_0", "matmul_1"):
+        for name in (f"{op}_0", f"{op}_1"):
             cfg = base
             for key in (f"model_layer_{i}", "model_layer"):
                 entry = q_config.get(key)

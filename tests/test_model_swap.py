@@ -293,9 +293,11 @@ def test_shared_activation_groups_int_config_gpu():
 
 
 @pytest.mark.gpu
-def test_quantized_attention_end_to_end_gpu():
+@pytest.mark.parametrize("family", ["llama", "opt"])
+def test_quantized_attention_end_to_end_gpu(family):
     """enable_quantized_attention: both attention products of every layer go through matmul_flexible (reference
-    llama_decoder.py:259-297).  Logits against a CPU twin whose projections AND attention products run the oracle."""
+    llama_decoder.py:259-297; opt_decoder.py:125,190 with the "bmm" configuration).  Logits against a CPU twin whose
+    projections AND attention products run the oracle."""
     import copy
     import json
     import os
@@ -309,18 +311,19 @@ def test_quantized_attention_end_to_end_gpu():
     from oracle import lqer_oracle as O
 
     mm_cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matmul_config.json")))
-    qc = {"linear": MXINT_Q, "matmul": mm_cfg}
-    model = quantize_model(_tiny_llama(), qc, {"linear": {"rank": 16}})
+    lin_q = MXINT_Q if family == "llama" else OPT_Q
+    qc = {"linear": lin_q, ("matmul" if family == "llama" else "bmm"): mm_cfg}
+    model = quantize_model(_tiny_llama() if family == "llama" else _tiny_opt(), qc, {"linear": {"rank": 16}})
     load_low_rank_dict(model, _ab_dict(model, 16))
     twin = copy.deepcopy(model)
     for name, m in list(twin.named_modules()):
         if isinstance(m, LinearFlexibleLqer):
             parent = twin.get_submodule(name.rsplit(".", 1)[0])
-            setattr(parent, name.rsplit(".", 1)[1], _OracleLinear(m, MXINT_Q))
+            setattr(parent, name.rsplit(".", 1)[1], _OracleLinear(m, lin_q))
 
     def oracle_attention(module, query, key, value, attention_mask, scaling, dropout=0.0, **kwargs):
-        k = A._repeat_kv(key, module.num_key_value_groups)
-        v = A._repeat_kv(value, module.num_key_value_groups)
+        k = A._repeat_kv(key, getattr(module, "num_key_value_groups", 1))
+        v = A._repeat_kv(value, getattr(module, "num_key_value_groups", 1))
         b, h, s, d = query.shape
         w = O.matmul_flexible(query.reshape(b * h, s, d), k.reshape(b * h, -1, d).transpose(1, 2), mm_cfg).reshape(b, h, s, -1) * scaling
         if attention_mask is not None:
@@ -334,7 +337,7 @@ def test_quantized_attention_end_to_end_gpu():
     twin.set_attn_implementation("lqer_oracle_eager")
     A.enable_quantized_attention(model, qc)
     assert model.config._attn_implementation == A.IMPLEMENTATION
-    ids = torch.randint(0, 320, (2, 20), generator=torch.Generator().manual_seed(11))
+    ids = torch.randint(0, 200, (2, 20), generator=torch.Generator().manual_seed(11))
     with torch.no_grad():
         ref = twin(input_ids=ids).logits
         plain = copy.deepcopy(twin)
