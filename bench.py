@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the LQER quantized-Linear hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c4a16|d1|d16|d1a16] [--no-cpu-baseline]
+                    [--graph G] [--prewarm-ms T]
 
 A step = one pass of the hot path (x fp16 in -> activation quantize -> rank-r side GEMM ->
 fused W4A8 GEMM -> y fp16 out) over one batch of synthetic tokens, inputs resident in HBM.
@@ -13,6 +14,10 @@ collective - and the value is the whole-job aggregate: weak sca
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra
 objects: "roofline" (dominant kernel: algorithmic FLOPs / its HIP-event time, against the dense
 bf16 MFMA peak) and "cpu_baseline" (the CPU oracle timed on this box's host cores).
+
+Timing: setup (packing, plans), an untimed device clock ramp of --prewarm-ms (300 ms: after idling the GPU needs
+tens of milliseconds of load to reach the clocks it then holds, and the default C2 run is only ~5 ms long), the W
+untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, max over ranks.
 """
 from __future__ import annotations
 
