@@ -42,19 +42,27 @@ int main() {
   hipMalloc(&c, 8);
   hipMalloc(&sink, 256 * 512 * 4);
   const int iters = 20000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
   const char* names[4] = {"v_mfma_f32_32x32x16_bf16", "v_mfma_i32_32x32x16_i8 ", "v_mfma_i32_32x32x32_i8 ", "v_mfma_f32_32x32x16_f16 "};
   for (int threads = 256; threads <= 512; threads += 256)
     for (int kind = 0; kind < 4; ++kind) {
+      float ms = 0;
       for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
         if (kind == 0) k<0><<<256, threads>>>(iters, c, sink);
         if (kind == 1) k<1><<<256, threads>>>(iters, c, sink);
         if (kind == 2) k<2><<<256, threads>>>(iters, c, sink);
         if (kind == 3) k<3><<<256, threads>>>(iters, c, sink);
-        hipDeviceSynchronize();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
       }
       unsigned long long h;
       hipMemcpy(&h, c, 8, hipMemcpyDeviceToHost);
-      printf("%s  %5.1f cycles per instruction and wave, %d wave(s) per SIMD\n", names[kind], (double)h / (4.0 * iters), threads / 256);
+      const double ops = 2.0 * 32 * 32 * (kind == 2 ? 32 : 16) * 4.0 * iters * (threads / 64) * 256;
+      printf("%s  %5.1f cycles per instruction and wave, %d wave(s) per SIMD; whole kernel %.3f ms = %.0f T(FL)OP/s\n", names[kind],
+             (double)h / (4.0 * iters), threads / 256, ms, ops / (ms * 1e-3) / 1e12);
     }
   return 0;
 }
