@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the LQER quantized-Linear hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|c4a16|d1|d16|d1a16] [--no-cpu-baseline]
-                    [--graph G] [--prewarm-ms T]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|d1|d16|d1a16]
+                    [--sweep auto|weak|strong] [--no-cpu-baseline] [--no-check] [--no-module] [--graph G] [--prewarm-ms T]
 
-A step = one pass of the hot path (x fp16 in -> activation quantize -> rank-r side GEMM ->
-fused W4A8 GEMM -> y fp16 out) over one batch of synthetic tokens, inputs resident in HBM.
-Default workload = BASELINE.json configs[1]: one LqerLinear 4096 -> 4096, rank 32, W4A8 MXINT
-(block 16), M = 2048 tokens.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank runs its own independent Linear(s) - the path shards into independent units with no data-path
-collective - and the value is the whole-job aggregate: weak scaling.
+A step = one pass of the hot path (x fp16 in -> activation quantize -> rank-r side GEMM -> fused W4A8 GEMM -> y fp16
+out) over one batch of synthetic tokens for every Linear unit this rank owns, inputs resident in HBM.  Default
+workload = BASELINE.json configs[1]: one LqerLinear 4096 -> 4096, rank 32, W4A8 MXINT (block 16), M = 2048 tokens.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with two extra
-objects: "roofline" (dominant kernel: algorithmic FLOPs / its HIP-event time, against the dense
-bf16 MFMA peak) and "cpu_baseline" (the CPU oracle timed on this box's host cores).
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): the path shards into independent Linear
+units.  Rank 0 generates the token batch x once per distinct K and BROADCASTS it (RCCL, outside the timed region, timed
+separately as `broadcast_ms`); every rank builds the weights of its own units from a seed; per-rank times and checksums
+are GATHERED after the timed region.  No collective on the data path.
+  * model sweeps (c3 / c4 / c5): the model's decoder layers are split over the ranks by the reference's rule - rank g
+    owns layers [g ceil(L/G), (g+1) ceil(L/G)) (experiments/infer_device_map.py:29-37, lqer_amd.sweep.layer_partition)
+    - total work is fixed: "scaling": "strong".  --sweep weak gives every rank the whole model instead.
+  * single-Linear workloads (c2, d1, d16): every rank runs its own Linear of that shape on the broadcast batch (N
+    independent units - e.g. the same projection of N layers): "scaling": "weak".
 
-Timing: setup (packing, plans), an untimed device clock ramp of --prewarm-ms (300 ms: after idling the GPU needs
-tens of milliseconds of load to reach the clocks it then holds, and the default C2 run is only ~5 ms long), the W
+Prints ONE JSON line on rank 0 (driver contract) with these extra objects: "roofline" (dominant kernel: algorithmic
+FLOPs / its HIP-event time inside the timed region, against the dense MFMA peak of the main loop's operand type),
+"cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample), "module" (the same K steps timed
+through the drop-in nn.Module, `mod(x)` - the boundary the reference's callers use; `value` is the C-ABI figure) and
+"parity_rel_l2" (row slices of the outputs the timed kernels just wrote, against the CPU oracle).
+
+Timing: setup (packing, plans, broadcast), an untimed device clock ramp of --prewarm-ms (300 ms: after idling the GPU
+needs tens of milliseconds of load to reach the clocks it then holds, and the default C2 run is only ~5 ms long), the W
 untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides, max over ranks.
 """
 from __future__ import annotations
@@ -48,32 +57,37 @@ OPT_Q = dict(MXINT_Q, b_quantizer=_bfp(8, [1, 16], False))
 # per-token activation format BASELINE.json's "W4A8 L2QER-INT" pins: block_fp(8, [1,-1])
 INT_Q = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=_bfp(8, [1, -1], True),
              w_quantizer=_bfp(4, [1, 128], False), b_quantizer=dict(name="passthrough"))
+# the same with one weight block per row (llama-7b-int.toml:87, block_size [1, -1])
+INTROW_Q = dict(INT_Q, w_quantizer=_bfp(4, [1, -1], False))
 
 # the INT templates as shipped (llama-7b-int.toml q_config.linear): pass-through fp16 activations ("W4A16"), A_out and
 # B_out falling back to the same pass-through (linear.py:115-124), A/B unquantized
 A16_Q = dict(INT_Q, x_quantizer=dict(name="passthrough", width=16, frac_width=12))
-UNQUANTIZED_AB = (INT_Q, A16_Q)
+UNQUANTIZED_AB = (INT_Q, INTROW_Q, A16_Q)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 INT8_MFMA_PEAK_TOPS = 5000.0    # 2x bf16 per clock (same guide, "Matrix cores", I8 row)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md, HBM3E
 
+LLAMA13B = [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)]
 WORKLOADS = {
-    # name: (description, M, rank, bias, q_config, [(K, N, count per layer)], layers)
+    # name: (description, M, rank, bias, q_config, [(K, N, count per layer)], decoder layers of the model)
     "c2": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=2048 (BASELINE configs[1])", 2048, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
     "c3": ("Llama-7B 7 projections x 32 layers rank32 W4A8-MXINT16 M=2048 (BASELINE configs[2])", 2048, 32, False, MXINT_Q,
            [(4096, 4096, 4), (4096, 11008, 2), (11008, 4096, 1)], 32),
-    "c4": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A8(per-token) M=16384 (BASELINE configs[3], per-GPU share)", 16384, 64, False,
-           INT_Q, [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)], 5),
+    "c4": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A8(per-token) M=16384 (BASELINE configs[3])", 16384, 64, False,
+           INT_Q, LLAMA13B, 40),
+    "c4row": ("Llama-13B 7 projections x 40 layers rank64 W4(one block per row, llama-7b-int.toml:87)A8(per-token) M=16384", 16384, 64,
+              False, INTROW_Q, LLAMA13B, 40),
     "c5": ("OPT-6.7B 6 projections x 32 layers rank128 W4A8-MXINT16 M=2048 (BASELINE configs[4])", 2048, 128, True, OPT_Q,
            [(4096, 4096, 4), (4096, 16384, 1), (16384, 4096, 1)], 32),
-    "c4a16": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A16 (the reference's INT template as shipped) M=16384, per-GPU share",
-              16384, 64, False, A16_Q, [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)], 5),
+    "c4a16": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A16 (the reference's INT template as shipped) M=16384",
+              16384, 64, False, A16_Q, LLAMA13B, 40),
     "d1a16": ("LqerLinear 4096x4096 rank32 W4(block128)A16 M=1 (decode)", 1, 32, False, A16_Q, [(4096, 4096, 1)], 1),
     # decode sizes (HBM-bound on the packed weight; roofline quoted in GB/s): the small-M kernel
     "d1": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=1 (decode)", 1, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
     "d16": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=16 (decode)", 16, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md, HBM3E
 
 
 def flops(M, K, N, r):
@@ -81,40 +95,61 @@ def flops(M, K, N, r):
     return 2 * M * K * N + 2 * M * K * r + 2 * M * r * N
 
 
-def make_case(M, K, N, r, seed=0, bias=False, quantize_ab=True):
-    """Synthetic inputs of SURVEY.md §8d: x ~ N(0,1) with three x30 outlier channels, W ~ N(0, 0.02^2),
-    A, B ~ 0.01 N(0,1) snapped to the 8-bit MXINT grid (blocks of 16 along K / rank) like the
-    reference's approximator output (llama-7b.toml:60-73)."""
-    from oracle import lqer_oracle as O  # generator for synthetic A/B only (never on the timed path)
+def _snap_mxint8_dim0(t):
+    """t -> the 8-bit MXINT grid with blocks of 16 along dim 0 (the reference approximator's A / B format,
+    llama-7b.toml:60-73).  On a GPU box this is the library's own HIP quantizer; without a GPU (CPU-only tools and
+    tests) the CPU oracle's.  Setup of synthetic inputs only - any values would do."""
+    if torch.cuda.is_available():
+        from lqer_amd import ops
 
+        fmt = ops.make_qfmt(_bfp(8, [1, 16], True), "x")
+        return ops.quantize_mxint(t.t().contiguous().cuda(), fmt, want=("deq",))["deq"].t().contiguous().cpu()
+    from oracle import lqer_oracle as O
+
+    return O.mxint_quantize(t, width=8, block_size=[16, 1], skip_first_dim=False)
+
+
+def make_x(M, K, seed=0):
+    """Synthetic token batch of SURVEY.md §8d: x ~ N(0,1) with three x30 outlier channels."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(M, K, generator=g)
     for c in (7, 1033, 2900):
         if c < K:
             x[:, c] *= 30.0
+    return x, g
+
+
+def make_weights(g, K, N, r, bias=False, quantize_ab=True):
+    """W ~ N(0, 0.02^2); A, B ~ 0.01 N(0,1), snapped to the 8-bit MXINT grid for the MXINT configurations, left
+    unquantized for the INT ones (llama-7b-int.toml:61-68); optional bias ~ 0.01 N(0,1)."""
     W = 0.02 * torch.randn(N, K, generator=g)
-    if r > 0 and quantize_ab:
-        A = O.mxint_quantize(0.01 * torch.randn(K, r, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
-        B = O.mxint_quantize(0.01 * torch.randn(r, N, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
-    elif r > 0:  # the INT configs keep A, B unquantized (llama-7b-int.toml:61-68)
+    A = B = None
+    if r > 0:
         A = 0.01 * torch.randn(K, r, generator=g)
         B = 0.01 * torch.randn(r, N, generator=g)
-    else:
-        A = B = None
-    if bias:
-        return x, W, A, B, 0.01 * torch.randn(N, generator=g)
-    return x, W, A, B
+        if quantize_ab:
+            A, B = _snap_mxint8_dim0(A), _snap_mxint8_dim0(B)
+    return (W, A, B, 0.01 * torch.randn(N, generator=g)) if bias else (W, A, B)
 
 
-def cpu_baseline(M, K, N, r, q_config, reps=3):
-    """The CPU oracle (a port of the reference's eager-torch emulation, routed through the same
-    pad/unfold/fold blocking ops as the reference) timed on all host cores; steady state, i.e. the
-    one-time weight quantization (reference linear.py:149-153) is done before the clock starts."""
+def make_case(M, K, N, r, seed=0, bias=False, quantize_ab=True):
+    """(x, W, A, B[, bias]) from one seed (tests, tools, smoke)."""
+    x, g = make_x(M, K, seed)
+    return (x,) + make_weights(g, K, N, r, bias, quantize_ab)
+
+
+def cpu_baseline(M, K, N, r, q_config, reps=2):
+    """The CPU oracle (a port of the reference's eager-torch emulation, routed through the same pad/unfold/fold blocking
+    ops as the reference) timed on the host cores; steady state, i.e. the one-time weight quantization (reference
+    linear.py:149-153) is done before the clock starts.  Bounded sample: at most 2048 tokens of the workload's first
+    projection shape (rows are independent, the emulation's cost is linear in M)."""
     from oracle import lqer_oracle as O
 
-    cores = min(os.cpu_count() or 1, int(os.environ.get("LQER_CPU_THREADS", "16")))
+    host = os.cpu_count() or 1
+    cores = min(host, int(os.environ.get("LQER_CPU_THREADS", "16")))  # tools/cpu_scan.py: no gain beyond 16 threads
     torch.set_num_threads(cores)
-    x, W, A, B = make_case(M, K, N, r, seed=0, quantize_ab=not any(q_config is c for c in UNQUANTIZED_AB))
+    Ms = min(M, 2048)
+    x, W, A, B = make_case(Ms, K, N, r, seed=0, quantize_ab=not any(q_config is c for c in UNQUANTIZED_AB))
     x = x.half().float()
     wq = O.get_quantizer(q_config["w_quantizer"])(W)
     O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)  # warm-up
@@ -123,23 +158,34 @@ def cpu_baseline(M, K, N, r, q_config, reps=3):
         t0 = time.perf_counter()
         O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)
         best = min(best, time.perf_counter() - t0)
-    return {"value": round(flops(M, K, N, r) / best / 1e12, 4), "unit": "TFLOP/s-equiv", "cores": cores, "kind": "port",
-            "ms": round(best * 1e3, 2), "tokens_per_s": round(M / best, 1),
-            "sample": f"full workload M={M} K={K} N={N} r={r}, fp32 eager torch-CPU, min of {reps} after warm-up, weights pre-quantized"}
+    return {"value": round(flops(Ms, K, N, r) / best / 1e12, 4), "unit": "TFLOP/s-equiv", "cores": cores, "host_cores": host,
+            "kind": "port", "ms": round(best * 1e3, 2), "tokens_per_s": round(Ms / best, 1),
+            "sample": f"M={Ms} of {M} tokens, K={K} N={N} r={r} (first projection shape), fp32 eager torch-CPU, "
+                      f"min of {reps} after warm-up, weights pre-quantized"}
+
+
+def check_rows(M):
+    """Rows compared with the oracle after the timed region: the first and the last 96 (first / last row tile)."""
+    n = min(96, M)
+    return torch.tensor(sorted(set(range(n)) | set(range(M - n, M))))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; 4 for the M=16384 model sweeps)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10; 1 for the M=16384 sweeps)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--sweep", default="auto", choices=["auto", "weak", "strong"],
+                    help="multi-GPU: strong = the model's layers split over the ranks (default for c3/c4/c5), weak = every "
+                         "rank runs the full unit list (default for single-Linear workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle comparison of the timed outputs")
+    ap.add_argument("--no-module", action="store_true", help="skip the second timed region through the nn.Module")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed device clock ramp before the warm-up steps (0 = none)")
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="capture G consecutive steps in one hipGraph and replay it steps/G times (launch-bound decode sizes; "
                          "G ~ the number of Linears a model pushes a token through)")
-    ap.add_argument("--check", action="store_true", help="also verify y against the CPU oracle (rank 0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,22 +212,48 @@ def main():
     from lqer_amd import _lib, ops, sweep
 
     desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS[args.workload]
-    # this rank's units: one module per distinct projection shape (weights differ per rank by seed);
-    # a model sweep re-runs each shape `count * layers_per_rank` times per step
-    layers_here = layers  # weak scaling: every rank runs a full unit list of its own
+    big = M >= 8192
+    if args.steps is None:
+        args.steps = 4 if big else 50
+    if args.warmup is None:
+        args.warmup = 1 if big else 10
+    strong = (args.sweep == "strong") or (args.sweep == "auto" and layers > 1)
+    if strong and layers == 1 and world > 1:
+        sys.exit("--sweep strong needs a model workload (c3/c4/c5): a single Linear has no layers to split")
+    my_layers = sweep.layer_partition(layers, world)[rank] if strong else range(layers)
+    layers_here = len(my_layers)
+    quantize_ab = not any(qc is c for c in UNQUANTIZED_AB)
+
+    # ---- the token batch: generated on rank 0, broadcast once per distinct K (RCCL over xGMI), outside the timed region
+    xs, broadcast_ms = {}, 0.0
+    for K in sorted({K for K, _, _ in shapes}):
+        if rank == 0:
+            xd = make_x(M, K, seed=0)[0].half().to(dev)
+        else:
+            xd = torch.empty(M, K, dtype=torch.float16, device=dev)
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            sweep.broadcast_activation(xd, src=0)
+            torch.cuda.synchronize()
+            broadcast_ms += (time.perf_counter() - t0) * 1e3
+        xs[K] = xd
+
+    # ---- this rank's units: one module per distinct projection shape, weights from a per-rank seed; a model sweep re-runs
+    # each shape `count x layers owned` times per step (layers differ in values, not in cost)
     mods = []
     for i, (K, N, cnt) in enumerate(shapes):
-        case = make_case(M, K, N, r, seed=sweep.unit_seed(rank, i), bias=has_bias, quantize_ab=not any(qc is c for c in UNQUANTIZED_AB))
-        x, W, A, B = case[:4]
+        g = torch.Generator().manual_seed(sweep.unit_seed(rank, i))
+        wts = make_weights(g, K, N, r, bias=has_bias, quantize_ab=quantize_ab)
         mod = lqer_amd.LinearFlexibleLqer(K, N, bias=has_bias, q_config=qc, l_config={"rank": r})
-        sd = {"weight": W, "A": A, "B": B}
+        sd = {"weight": wts[0], "A": wts[1], "B": wts[2]}
         if has_bias:
-            sd["bias"] = case[4]
+            sd["bias"] = wts[3]
         mod.load_state_dict(sd)
         mod = mod.to(dev).half()
-        xd = x.half().to(dev)
-        y = mod(xd)  # packs the operands (one-time, like the reference's first forward)
-        mods.append((mod, xd, K, N, cnt * layers_here, y))
+        y = mod(xs[K])  # packs the operands (one-time, like the reference's first forward)
+        mods.append((mod, xs[K], K, N, cnt * layers_here, y, wts))
     torch.cuda.synchronize()
 
     L = _lib.lib()
@@ -193,7 +265,7 @@ def main():
     # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
     plans = []
     ws = ops.workspace(dev, max(ops.linear_sizes(mod._desc(), M).workspace for mod, *_ in mods))  # one buffer for all
-    for mod, xd, K, N, reps, y in mods:
+    for mod, xd, K, N, reps, y, _ in mods:
         desc = mod._desc()
         p = mod._packed
         Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
@@ -211,7 +283,7 @@ def main():
         plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=p["a_t"].data_ptr(), a_limbs=p["a_limbs"], xq=xq, xaq=xaq,
                           xscr=xscr, nscr=nscr, w=p["w"].data_ptr(),
                           b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),
-                          gscr=gscr, K=K, N=N, reps=reps))
+                          gscr=gscr, K=K, N=N, reps=reps, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16)))
 
     def step(timed: bool, stream=stream):
         for pl in plans:
@@ -232,14 +304,32 @@ def main():
                     e1.record()
                     gemm_events.append((e0, e1, K, N))
 
+    def step_module():
+        for mod, xd, K, N, reps, _, _ in mods:
+            for _ in range(reps):
+                mod(xd)
+
+    def timed_region(fn, steps):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(steps)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     # Device clock ramp (setup, like the packing above): after idling the GPU needs tens of milliseconds of load to
     # reach the clocks it then holds - a 60-step run (5 ms) would measure the ramp, not the kernels (C2: 850 vs 970
     # TFLOP/s-equiv on the same box).  Untimed; the W warm-up steps and the K timed steps follow unchanged.
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.prewarm_ms * 1e-3:
-        for _ in range(20):
-            step(False)
-        torch.cuda.synchronize()
+    if layers_here > 0:
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < args.prewarm_ms * 1e-3:
+            for _ in range(1 if big else 20):
+                step(False)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
@@ -256,54 +346,64 @@ def main():
                 step(False, torch.cuda.current_stream(dev).cuda_stream)
         graph.replay()
         torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if graph is not None:
-        for _ in range(args.steps // args.graph):
-            graph.replay()
-    else:
-        for _ in range(args.steps):
-            step(True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+
+    def run_abi(steps):
+        if graph is not None:
+            for _ in range(steps // args.graph):
+                graph.replay()
+        else:
+            for _ in range(steps):
+                step(True)
+
+    elapsed_rank = timed_region(run_abi, args.steps)
     if graph is not None:
         for _ in range(min(args.steps, 4 * EV_EVERY)):
             step(True)
         torch.cuda.synchronize()
-    elapsed = sweep.max_over_ranks(elapsed, dev)
-    checksums = sweep.gather_checksums(float(mods[0][5].float().sum().item()), dev)
+    elapsed = sweep.max_over_ranks(elapsed_rank, dev)
 
-    flops_rank = sum(flops(M, K, N, r) * reps for _, _, K, N, reps, _ in mods)
-    tokens_rank = M  # a model sweep pushes the same M tokens through every layer
-    total_flops = flops_rank * world
+    # second timed region: the same K steps through the drop-in module (torch.empty, descriptor cache, ctypes marshalling
+    # included) - the boundary the reference's callers use
+    module = None
+    if not args.no_module:
+        for _ in range(max(1, args.warmup // 2)):
+            step_module()
+        el_mod = sweep.max_over_ranks(timed_region(lambda n: [step_module() for _ in range(n)], args.steps), dev)
+        module = {"ms_per_step": round(el_mod / args.steps * 1e3, 4), "vs_c_abi": round(el_mod / elapsed, 4)}
+
+    # ---- gather (outside the timed regions): per-rank elapsed time, a checksum of the first unit's output
+    ysum = float(mods[0][5].float().sum().item()) if layers_here > 0 else 0.0
+    gathered = sweep.gather_rows([elapsed_rank * 1e3 / args.steps, ysum, float(layers_here)], dev)
+
+    flops_rank = sum(flops(M, K, N, r) * reps for _, _, K, N, reps, _, _ in mods)
+    flops_all = sweep.sum_over_ranks(float(flops_rank), dev)
     ms_per_step = elapsed / args.steps * 1e3
-    value = sweep.aggregate_throughput(flops_rank, args.steps, world, elapsed)
+    value = flops_all * args.steps / elapsed / 1e12
 
-    if args.check and rank == 0:
-        from oracle import lqer_oracle as O
+    # ---- parity of what was just timed: row slices of every unit's output buffer against the CPU oracle (rank 0)
+    parity = None
+    if not args.no_check and rank == 0:
+        from oracle import lqer_oracle as O  # the checker - after the timed regions, never inside them
 
-        mod, xd, K, N, _, y = mods[0]
-        case = make_case(M, K, N, r, seed=sweep.unit_seed(0, 0), bias=has_bias, quantize_ab=not any(qc is c for c in UNQUANTIZED_AB))
-        ref = O.lqer_linear_forward(case[0].half().float(), case[1].half().float(), case[4].half().float() if has_bias else None,
-                                    case[2].half().float(), case[3].half().float(), qc)
-        err = float((y.float().cpu() - ref).norm() / ref.norm())
-        print(f"# parity vs CPU oracle: rel-L2 {err:.3e}", file=sys.stderr)
-        assert err <= 1e-3, err
+        idx = check_rows(M)
+        worst = 0.0
+        for mod, xd, K, N, reps, y, wts in mods:
+            h = lambda t: None if t is None else t.half().float()
+            ref = O.lqer_linear_forward(xd[idx.to(dev)].float().cpu(), h(wts[0]), h(wts[3]) if has_bias else None, h(wts[1]), h(wts[2]), qc)
+            got = y[idx.to(dev)].float().cpu()
+            worst = max(worst, float((got - ref).norm() / ref.norm()))
+        parity = worst
+        print(f"# parity vs CPU oracle ({len(idx)} rows x {len(mods)} shapes): rel-L2 {parity:.3e}", file=sys.stderr)
 
     if rank == 0:
-        # dominant kernel = k_lqer_gemm; algorithmic FLOPs per launch = 2MKN + 2MrN
+        # dominant kernel = the fused GEMM; algorithmic FLOPs per launch = 2MKN + 2MrN
         # an event pair around a kernel also measures the gap between the first event and the kernel's start: the
         # same pair around nothing, recorded right behind a kernel, gives that overhead (median of 32), which is
         # subtracted - the result agrees with the kernel durations of the rocprofv3 trace of the same command
         cal = []
         for _ in range(32):
-            _lib.check(L.lqer_quantize_act_mxint(mods[0][1].data_ptr(), _lib.F16, 32, mods[0][2], mods[0][2],
-                                                 C.byref(ops.make_qfmt(MXINT_Q["x_quantizer"])), ops.workspace(dev, 1 << 20).data_ptr(), stream), "cal")
+            _lib.check(L.lqer_quantize_act_mxint(mods[0][1].data_ptr(), _lib.F16, min(32, M), mods[0][2], mods[0][2],
+                                                 C.byref(ops.make_qfmt(MXINT_Q["x_quantizer"], "x")), ops.workspace(dev, 1 << 20).data_ptr(), stream), "cal")
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
             c1.record()
@@ -316,16 +416,21 @@ def main():
             tot_fl += 2.0 * M * K * N + 2.0 * M * r * N
             n_launch += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes (a profiler
-        # cannot run inside this process); the committed summary is quoted for the workload it was taken on
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_final_gemm_traffic.json")
-        if args.workload == "c2" and os.path.exists(tfile):
+        routes = sorted({pl["route"] for pl in plans})
+        kname = {_lib.ROUTE_SMALLM: "k_lqer_gemm_smallm", _lib.ROUTE_TILE128: "k_lqer_gemm", _lib.ROUTE_TILE256: "k_lqer_gemm_m256"}
+        kernels = "+".join(kname.get(rt, str(rt)) for rt in routes)
+        # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this very
+        # command (tools/pmc_bench.sh; a profiler cannot run inside this process); the committed summary of the
+        # workload is quoted, with its ratio to the algorithmic bytes
+        traffic, traffic_ratio = None, None
+        tfile = os.path.join(ROOT, "profiles", f"r02_traffic_{args.workload}.json")
+        if os.path.exists(tfile):
             with open(tfile) as fh:
-                traffic = json.load(fh)["traffic_bytes_per_launch"]
+                tj = json.load(fh)
+            traffic, traffic_ratio = tj.get("traffic_bytes_per_launch"), tj.get("ratio_to_algorithmic")
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": "k_lqer_gemm",
-                    "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
+                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
+                    "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
                     "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                     "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4)}
         if M <= 64:
@@ -337,8 +442,8 @@ def main():
                 tot_by += Np * Kp * 0.5625 + Np * rp * 2 + M * Kp * 2 + M * rp * 2 + M * N * 2 + (Np * 4 if has_bias else 0)  # (one copy of every image: algorithmic)
             gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_lqer_gemm_smallm",
-                        "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch}
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
+                        "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch}
         out = {
             "metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv",
             "value": round(value, 2),
@@ -348,25 +453,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f16" if mods[0][0]._x_f16 else "bf16",  # the arithmetic type of the main loop's MFMA operands
             "data": "synthetic",
-            "config": {"workload": desc_txt, "tokens_per_step_per_gpu": M, "rank": r,
+            "config": {"workload": desc_txt, "tokens_per_step": M, "rank": r,
                        "formats": "x %s, W MXINT4/%s, A_out,B_out as x, y fp16" % (
                            "MXINT8/%s" % qc["x_quantizer"]["block_size"][-1] if qc["x_quantizer"]["name"] == "block_fp"
                            else ("fp16 pass-through (fp16 MFMA main loop)" if mods[0][0]._x_f16 else "fp16 pass-through (2 bf16 limbs)"),
                            qc["w_quantizer"]["block_size"][-1]),
-                       "sharding": "independent Linear units per rank, no data-path collective"},
-            "tokens_per_s": round(tokens_rank * world * args.steps / elapsed, 1),
+                       "boundary": "C ABI (lqer_quantize_act_xa + lqer_linear_gemm per Linear, pre-built plans); the nn.Module figure is in `module`",
+                       "sharding": ("decoder layers split over the ranks, ceil(L/G) consecutive layers each (infer_device_map.py:29-37)"
+                                    if strong else "every rank runs its own Linear unit(s) of the workload") +
+                                   "; x broadcast from rank 0 and per-rank results gathered outside the timed region, no data-path collective",
+                       "layers_per_rank": [int(row[2]) for row in gathered]},
+            "tokens_per_s": round(M * args.steps / elapsed * (1 if strong else world), 1),
             "launch": ("hipGraph replay, %d steps per graph" % args.graph) if graph is not None else "direct launches",
             "prewarm_ms": args.prewarm_ms,
+            "broadcast_ms": round(broadcast_ms, 3),
             "roofline": roofline,
-            "rank_checksums": [round(c, 3) for c in checksums],
+            "module": module,
+            "parity_rel_l2": None if parity is None else float(f"{parity:.3e}"),
+            "parity_rows": None if parity is None else int(len(check_rows(M))),
+            "rank_ms_per_step": [round(row[0], 4) for row in gathered],
+            "rank_checksums": [round(row[1], 3) for row in gathered],
         }
         if world == 1 and not args.no_cpu_baseline:
             K0, N0, _ = shapes[0]
             out["cpu_baseline"] = cpu_baseline(M, K0, N0, r, qc)
+        if parity is not None:
+            assert parity <= 1e-3, f"parity of the timed outputs vs the CPU oracle: rel-L2 {parity:.3e} > 1e-3"
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -10,8 +10,11 @@
  *
  * Conventions
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *  - kernels are launched on the calling thread's CURRENT HIP device: the caller makes the device that owns the buffers
+ *    current (hipSetDevice) before the call - the Python mirror does (lqer_amd/linear.py, ops.py);
  *  - the caller owns every buffer (incl. workspace); the library never allocates, frees or
- *    retains pointers, keeps no global mutable state, and is re-entrant;
+ *    retains pointers, and is re-entrant (its only process-wide state are std::once_flag-guarded, idempotent kernel
+ *    attribute settings and the thread-local error text);
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  *    stream) and performs no host synchronisation, so calls may be captured in a hipGraph;
  *  - return value 0 = success, <0 = error (LQER_E_*); lqer_last_error() gives the text of the
@@ -30,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 2
+#define LQER_ABI_VERSION 3
 
 /* error codes */
 #define LQER_OK 0
@@ -180,6 +183,16 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
                      const void* w_packed, const void* xaq_bf16, const void* b_t, int b_limbs,
                      const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
                      size_t scratch_bytes, void* stream);
+
+/* Which GEMM kernel lqer_linear_gemm launches for `M` tokens of this descriptor and element type (the choice depends on
+ * nothing else): LQER_ROUTE_SMALLM (M <= 64: one workgroup per 16 output columns streams its packed weight rows),
+ * LQER_ROUTE_TILE128 (128 x 256 tiles), LQER_ROUTE_TILE256 (256 x 256 tiles, M >= 512 when that needs fewer rounds of one
+ * tile per CU).  < 0: the error lqer_linear_gemm would return.  For benchmarks and tests that must know which kernel
+ * they are looking at. */
+#define LQER_ROUTE_SMALLM 0
+#define LQER_ROUTE_TILE128 1
+#define LQER_ROUTE_TILE256 2
+int lqer_gemm_route(const lqer_linear_desc_t* desc, int64_t M, int dtype);
 
 /* Decode sizes (launch-bound: each kernel runs ~3 us).  Returns 1 when, for this descriptor and token count, the
  * re-quantized side product never has to be materialised: M <= 64, x and A_out block_fp in blocks of 16 (width <= 9),

@@ -11,10 +11,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16 = 0, 1, 2
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
+ROUTE_SMALLM, ROUTE_TILE128, ROUTE_TILE256 = 0, 1, 2
 
 
 class QFmt(C.Structure):
@@ -67,6 +68,7 @@ SIGNATURES = {
     "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "lqer_decode_partials": (_i, [_dp, _i64]),
+    "lqer_gemm_route": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
 }
 

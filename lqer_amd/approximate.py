@@ -33,9 +33,9 @@ def _quantize_along_dim0(t: torch.Tensor, cfg: Optional[dict]) -> torch.Tensor:
     bs = [bs] if isinstance(bs, int) else list(bs)
     if len(bs) == 2 and bs[1] == 1 and bs[0] != 1:
         c = dict(cfg, block_size=[1, bs[0]])
-        q = ops.quantize_mxint(t.t().contiguous(), ops.make_qfmt(c), want=("deq",))["deq"]
+        q = ops.quantize_mxint(t.t().contiguous(), ops.make_qfmt(c, "w"), want=("deq",))["deq"]
         return q.t().contiguous()
-    return ops.quantize_mxint(t.contiguous(), ops.make_qfmt(cfg), want=("deq",))["deq"]
+    return ops.quantize_mxint(t.contiguous(), ops.make_qfmt(cfg, "w"), want=("deq",))["deq"]
 
 
 @torch.no_grad()
@@ -45,7 +45,7 @@ def lqer_factors(W: torch.Tensor, w_cfg: dict, rank: int, a_cfg: Optional[dict] 
     scale of L2QER (lqer_act.py); None gives LQER-SVD."""
     ops._need_gpu(W)
     Wf = W.float()
-    Wq = ops.quantize_mxint(Wf.contiguous(), ops.make_qfmt(w_cfg), want=("deq",))["deq"]
+    Wq = ops.quantize_mxint(Wf.contiguous(), ops.make_qfmt(w_cfg, "w"), want=("deq",))["deq"]
     err_t = (Wf - Wq).t()
     if scale is not None:
         s = scale.to(Wf.device, torch.float32)

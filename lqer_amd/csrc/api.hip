@@ -306,6 +306,38 @@ int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, con
                              dtype, ldy, scratch, scratch_bytes, stream);
 }
 
+// fills the kernel arguments that depend on the descriptor and the token count alone (shapes, formats, limb counts)
+static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, GemmArgs& g) {
+  const bool lowrank = d->rank > 0;
+  if (!fmt_ok(&d->w_fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
+  if (lowrank && !fmt_ok(&d->b_out_fmt, "B_out_quantizer", 24)) return LQER_E_UNSUPPORTED;
+  if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (lowrank && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
+    return LQER_E_INVALID;
+  if (!need_f16(d, dtype, "linear_gemm")) return LQER_E_INVALID;
+  const int xl = act_limbs(d), al = lowrank ? xa_limbs(d) : 1;
+  g.M = (int)M;
+  g.N = d->out_features;
+  g.Np = (int)lqer_padded_n(d->out_features);
+  g.x_f16 = x_is_f16(d) ? 1 : 0;
+  g.Kp = (int)lqer_padded_k(d->in_features) * xl;  // limbs side by side along k, weight image repeated to match
+  g.rp = (int)lqer_padded_r(d->rank) * al;
+  g.w_mbits = d->w_fmt.width - 1;
+  if (lowrank) g.bout = make_qp(d->b_out_fmt);
+  return LQER_OK;
+}
+
+int lqer_gemm_route(const lqer_linear_desc_t* d, int64_t M, int dtype) {
+  if (!d || M < 0) {
+    set_error("gemm_route: bad argument");
+    return LQER_E_INVALID;
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  const int rc = gemm_shape_args(d, M, dtype, g);
+  if (rc) return rc;
+  return gemm_route(g, d->rank > 0);
+}
+
 int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
                         int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy,
                         void* scratch, size_t scratch_bytes, void* stream) {
@@ -319,20 +351,18 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
     set_error("linear_gemm: rank %d but no side-path operands (xaq == NULL: only the decode route, see lqer_decode_partials)", d->rank);
     return LQER_E_INVALID;
   }
-  if (!fmt_ok(&d->w_fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
-  if (lowrank && !fmt_ok(&d->b_out_fmt, "B_out_quantizer", 24)) return LQER_E_UNSUPPORTED;
   if (b_limbs < 0 || b_limbs > 3) {
     set_error("linear_gemm: b_limbs %d outside [0,3]", b_limbs);
     return LQER_E_INVALID;
   }
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  const int rc = gemm_shape_args(d, M, dtype, g);
+  if (rc) return rc;
   g.xq = (const bf16_t*)xq;
   g.wp = (const uint8_t*)w_packed;
   g.xaq = (const bf16_t*)xaq;
-  if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (lowrank && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
-    return LQER_E_INVALID;
-  const int xl = act_limbs(d), al = lowrank ? xa_limbs(d) : 1;
+  const int al = lowrank ? xa_limbs(d) : 1;
   if (lowrank && !from_partials && (xaq_ld < lqer_padded_r(d->rank) * al || xaq_ld % 8 != 0 || ((uintptr_t)xaq & 15) != 0)) {
     set_error("linear_gemm: xaq row stride %lld (elements) must be a multiple of 8 and at least the padded rank %lld, "
               "xaq 16-byte aligned", (long long)xaq_ld, (long long)lqer_padded_r(d->rank));
@@ -343,16 +373,7 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
   g.bias = d->has_bias ? bias_q : nullptr;
   g.y = y;
   g.ldy = ldy;
-  g.M = (int)M;
-  g.N = d->out_features;
-  g.Np = (int)lqer_padded_n(d->out_features);
-  if (!need_f16(d, dtype, "linear_gemm")) return LQER_E_INVALID;
-  g.x_f16 = x_is_f16(d) ? 1 : 0;
-  g.Kp = (int)lqer_padded_k(d->in_features) * xl;  // limbs side by side along k, weight image repeated to match
-  g.rp = (int)lqer_padded_r(d->rank) * al;
   g.b_limbs = b_limbs;
-  g.w_mbits = d->w_fmt.width - 1;
-  if (lowrank) g.bout = make_qp(d->b_out_fmt);
   if (from_partials) {
     xa_fused_plan(M, d->in_features, d->rank, &g.xa_nchunk, &g.xa_cstride);
     if (scratch_bytes < (size_t)g.xa_nchunk * g.xa_cstride * sizeof(float)) {

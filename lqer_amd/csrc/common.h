@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/lqer_hip.h"
 
 namespace lqer {
@@ -285,10 +287,25 @@ bool xa_fused_partials_ok(const QP& qx, const QP& qa, int64_t r);  // formats th
 void xa_fused_plan(int64_t M, int64_t K, int64_t r, int* nchunk, int64_t* cstride);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
+int gemm_route(const GemmArgs& g, bool lowrank);  // LQER_ROUTE_* the dispatch would take (or an error code)
 bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) rounds with 256 x 256 tiles
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
+
+// ---- kernel attributes (host) -----------------------------------------------------------------------
+// Raising a kernel's dynamic-LDS limit is idempotent but not free: done once per kernel instantiation and device,
+// thread-safely (the only process-wide state of the library besides the thread-local error text).
+struct LdsLimitOnce {
+  static constexpr int MAX_DEV = 64;
+  std::once_flag flag[MAX_DEV];
+  void set(const void* kernel, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::call_once(flag[dev & (MAX_DEV - 1)],
+                   [&] { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+  }
+};
 
 // ---- error plumbing (host) -------------------------------------------------------------------
 void set_error(const char* fmt, ...);

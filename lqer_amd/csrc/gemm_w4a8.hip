@@ -639,25 +639,16 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
 template <int DT>
 static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st) {
   const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n);
-  // raising the dynamic-LDS limit is idempotent; the flag only saves the call on later launches
 #define LQER_GEMM_LAUNCH(LR, BO)                                                                                \
   do {                                                                                                          \
-    static bool attr_done = false;                                                                              \
-    if (!attr_done) {                                                                                           \
-      (void)hipFuncSetAttribute((const void*)k_lqer_gemm<DT, LR, BO>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                GEMM_LDS);                                                                      \
-      attr_done = true;                                                                                         \
-    }                                                                                                           \
+    static LdsLimitOnce lds_once;                                                                               \
+    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO>, GEMM_LDS);                                               \
     k_lqer_gemm<DT, LR, BO><<<grid, 512, GEMM_LDS, st>>>(g);                                                    \
   } while (0)
 #define LQER_GEMM_LAUNCH_STAGED(BO)                                                                             \
   do {                                                                                                          \
-    static bool attr_done = false;                                                                              \
-    if (!attr_done) {                                                                                           \
-      (void)hipFuncSetAttribute((const void*)k_lqer_gemm<DT, true, BO, true>,                                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);                          \
-      attr_done = true;                                                                                         \
-    }                                                                                                           \
+    static LdsLimitOnce lds_once;                                                                               \
+    lds_once.set((const void*)k_lqer_gemm<DT, true, BO, true>, GEMM_LDS);                                       \
     k_lqer_gemm<DT, true, BO, true><<<grid, 512, GEMM_LDS, st>>>(g);                                            \
   } while (0)
 #ifndef LQER_STAGE_MIN
@@ -691,19 +682,39 @@ size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
   return (size_t)lqer_padded_m(m_max) * ((Np + L - 1) / L) * sizeof(float);
 }
 
+// B_out handling of a launch: 0 pass-through, 1 blocks of 16 (maxima in registers), 2 other blocks (pre-pass); < 0 error
+static int bout_mode(const GemmArgs& g, bool lowrank, int* L_out) {
+  if (lowrank && g.bout.kind == LQER_Q_MXINT) {
+    if (g.bout.block == 16) return 1;
+    const int L = (g.bout.block <= 0 || g.bout.block >= g.N) ? g.Np : g.bout.block;
+    if (L % 16 != 0) {
+      set_error("B_out_quantizer block %d: must be a multiple of 16 or cover the row", g.bout.block);
+      return LQER_E_UNSUPPORTED;
+    }
+    if (L_out) *L_out = L;
+    return 2;
+  }
+  if (lowrank && g.bout.kind != LQER_Q_PASSTHROUGH) {
+    set_error("B_out_quantizer kind %d not implemented", g.bout.kind);
+    return LQER_E_UNSUPPORTED;
+  }
+  return 0;
+}
+
+int gemm_route(const GemmArgs& g, bool lowrank) {
+  const int bout = bout_mode(g, lowrank, nullptr);
+  if (bout < 0) return bout;
+  if (smallm_eligible(g, bout)) return LQER_ROUTE_SMALLM;
+  if (m256_eligible(g)) return LQER_ROUTE_TILE256;
+  return LQER_ROUTE_TILE128;
+}
+
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st) {
   if (g.M == 0 || g.N == 0) return LQER_OK;
-  int bout = 0;
-  if (lowrank && g.bout.kind == LQER_Q_MXINT) {
-    if (g.bout.block == 16) {
-      bout = 1;
-    } else {
-      const int L = (g.bout.block <= 0 || g.bout.block >= g.N) ? g.Np : g.bout.block;
-      if (L % 16 != 0) {
-        set_error("B_out_quantizer block %d: must be a multiple of 16 or cover the row", g.bout.block);
-        return LQER_E_UNSUPPORTED;
-      }
-      bout = 2;
+  int L = 0;
+  const int bout = bout_mode(g, lowrank, &L);
+  if (bout < 0) return bout;
+  if (bout == 2) {
       g.bout_L = L;
       g.bout_nblk = (g.Np + L - 1) / L;
       const size_t need = (size_t)lqer_padded_m(g.M) * g.bout_nblk * sizeof(float);
@@ -727,10 +738,6 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
         k_bout_amax<2><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
       else
         k_bout_amax<1><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
-    }
-  } else if (lowrank && g.bout.kind != LQER_Q_PASSTHROUGH) {
-    set_error("B_out_quantizer kind %d not implemented", g.bout.kind);
-    return LQER_E_UNSUPPORTED;
   }
   if (smallm_eligible(g, bout)) return smallm_dispatch(g, dtype, lowrank, bout, st);  // decode sizes: HBM-bound variant
   if (m256_eligible(g)) return m256_dispatch(g, dtype, lowrank, bout, st);            // large M: 256 x 256 tiles

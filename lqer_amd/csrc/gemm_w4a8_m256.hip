@@ -410,12 +410,8 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
   const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n);
 #define LQER_M256_LAUNCH(LR, BO)                                                                                    \
   do {                                                                                                              \
-    static bool attr_done = false;                                                                                  \
-    if (!attr_done) {                                                                                               \
-      (void)hipFuncSetAttribute((const void*)k_lqer_gemm_m256<DT, LR, BO>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                GEMM_LDS);                                                                          \
-      attr_done = true;                                                                                             \
-    }                                                                                                               \
+    static LdsLimitOnce lds_once;                                                                                   \
+    lds_once.set((const void*)k_lqer_gemm_m256<DT, LR, BO>, GEMM_LDS);                                              \
     k_lqer_gemm_m256<DT, LR, BO><<<grid, 512, GEMM_LDS, st>>>(g);                                                   \
   } while (0)
   if (!lowrank)

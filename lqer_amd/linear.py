@@ -42,6 +42,11 @@ class _LinearBase(nn.Linear):
         self._fmt = {}
         self._packed = None
         self._packed_only = False  # True: images came from a packed checkpoint, the dense parameters are not used
+        # The weight and the bias are quantized ONCE, like the reference (linear.py:149-153: w_is_quantized stays True;
+        # block_fp quantization is not idempotent - a block maximum that rounds down to a power of two lowers the
+        # exponent of a second pass).  Their images outlive invalidate_packed() until the dense parameter is reloaded.
+        self._w_single = None      # single-copy packed weight image of the current `weight`
+        self._bias_q = None        # fp32 [Np] b_quantizer(bias) of the current `bias`
         self._group = None         # SharedActivation of Linears fed by the same tensor (models.quantize_model)
         self._fw_cache = {}        # token count -> (descriptor, workspace bytes)
         self._x_f16 = False        # pass-through fp16 activations on the fp16 MFMA route (decided when the images are built)
@@ -124,21 +129,30 @@ class _LinearBase(nn.Linear):
         return flat if c == 1 else flat.view(rows, c, rb)[:, 0].contiguous().reshape(-1)
 
     # -- derived buffers -------------------------------------------------------------------------
-    def invalidate_packed(self) -> None:
-        """Drop the packed images (called after weights change); the next forward re-packs."""
+    def invalidate_packed(self, weight_changed: bool = False, bias_changed: bool = False) -> None:
+        """Drop the derived images; the next forward rebuilds them.  The weight / bias keep their quantized-once images
+        (and `w_is_quantized`) unless the dense parameter itself was replaced: pass weight_changed / bias_changed = True
+        after writing new unquantized values into `weight` / `bias` by hand (load_state_dict does it by itself)."""
         self._packed = None
         self._fw_cache = {}
         self._x_f16 = False
-        if self.is_ptq:
-            self.w_is_quantized = False
+        if weight_changed:
+            self._w_single = None
+            if self.is_ptq:
+                self.w_is_quantized = False
+        if bias_changed or weight_changed:  # (the reference quantizes both in its one first-forward step)
+            self._bias_q = None
         if getattr(self, "_group", None) is not None:
             self._group.invalidate()
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
-        if any((prefix + k) in state_dict for k in ("weight", "bias", "A", "B")):  # dense operands (re)loaded
+        has = lambda k: (prefix + k) in state_dict
+        if any(has(k) for k in ("weight", "bias", "A", "B")):  # dense operands (re)loaded
             self._packed_only = False
-            self.invalidate_packed()
+            # A, B alone (runners.py:220-222 loads them after the first forward may have run): the weight is NOT
+            # quantized a second time
+            self.invalidate_packed(weight_changed=has("weight"), bias_changed=has("bias"))
 
     def _apply(self, fn, recurse=True):
         keep = getattr(self, "_packed_only", False) and self._packed is not None
@@ -162,6 +176,7 @@ class _LinearBase(nn.Linear):
                     p = self._replicate({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in p.items()})
                 self._packed = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in p.items()}
         else:
+            # .to() / .half(): the A / B images follow the new dtype and device; the weight stays quantized once
             self.invalidate_packed()
         return out
 
@@ -243,20 +258,28 @@ class _LinearBase(nn.Linear):
     def _pack(self) -> None:
         """One-time operand preparation = linear.py:149-153 (weight.copy_(w_quantizer(weight)), same for
         bias) plus the build's packed images.  Like the reference, the weight/bias parameters hold the
-        quantized values afterwards."""
+        quantized values afterwards, and they are quantized exactly once: when only the derived images were dropped
+        (.to(), .half(), A / B reloaded) the kept weight / bias images are reused."""
         W = self.weight.data
         ops._need_gpu(W)
         f = self._fmt
-        p = {"w": ops.pack_weight(W, f["w"])}
-        if self.bias is not None:
-            p["bias"] = ops.pack_bias(self.bias.data, f["b"])
-            self.bias.data.copy_(p["bias"][: self.out_features].to(self.bias.dtype))
-        if self.rank > 0:
-            p["a_t"], p["b_t"], p["a_limbs"], p["b_limbs"] = ops.pack_lowrank(self.A.data, self.B.data)
-        # the parameter now carries w_quantizer(W) (|w| <= 1e-8 kept as is, block_fp.py:79-80)
-        wq = ops.quantize_mxint(W, f["w"], want=("deq",))["deq"]
-        self.weight.data.copy_(wq.to(W.dtype))
-        self._packed = self._replicate(p)
+        with torch.cuda.device(W.device):
+            if self.w_is_quantized and self._w_single is not None:
+                w_img = self._w_single = self._w_single.to(W.device)
+            else:
+                w_img = self._w_single = ops.pack_weight(W, f["w"])
+                # the parameter now carries w_quantizer(W) (|w| <= 1e-8 kept as is, block_fp.py:79-80)
+                wq = ops.quantize_mxint(W, f["w"], want=("deq",))["deq"]
+                self.weight.data.copy_(wq.to(W.dtype))
+            p = {"w": w_img}
+            if self.bias is not None:
+                if self._bias_q is None:
+                    self._bias_q = ops.pack_bias(self.bias.data, f["b"])
+                    self.bias.data.copy_(self._bias_q[: self.out_features].to(self.bias.dtype))
+                p["bias"] = self._bias_q = self._bias_q.to(W.device)
+            if self.rank > 0:
+                p["a_t"], p["b_t"], p["a_limbs"], p["b_limbs"] = ops.pack_lowrank(self.A.data, self.B.data)
+            self._packed = self._replicate(p)
         self.w_is_quantized = True
 
     # -- forward -------------------------------------------------------------------------------
@@ -264,42 +287,49 @@ class _LinearBase(nn.Linear):
         if not self.is_ptq:
             raise NotImplementedError("lqer_amd implements the PTQ inference branch only (q_config['is_ptq'] = True)")
         ops._need_gpu(x)
-        with torch.no_grad():
-            if self._packed is None or self.w_is_quantized is False:
-                self._pack()
-            K, N = self.in_features, self.out_features
-            if x.shape[-1] != K:
-                raise RuntimeError(f"expected last dim {K}, got {tuple(x.shape)}")
-            if self._fmt["x"].kind == _lib.Q_PASSTHROUGH and x.dtype != self.weight.dtype:
-                # the packed images hold one copy per bf16 limb of the module's dtype (F.linear raises here as well)
-                raise RuntimeError(f"expected input dtype {self.weight.dtype} (pass-through x_quantizer), got {x.dtype}")
-            x2 = x.reshape(-1, K)
-            if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < K):
-                x2 = x2.contiguous()
-            M = x2.shape[0]
-            y = torch.empty(M, N, dtype=x.dtype, device=x.device)
-            if M > 0 and self._group is not None and self._group.forward_member(self, x, x2, y):
-                return y.reshape(*x.shape[:-1], N)
-            if M > 0:
-                # descriptor and workspace size per token count, built once (decode-size forwards are host-bound)
-                ent = self._fw_cache.get(M)
-                if ent is None:
-                    desc = self._desc()
-                    ent = self._fw_cache[M] = (desc, ops.linear_sizes(desc, M).workspace)
-                    if len(self._fw_cache) > 64:
-                        self._fw_cache = {M: ent}
-                desc, ws_bytes = ent
-                ws = ops.workspace(x.device, ws_bytes)
-                p = self._packed
-                check(
-                    _lib.lib().lqer_linear_forward(
-                        C.byref(desc), x2.data_ptr(), ops.dtype_code(x2), M, x2.stride(0) if M > 1 else K,
-                        p["w"].data_ptr(), ops._ptr(p.get("a_t")), ops._ptr(p.get("b_t")),
-                        p.get("a_limbs", 0), p.get("b_limbs", 0), ops._ptr(p.get("bias")),
-                        y.data_ptr(), N, ws.data_ptr(), ws.numel(), ops._stream(x.device)),
-                    "lqer_linear_forward",
-                )
+        # the C ABI launches on the calling thread's current device: make x's device current for the call (a module on
+        # cuda:1 under a single-process device map, reference experiments/infer_device_map.py:29-37)
+        if x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):
+                return self._forward_on_current_device(x)
+        return self._forward_on_current_device(x)
+
+    @torch.no_grad()
+    def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
+        if self._packed is None or self.w_is_quantized is False:
+            self._pack()
+        K, N = self.in_features, self.out_features
+        if x.shape[-1] != K:
+            raise RuntimeError(f"expected last dim {K}, got {tuple(x.shape)}")
+        if self._fmt["x"].kind == _lib.Q_PASSTHROUGH and x.dtype != self.weight.dtype:
+            # the packed images hold one copy per bf16 limb of the module's dtype (F.linear raises here as well)
+            raise RuntimeError(f"expected input dtype {self.weight.dtype} (pass-through x_quantizer), got {x.dtype}")
+        x2 = x.reshape(-1, K)
+        if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < K):
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        y = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        if M == 0 or (self._group is not None and self._group.forward_member(self, x, x2, y)):
             return y.reshape(*x.shape[:-1], N)
+        # per token count and dtype, built once: descriptor, workspace size and the constant part of the argument list
+        # (decode-size forwards are host-bound: the ctypes marshalling of 16 arguments is not free)
+        key = (M, x2.dtype)
+        ent = self._fw_cache.get(key)
+        if ent is None:
+            desc = self._desc()
+            p = self._packed
+            if len(self._fw_cache) > 64:
+                self._fw_cache = {}
+            ent = self._fw_cache[key] = (desc, C.byref(desc), ops.linear_sizes(desc, M).workspace, ops.dtype_code(x2),
+                                         (p["w"].data_ptr(), ops._ptr(p.get("a_t")), ops._ptr(p.get("b_t")),
+                                          p.get("a_limbs", 0), p.get("b_limbs", 0), ops._ptr(p.get("bias"))))
+        desc, dref, ws_bytes, dt, consts = ent
+        ws = ops.workspace(x.device, ws_bytes)
+        rc = _lib.lib().lqer_linear_forward(dref, x2.data_ptr(), dt, M, x2.stride(0) if M > 1 else K, *consts,
+                                            y.data_ptr(), N, ws.data_ptr(), ws.numel(), ops._stream(x.device))
+        if rc:
+            check(rc, "lqer_linear_forward")
+        return y.reshape(*x.shape[:-1], N)
 
     def __repr__(self):
         return "{}(in_features={}, out_features={}, bias={}, is_ptq={}, rank={}, backend=hip/gfx950)".format(
@@ -342,12 +372,13 @@ class SharedActivation:
         self._ver = -1
         self._buf = {}        # per (M, device): xq, xaq buffers
         self._cur = None
+        self._served = set()  # members served from the current images
         if self.enabled:
             for m in self.members:
                 m._group = self
 
     def invalidate(self):
-        self._cat, self._x, self._cur = None, None, None
+        self._cat, self._x, self._cur, self._served = None, None, None, set()
 
     @torch.no_grad()
     def _pack_cat(self, dev):
@@ -381,7 +412,12 @@ class SharedActivation:
         L = _lib.lib()
         M, K = x2.shape
         m0 = self.members[0]
-        fresh = not (x is self._x and x._version == self._ver and self._cur is not None and self._cur["M"] == M)
+        # the shared images serve a member only for the very tensor object they were made from, unmodified (version
+        # counter; inference tensors have none - torch.inference_mode() - and rely on object identity), and only once per
+        # member: a member that comes back with the same tensor starts a new round
+        ver = None if x.is_inference() else x._version
+        idx = self.members.index(mod)
+        fresh = not (x is self._x and ver == self._ver and self._cur is not None and self._cur["M"] == M and idx not in self._served)
         if fresh:
             gdesc = m0._desc()
             gdesc.rank = self._cat["rp_total"]
@@ -398,9 +434,12 @@ class SharedActivation:
                                          self._cat["a_t"].data_ptr(), self._cat["a_limbs"], b["xq"].data_ptr(),
                                          b["xaq"].data_ptr(), b["scr"].data_ptr(), b["nscr"], ops._stream(dev)),
                   "lqer_quantize_act_xa (shared input)")
-            self._x, self._ver, self._cur = x, x._version, dict(b, M=M)
+            self._x, self._ver, self._cur, self._served = x, ver, dict(b, M=M), set()
         cur = self._cur
-        off = self._cat["offs"][self.members.index(mod)]
+        self._served.add(idx)
+        if len(self._served) == len(self.members):
+            self._x = None  # every member has been served: do not pin the activation tensor until the next call
+        off = self._cat["offs"][idx]
         desc = mod._desc()
         p = mod._packed
         gs = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
@@ -419,10 +458,10 @@ class LinearFlexible(_LinearBase):
         # without a "default" key raises KeyError there and here.
         x_cfg = deepcopy(q_config.get("x_quantizer", q_config["default"]))
         w_cfg = deepcopy(q_config.get("w_quantizer", q_config["default"]))
-        self._fmt["x"] = ops.make_qfmt(x_cfg)
-        self._fmt["w"] = ops.make_qfmt(w_cfg)
+        self._fmt["x"] = ops.make_qfmt(x_cfg, "x")
+        self._fmt["w"] = ops.make_qfmt(w_cfg, "w")
         if self.bias is not None:
-            self._fmt["b"] = ops.make_qfmt(deepcopy(q_config.get("b_quantizer", q_config["default"])))
+            self._fmt["b"] = ops.make_qfmt(deepcopy(q_config.get("b_quantizer", q_config["default"])), "b")
 
     def _setup_lqer(self, l_config: dict):
         pass
@@ -432,8 +471,8 @@ class LinearFlexibleLqer(LinearFlexible):
     def _setup_quantizers(self, q_config: dict):
         LinearFlexible._setup_quantizers(self, q_config)
         fall = q_config.get("x_quantizer", q_config["default"])
-        self._fmt["B_out"] = ops.make_qfmt(deepcopy(q_config.get("B_out_quantizer", fall)))
-        self._fmt["A_out"] = ops.make_qfmt(deepcopy(q_config.get("A_out_quantizer", fall)))
+        self._fmt["B_out"] = ops.make_qfmt(deepcopy(q_config.get("B_out_quantizer", fall)), "B_out")
+        self._fmt["A_out"] = ops.make_qfmt(deepcopy(q_config.get("A_out_quantizer", fall)), "A_out")
 
     def _setup_lqer(self, l_config: dict):
         # y = x_q W_q^T + (x_q A) B ;  A [in, rank], B [rank, out], zeros until loaded (linear.py:134-143)

@@ -27,6 +27,22 @@ def _need_gpu(*ts: torch.Tensor) -> None:
             raise RuntimeError("lqer_amd runs on the HIP device only: got a CPU tensor (there is no CPU fallback)")
 
 
+def _on_tensor_device(fn):
+    """The C ABI launches on the calling thread's CURRENT device (include/lqer_hip.h): run `fn` with the device of its
+    first tensor argument current, so that a tensor on cuda:1 is never handed to a launch on cuda:0."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        t = next((a for a in args if torch.is_tensor(a)), None)
+        if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+            with torch.cuda.device(t.device):
+                return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+
+    return wrapped
+
+
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
@@ -35,9 +51,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def make_qfmt(cfg: Optional[dict], last_dim_only: bool = True) -> QFmt:
-    """One q_config entry (reference quantize/__init__.py:1-40 schema) -> lqer_qfmt_t.
-    Blocks must run along the last dim: block_size [1, L], [L] or [-1] (every template config)."""
+def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
+    """One q_config entry (reference quantize/__init__.py:1-40 schema) -> lqer_qfmt_t.  `role` = which tensor the
+    quantizer is applied to ("x", "A_out", "B_out": activations [.., tokens, features]; "w": the 2-D weight; "b": the
+    1-D bias), because the reference right-aligns `block_size` to the tensor and `skip_first_dim` picks the blocking
+    routine (quantizers/utils.py:42-67, :261-284).  The HIP path implements blocks that run along the last dim within
+    one row: [1, L], or a one-entry [L] / [-1] where the reference reads it per row (activations and weights with
+    skip_first_dim = true - the default, block_fp.py:111-118 - and the bias).  Anything else (2-D tiles, e.g. a weight
+    with skip_first_dim = false and block_size [L] = all rows x L) raises instead of being silently read per row."""
     if cfg is None:
         raise KeyError("quantizer config missing")
     name = cfg["name"]
@@ -47,14 +68,25 @@ def make_qfmt(cfg: Optional[dict], last_dim_only: bool = True) -> QFmt:
         raise NotImplementedError(f"quantizer '{name}' is not implemented on the HIP path (block_fp, passthrough)")
     bs = cfg.get("block_size", [16])
     bs = [bs] if isinstance(bs, int) else list(bs)
-    if any(b not in (1,) for b in bs[:-1]):
-        raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path")
+    skip = bool(cfg.get("skip_first_dim", True))
+    if role == "b":
+        assert not skip, "skip_first_dim must be False for bias to be blocked"  # (utils.py:268-271)
+        if len(bs) > 1 and any(b != 1 for b in bs[:-1]):
+            bs = bs[-1:]  # right-aligned to a 1-D tensor: only the last entry counts
+    else:
+        if any(b != 1 for b in bs[:-1]):
+            raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path")
+        if len(bs) < 2 and not skip:
+            raise NotImplementedError(
+                f"block_size {bs} with skip_first_dim = false is right-aligned to [-1, {bs[-1]}] (2-D tiles over all rows, "
+                "quantizers/utils.py:42-67): only per-row blocks ([1, L], or [L] with skip_first_dim = true) are implemented")
     ew = int(cfg.get("exponent_width", 8))
     eb = cfg.get("exponent_bias", None)
     eb = 2 ** (ew - 1) - 1 if eb in (None, "none", "None", "NA") else int(eb)
     return QFmt(_lib.Q_MXINT, int(cfg.get("width", 12)), int(bs[-1]), ew, eb)
 
 
+@_on_tensor_device
 def quantize_mxint(x: torch.Tensor, fmt: QFmt, want=("deq", "codes", "exps")) -> Dict[str, torch.Tensor]:
     """MXINT quantizer over the last dim of x (any leading dims).  Returns the requested images."""
     _need_gpu(x)
@@ -83,6 +115,7 @@ def quantize_mxint(x: torch.Tensor, fmt: QFmt, want=("deq", "codes", "exps")) ->
     return out
 
 
+@_on_tensor_device
 def quantize_act(x2: torch.Tensor, fmt: QFmt, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [M,K] -> exact bf16 image [Mp,Kp] of x_quantizer(x)."""
     _need_gpu(x2)
@@ -104,6 +137,7 @@ def linear_sizes(desc: LinearDesc, m_max: int) -> LinearSizes:
     return sz
 
 
+@_on_tensor_device
 def pack_weight(W: torch.Tensor, fmt: QFmt) -> torch.Tensor:
     _need_gpu(W)
     N, K = W.shape
@@ -120,6 +154,7 @@ def pack_weight(W: torch.Tensor, fmt: QFmt) -> torch.Tensor:
     return packed
 
 
+@_on_tensor_device
 def replicate_rows(src: torch.Tensor, rows: int, row_bytes: int, copies: int) -> torch.Tensor:
     """[rows][row_bytes] -> [rows][copies * row_bytes] (every row repeated): the packed images of a Linear with
     pass-through activations hold one copy per bf16 limb of the activation (include/lqer_hip.h)."""
@@ -134,6 +169,7 @@ def replicate_rows(src: torch.Tensor, rows: int, row_bytes: int, copies: int) ->
     return dst.view(src.dtype)
 
 
+@_on_tensor_device
 def f16_prepare(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: Optional[torch.Tensor], a_limbs: int, r: int):
     """Eligibility of the fp16 fast path of pass-through fp16 activations (include/lqer_hip.h, lqer_f16_prepare):
     returns (ok, a_t_f16) - ok is False when a weight block scale or an element of A is outside fp16.  Synchronises."""
@@ -154,6 +190,7 @@ def desc_limbs(desc: LinearDesc) -> Tuple[int, int]:
     return a.value, b.value
 
 
+@_on_tensor_device
 def unpack_weight(packed: torch.Tensor, N: int, K: int, fmt: QFmt) -> torch.Tensor:
     _need_gpu(packed)
     out = torch.empty(N, K, dtype=torch.float32, device=packed.device)
@@ -161,6 +198,7 @@ def unpack_weight(packed: torch.Tensor, N: int, K: int, fmt: QFmt) -> torch.Tens
     return out
 
 
+@_on_tensor_device
 def pack_lowrank(A: torch.Tensor, B: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, int, int]:
     """A [K,r], B [r,N] -> (a_t, b_t, a_limbs, b_limbs).  Synchronises once to read the limb counts."""
     _need_gpu(A, B)
@@ -182,6 +220,7 @@ def pack_lowrank(A: torch.Tensor, B: torch.Tensor) -> Tuple[torch.Tensor, torch.
     return a_t, b_t, int(fl[0]), int(fl[1])
 
 
+@_on_tensor_device
 def pack_bias(bias: torch.Tensor, fmt: QFmt) -> torch.Tensor:
     _need_gpu(bias)
     N = bias.shape[0]

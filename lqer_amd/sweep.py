@@ -60,3 +60,37 @@ def gather_checksums(value: float, device: torch.device) -> List[float]:
 def aggregate_throughput(flops_per_rank_step: float, steps: int, world: int, elapsed_max: float) -> float:
     """Weak scaling: every rank does `flops_per_rank_step` per step; TFLOP/s of the whole job."""
     return flops_per_rank_step * world * steps / elapsed_max / 1e12
+
+
+def broadcast_activation(x: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """The one exchange step of a multi-layer sweep: the token batch x [M, K] is generated on rank
+    `src` and broadcast to every rank (RCCL over xGMI on GPUs, gloo in the CPU tests), once per distinct K, outside
+    any timed region.  In place; identity without a process group."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(x, src=src)
+    return x
+
+
+def gather_rows(values: Sequence[float], device: torch.device) -> List[List[float]]:
+    """One row of floats per rank (per-rank time, checksum, unit count ...), gathered on every rank."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [[float(v) for v in values]]
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.tolist()] for o in out]
+
+
+def sum_over_ranks(value: float, device: torch.device) -> float:
+    """Whole-job total of a per-rank quantity (FLOPs per step: ranks of a layer-partitioned sweep own different counts)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

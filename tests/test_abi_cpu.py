@@ -115,6 +115,19 @@ def test_make_qfmt_schema():
         ops.make_qfmt(dict(name="block_fp", width=8, block_size=[16, 1]))
     with pytest.raises(NotImplementedError):
         ops.make_qfmt(dict(name="minifloat", width=8))
+    # the role decides how a one-entry block_size is right-aligned (quantizers/utils.py:42-67, :261-284): per row for
+    # activations / weights with skip_first_dim = true (the quantizer's default) and for the 1-D bias; a 2-D tensor with
+    # skip_first_dim = false reads [L] as tiles of ALL rows x L - not on the HIP path, and never silently per row
+    w = dict(name="block_fp", width=4, block_size=[128], skip_first_dim=False)
+    with pytest.raises(NotImplementedError):
+        ops.make_qfmt(w, "w")
+    with pytest.raises(NotImplementedError):
+        ops.make_qfmt(dict(w, width=8), "x")
+    assert ops.make_qfmt(dict(w, skip_first_dim=True), "w").block == 128
+    assert ops.make_qfmt(dict(w, block_size=[1, 128]), "w").block == 128
+    assert ops.make_qfmt(dict(name="block_fp", width=8, block_size=[16], skip_first_dim=False), "b").block == 16
+    with pytest.raises(AssertionError):  # the reference asserts the same for a bias (utils.py:268-271)
+        ops.make_qfmt(dict(name="block_fp", width=8, block_size=[16], skip_first_dim=True), "b")
 
 
 def test_module_mirrors_reference_interface():

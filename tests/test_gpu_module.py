@@ -1,0 +1,143 @@
+"""Module-level behaviour of the drop-in Linear on the GPU: quantize-once semantics (reference linear.py:149-153),
+shared activations under torch.inference_mode(), launches on a non-current device.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lqer_oracle as O  # the checker
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import lqer_amd
+
+    return lqer_amd
+
+
+def _non_idempotent_weight(N, K, seed=0, frac=0.51):
+    """Weights whose block maxima round DOWN to a power of two under W4 blocks of 16 (|w| in (0.47, 0.53) * 2^k rounds
+    to code 4 = 2^(k-1)): a second quantization pass lowers the block exponent and clamps that element to 7/8."""
+    g = torch.Generator().manual_seed(seed)
+    W = 0.02 * torch.randn(N, K, generator=g)
+    blk = W.reshape(N, K // 16, 16)
+    amax = blk.abs().amax(-1, keepdim=True)
+    e = torch.ceil(torch.log2(amax))
+    scale = (frac * 2.0 ** e) / amax  # block maximum -> frac * 2^e
+    return (blk * scale).reshape(N, K)
+
+
+def test_weight_is_quantized_exactly_once(lq):
+    from bench import MXINT_Q, make_case
+
+    M, K, N, r = 40, 256, 192, 32
+    x, _, A, B = make_case(M, K, N, r, seed=3)
+    W = _non_idempotent_weight(N, K)
+    wq = O.get_quantizer(MXINT_Q["w_quantizer"])(W)
+    assert not torch.equal(O.get_quantizer(MXINT_Q["w_quantizer"])(wq), wq)  # the premise: Q(Q(W)) != Q(W)
+    xd = x.to(DEV)
+    ref = O.lqer_linear_forward(x, W, None, A, B, MXINT_Q)
+
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W}, strict=False)  # the HF checkpoint first (llama_decoder.py:507) ...
+    mod = mod.to(DEV)
+    mod(xd)  # ... a forward quantizes the weight in place ...
+    assert mod.w_is_quantized and torch.equal(mod.weight.detach().cpu(), wq)
+    mod.load_state_dict({"A": A, "B": B}, strict=False)  # ... then the low-rank dict (runners.py:220-222)
+    assert mod.w_is_quantized  # only A / B were reloaded
+    y = mod(xd).cpu()
+    assert torch.equal(mod.weight.detach().cpu(), wq)
+    assert (y - ref).norm() / ref.norm() <= 1e-5
+    # a dtype cast / device round trip rebuilds the A / B images but keeps Q(W)
+    m2 = mod.half()
+    y2 = m2(xd.half()).float().cpu()
+    ref16 = O.lqer_linear_forward(x.half().float(), wq, None, A.half().float(), B.half().float(), MXINT_Q, weight_is_quantized=True)
+    assert (y2 - ref16).norm() / ref16.norm() <= 1e-3
+    assert torch.equal(m2.weight.detach().float().cpu(), wq.half().float())
+    m3 = m2.cpu().to(DEV)
+    assert torch.equal(m3(xd.half()).float().cpu(), y2)
+    # reloading the dense weight DOES re-quantize
+    m3.load_state_dict({"weight": W.half()}, strict=False)
+    assert m3.w_is_quantized is False
+    y4 = m3(xd.half()).float().cpu()
+    ref4 = O.lqer_linear_forward(x.half().float(), W.half().float(), None, A.half().float(), B.half().float(), MXINT_Q)
+    assert (y4 - ref4).norm() / ref4.norm() <= 1e-3
+
+
+def test_bias_is_quantized_exactly_once(lq):
+    from bench import OPT_Q, make_case
+
+    M, K, N, r = 9, 128, 64, 16
+    x, W, A, B, b = make_case(M, K, N, r, seed=4, bias=True)
+    b = _non_idempotent_weight(1, N, seed=5, frac=0.501).reshape(N) * 0.5  # 8-bit: maxima in (0.5, 0.5039) 2^e round to 2^(e-1)
+    qb = O.get_quantizer(OPT_Q["b_quantizer"])
+    assert not torch.equal(qb(qb(b)), qb(b))  # the premise
+    ref = O.lqer_linear_forward(x, W, b, A, B, OPT_Q)
+    mod = lq.LinearFlexibleLqer(K, N, bias=True, q_config=OPT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "bias": b, "A": A, "B": B})
+    mod = mod.to(DEV)
+    y = mod(x.to(DEV)).cpu()
+    assert (y - ref).norm() / ref.norm() <= 1e-5
+    bq = mod.bias.detach().clone()
+    mod.load_state_dict({"A": A, "B": B}, strict=False)
+    assert torch.equal(mod(x.to(DEV)).cpu(), y) and torch.equal(mod.bias.detach(), bq)
+
+
+def test_shared_activation_under_inference_mode(lq):
+    """q/k/v handed the same tensor under torch.inference_mode(): inference tensors have no version counter - the group
+    must still serve the three members from one quantization, give the results of the members run alone, and start a new
+    round when a member comes back."""
+    from bench import MXINT_Q, make_case
+    from lqer_amd.linear import SharedActivation
+
+    M, K, r = 70, 256, 32
+    mods = []
+    for i, N in enumerate((192, 64, 128)):
+        x, W, A, B = make_case(M, K, N, r, seed=30 + i)
+        m = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+        m.load_state_dict({"weight": W, "A": A, "B": B})
+        mods.append(m.to(DEV).half())
+    xd = x.half().to(DEV)
+    alone = [m(xd).clone() for m in mods]
+    grp = SharedActivation(mods)
+    assert grp.enabled
+    with torch.inference_mode():
+        h = xd * 1.0  # an inference tensor
+        assert h.is_inference()
+        got = [m(h) for m in mods]
+        assert grp._x is None  # released after the last member
+        for a, g in zip(alone, got):
+            assert (a.float() - g.float()).norm() / a.float().norm() <= 2e-3  # (side-product summation order may differ)
+        again = [m(h) for m in mods]  # second round on the same object: images rebuilt, same bits
+        for g, a2 in zip(got, again):
+            assert torch.equal(g, a2)
+        h2 = xd * 2.0
+        got2 = mods[0](h2)
+        assert not torch.equal(got2, got[0])
+    with torch.no_grad():  # ordinary tensors: an in-place change between two members is noticed through the version counter
+        h = xd.clone()
+        y0 = mods[0](h)
+        h.mul_(2.0)
+        y1 = mods[1](h)
+        assert (y1.float() - 2 * alone[1].float()).norm() / (2 * alone[1].float()).norm() <= 5e-3
+
+
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
+def test_forward_on_a_non_current_device(lq):
+    from bench import MXINT_Q, make_case
+
+    M, K, N, r = 33, 256, 192, 32
+    x, W, A, B = make_case(M, K, N, r, seed=8)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    ref = O.lqer_linear_forward(x, W, None, A, B, MXINT_Q)
+    torch.cuda.set_device(0)
+    mod = mod.to("cuda:1")
+    y = mod(x.to("cuda:1"))
+    assert torch.cuda.current_device() == 0 and y.device.index == 1
+    assert (y.cpu() - ref).norm() / ref.norm() <= 1e-5

@@ -41,7 +41,62 @@ def test_two_ranks_gloo():
         assert agg == pytest.approx(2e12 * 2 * 5 / 2.0 / 1e12)
 
 
+def _sweep_worker(rank, world, port, q, n_layers):
+    """The strong-scaling sweep's host logic as bench.py runs it: rank 0 makes the token batch, it is broadcast once
+    per distinct K, every rank owns ceil(L / G) consecutive layers (uneven when G does not divide L), per-rank rows are
+    gathered and the whole-job FLOPs are summed."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from bench import flops, make_x
+
+        dev = torch.device("cpu")
+        shapes = [(64, 48, 2), (48, 64, 1)]  # (K, N, count per layer)
+        M, r = 8, 16
+        xs = {}
+        for K in sorted({K for K, _, _ in shapes}):
+            x = make_x(M, K, seed=0)[0].half() if rank == 0 else torch.full((M, K), float("nan"), dtype=torch.float16)
+            xs[K] = sweep.broadcast_activation(x, src=0)
+        mine = sweep.layer_partition(n_layers, world)[rank]
+        units = sweep.projection_units(shapes, mine)
+        fl = float(sum(flops(M, K, N, r) for _, K, N, _ in units))
+        total = sweep.sum_over_ranks(fl, dev)
+        rows = sweep.gather_rows([0.5 * (rank + 1), float(xs[64].float().sum()), float(len(mine))], dev)
+        q.put((rank, list(mine), len(units), total, rows, {K: float(v.float().abs().sum()) for K, v in xs.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_layers", [5, 4, 1])
+def test_layer_partitioned_sweep_two_ranks_gloo(n_layers):
+    from bench import flops, make_x
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + 7 * n_layers) % 2000
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q, n_layers)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per = -(-n_layers // 2)
+    assert res[0][1] == list(range(0, per)) and res[1][1] == list(range(per, n_layers))  # 5 -> 3 + 2, 4 -> 2 + 2, 1 -> 1 + 0
+    assert res[0][2] == 3 * per and res[1][2] == 3 * (n_layers - per)
+    want = n_layers * (2 * flops(8, 64, 48, 16) + flops(8, 48, 64, 16))
+    assert res[0][3] == res[1][3] == want  # a fixed model: total work does not depend on the split
+    assert res[0][4] == res[1][4] and [row[2] for row in res[0][4]] == [float(per), float(n_layers - per)]
+    assert [row[0] for row in res[0][4]] == [0.5, 1.0]
+    ref = {K: float(make_x(8, K, seed=0)[0].half().float().abs().sum()) for K in (48, 64)}
+    assert res[0][5] == res[1][5] == ref  # rank 1 received rank 0's batch (its own buffer was NaN)
+
+
 def test_single_process_is_identity():
+    x = torch.ones(2, 3)
+    assert sweep.broadcast_activation(x) is x
+    assert sweep.gather_rows([1.0, 2.0], torch.device("cpu")) == [[1.0, 2.0]] and sweep.sum_over_ranks(3.0, torch.device("cpu")) == 3.0
     assert sweep.max_over_ranks(0.25, torch.device("cpu")) == 0.25
     assert sweep.gather_checksums(3.0, torch.device("cpu")) == [3.0]
 

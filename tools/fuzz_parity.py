@@ -25,8 +25,8 @@ def one_case(rng):
     cfgname = rng.choice(["mxint", "opt", "int", "bout_pass", "a16", "a16", "a16mix"])
     dtype = rng.choice([torch.float16, torch.float16, torch.bfloat16, torch.float32])
     if kind == "m256":
-        K = rng.choice([64, 128, 200, 320])
-        r = rng.choice([0, 16, 32])
+        K = rng.choice([64, 128, 200, 320, 520, 1000])
+        r = rng.choice([0, 16, 32, 64, 128])
         dtype = torch.float16
     return M, K, N, r, cfgname, dtype
 
