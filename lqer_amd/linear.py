@@ -128,6 +128,12 @@ class _LinearBase(nn.Linear):
         flat = self._packed[name].reshape(-1).view(torch.uint8)
         return flat if c == 1 else flat.view(rows, c, rb)[:, 0].contiguous().reshape(-1)
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle: the per-token-count launch cache holds raw device pointers of THIS module's images
+        st = self.__dict__.copy()
+        st["_fw_cache"] = {}
+        return st
+
     # -- derived buffers -------------------------------------------------------------------------
     def invalidate_packed(self, weight_changed: bool = False, bias_changed: bool = False) -> None:
         """Drop the derived images; the next forward rebuilds them.  The weight / bias keep their quantized-once images
@@ -320,10 +326,12 @@ class _LinearBase(nn.Linear):
             p = self._packed
             if len(self._fw_cache) > 64:
                 self._fw_cache = {}
-            ent = self._fw_cache[key] = (desc, C.byref(desc), ops.linear_sizes(desc, M).workspace, ops.dtype_code(x2),
+            # (plain data only: the module must stay deep-copyable and picklable)
+            ent = self._fw_cache[key] = (desc, ops.linear_sizes(desc, M).workspace, ops.dtype_code(x2),
                                          (p["w"].data_ptr(), ops._ptr(p.get("a_t")), ops._ptr(p.get("b_t")),
                                           p.get("a_limbs", 0), p.get("b_limbs", 0), ops._ptr(p.get("bias"))))
-        desc, dref, ws_bytes, dt, consts = ent
+        desc, ws_bytes, dt, consts = ent
+        dref = C.byref(desc)
         ws = ops.workspace(x.device, ws_bytes)
         rc = _lib.lib().lqer_linear_forward(dref, x2.data_ptr(), dt, M, x2.stride(0) if M > 1 else K, *consts,
                                             y.data_ptr(), N, ws.data_ptr(), ws.numel(), ops._stream(x.device))

@@ -274,7 +274,7 @@ def test_shared_activation_groups_int_config_gpu():
     with torch.no_grad():
         a = shared(input_ids=ids).logits.float().cpu()
         b = plain(input_ids=ids).logits.float().cpu()
-    assert grp._x is not None  # the shared images were used
+    assert grp._cur is not None and len(grp._served) == len(grp.members)  # the shared images were made and served every member
     assert (a - b).norm() / b.norm() <= 5e-5
     # rank 48 is not a power of two and rank 24 is not a multiple of 16: one block per row cannot be cut per member
     for r in (48, 24):
