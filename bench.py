@@ -267,6 +267,8 @@ def main():
     ws = ops.workspace(dev, max(ops.linear_sizes(mod._desc(), M).workspace for mod, *_ in mods))  # one buffer for all
     for mod, xd, K, N, reps, y, _ in mods:
         desc = mod._desc()
+        if mod._x_i8 and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) != _lib.ROUTE_TILE256_I8:
+            desc = mod._desc(plain=True)  # token counts the int8 tile kernel does not serve: the bf16 kernels, same buffers
         p = mod._packed
         Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
         xl, al = ops.desc_limbs(desc)  # bf16 limbs of the activation / x A images (1, 1 unless pass-through)
@@ -417,7 +419,10 @@ def main():
             n_launch += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         routes = sorted({pl["route"] for pl in plans})
-        kname = {_lib.ROUTE_SMALLM: "k_lqer_gemm_smallm", _lib.ROUTE_TILE128: "k_lqer_gemm", _lib.ROUTE_TILE256: "k_lqer_gemm_m256"}
+        kname = {_lib.ROUTE_SMALLM: "k_lqer_gemm_smallm", _lib.ROUTE_TILE128: "k_lqer_gemm", _lib.ROUTE_TILE256: "k_lqer_gemm_m256",
+                 _lib.ROUTE_TILE256_I8: "k_lqer_gemm_i8"}
+        int8 = routes == [_lib.ROUTE_TILE256_I8]  # every GEMM of the step ran the int8 MFMA main loop
+        peak = INT8_MFMA_PEAK_TOPS if int8 else BF16_MFMA_PEAK_TFLOPS
         kernels = "+".join(kname.get(rt, str(rt)) for rt in routes)
         # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this very
         # command (tools/pmc_bench.sh; a profiler cannot run inside this process); the committed summary of the
@@ -428,8 +433,8 @@ def main():
             with open(tfile) as fh:
                 tj = json.load(fh)
             traffic, traffic_ratio = tj.get("traffic_bytes_per_launch"), tj.get("ratio_to_algorithmic")
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TOP/s" if int8 else "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
                     "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
                     "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                     "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4)}
@@ -455,7 +460,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "f16" if mods[0][0]._x_f16 else "bf16",  # the arithmetic type of the main loop's MFMA operands
+            # the arithmetic type of the main loop's MFMA operands
+            "dtype": "int8" if (M > 64 and int8) else ("f16" if mods[0][0]._x_f16 else "bf16"),
             "data": "synthetic",
             "config": {"workload": desc_txt, "tokens_per_step": M, "rank": r,
                        "formats": "x %s, W MXINT4/%s, A_out,B_out as x, y fp16" % (

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 3
+#define LQER_ABI_VERSION 4
 
 /* error codes */
 #define LQER_OK 0
@@ -52,6 +52,9 @@ extern "C" {
 #define LQER_Q_MXINT 1 /* "block_fp" */
 #define LQER_Q_PASSTHROUGH_F16 2 /* x_fmt only: pass-through fp16 activations multiplied natively (v_mfma_*_f16) - needs
                                     lqer_f16_prepare to report both operands exact, see "pass-through activations" */
+
+#define LQER_Q_MXINT_I8 3 /* x_fmt only: block_fp activations with ONE block per row (width <= 8) carried as int8 mantissas and
+                            multiplied on the int8 MFMA - needs lqer_i8_prepare to report the weight eligible, see "int8 route" */
 
 /* Geometry of the packed operands (fixed by the kernels; exported so callers can size buffers). */
 #define LQER_K_ALIGN 64     /* K is zero-padded to a multiple of this                        */
@@ -192,6 +195,7 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
 #define LQER_ROUTE_SMALLM 0
 #define LQER_ROUTE_TILE128 1
 #define LQER_ROUTE_TILE256 2
+#define LQER_ROUTE_TILE256_I8 3 /* 256 x 256 tiles, int8 MFMA main loop (x_fmt.kind = LQER_Q_MXINT_I8 only) */
 int lqer_gemm_route(const lqer_linear_desc_t* desc, int64_t M, int dtype);
 
 /* Decode sizes (launch-bound: each kernel runs ~3 us).  Returns 1 when, for this descriptor and token count, the
@@ -234,6 +238,30 @@ int lqer_desc_limbs(const lqer_linear_desc_t* desc, int* act_limbs, int* xa_limb
  * then skips the copy, and the split API accepts xq == x in lqer_quantize_act_xa / lqer_linear_gemm. */
 int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r,
                      void* a_t_f16, int32_t* flags, void* stream);
+
+/* ---- int8 route (the "W4A8 INT" configurations: x_quantizer block_fp with block_size [1,-1], i.e. one exponent per token,
+ * reference experiments/pipeline/sweep_lqer_act_int.sh:83; w_quantizer blocks of 128 k or one block per row,
+ * llama-7b-int.toml:87) ---------------------------------------------------------------------------------------------
+ * With one activation exponent per token and one weight exponent per 128 k (or more) the products of a 128-k group share
+ * one scale per output element, so their integer mantissas can be summed exactly on v_mfma_i32_32x32x32_i8 at twice the
+ * bf16 rate.  x_fmt.kind = LQER_Q_MXINT_I8 selects this:
+ *  - lqer_linear_sizes reports w_packed = the 4-bit sign-magnitude image of lqer_pack_weight_mxint followed (256-byte
+ *    aligned) by a second image for the int8 main loop: two's-complement nibbles + one left shift per (row, 128-k group)
+ *    + one scale per row (4.06 bit per weight).  Pack the first image as usual, then call lqer_i8_prepare on the same
+ *    buffer.  flags[0] != 0 (device int32[2]): some row's integer sums could leave the i32 range, or the image holds two
+ *    exponents inside one 128-k group - do not use LQER_Q_MXINT_I8 for this weight (plain LQER_Q_MXINT is always exact).
+ *  - the activation image xq is then int8: [Mp][K padded to 128] mantissas followed (256-byte aligned) by Mp fp32 row
+ *    scales; never larger than the bf16 image (K >= 128 required), so the workspace carving does not change.
+ *  - the split calls lqer_quantize_act_xa / lqer_lowrank_xa / lqer_linear_gemm[_ld] with this kind ALWAYS produce /
+ *    consume the int8 images; lqer_gemm_route says whether that is possible for M tokens (LQER_ROUTE_TILE256_I8: M >= 512
+ *    and 256-row tiles fill the chip, B_out pass-through or one block per row, padded rank x limbs of x A <= 128);
+ *    otherwise call them with kind LQER_Q_MXINT on the same buffers.  lqer_linear_forward chooses by itself.
+ * Requires x_fmt.width <= 8, x_fmt.block <= 0 or >= K, w_fmt.block <= 0, >= K or a multiple of 128. */
+int lqer_i8_prepare(void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* w_fmt, int32_t* flags, void* stream);
+/* Test hooks: the int8 weight image (inside w_packed) -> dequantized fp32 [N,K]; x [M,K] -> the int8 activation image. */
+int lqer_unpack_weight_i8(const void* w_packed, int64_t N, int64_t K, float* w_f32, void* stream);
+int lqer_quantize_act_i8(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const lqer_qfmt_t* fmt, void* xq_i8,
+                         void* stream);
 /* dst[row] = src[row] repeated `copies` times (device to device, stream-ordered; dst != src). */
 int lqer_replicate_rows(const void* src, void* dst, int64_t rows, int64_t row_bytes, int copies, void* stream);
 

@@ -26,6 +26,8 @@ int check_launch(const char* what) {
   return LQER_OK;
 }
 
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
 static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
   if (!f) {
     set_error("%s: null format", name);
@@ -33,7 +35,11 @@ static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
   }
   if (f->kind == LQER_Q_PASSTHROUGH) return true;
   if (f->kind == LQER_Q_PASSTHROUGH_F16 && strcmp(name, "x_quantizer") == 0) return true;
-  if (f->kind != LQER_Q_MXINT) {
+  if (f->kind == LQER_Q_MXINT_I8 && strcmp(name, "x_quantizer") != 0) {
+    set_error("%s: LQER_Q_MXINT_I8 is an x_quantizer kind", name);
+    return false;
+  }
+  if (f->kind != LQER_Q_MXINT && f->kind != LQER_Q_MXINT_I8) {
     set_error("%s: quantizer kind %d is not implemented on the HIP path", name, f->kind);
     return false;
   }
@@ -48,8 +54,6 @@ static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
   return true;
 }
 
-static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
 // bf16 limbs of a pass-through tensor: fmt.width = significand bits to carry (8 per limb); block_fp images need one
 static int limbs_of(const lqer_qfmt_t& f) {
   if (f.kind != LQER_Q_PASSTHROUGH) return 1;
@@ -57,6 +61,30 @@ static int limbs_of(const lqer_qfmt_t& f) {
 }
 static int act_limbs(const lqer_linear_desc_t* d) { return limbs_of(d->x_fmt); }
 static bool x_is_f16(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_PASSTHROUGH_F16; }
+static bool x_is_i8(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_MXINT_I8; }
+// byte offset of the int8 weight image inside w_packed (behind the sign-magnitude panels)
+static size_t i8_image_offset(const lqer_linear_desc_t* d) {
+  const size_t Kp = lqer_padded_k(d->in_features), Np = lqer_padded_n(d->out_features);
+  return align_up((Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES, 256);
+}
+// static requirements of the int8 route (include/lqer_hip.h "int8 route")
+static bool i8_formats_ok(const lqer_linear_desc_t* d) {
+  const lqer_qfmt_t &x = d->x_fmt, &w = d->w_fmt;
+  const int64_t K = d->in_features;
+  if (x.width < 2 || x.width > 8 || !(x.block <= 0 || x.block >= K)) {
+    set_error("LQER_Q_MXINT_I8: x_quantizer must be block_fp with width <= 8 and one block per row (got width %d block %d)", x.width, x.block);
+    return false;
+  }
+  if (w.kind != LQER_Q_MXINT || w.width > 4 || !(w.block <= 0 || w.block >= K || w.block % I8_BK == 0)) {
+    set_error("LQER_Q_MXINT_I8: w_quantizer blocks must span a multiple of 128 k or the whole row (got block %d)", w.block);
+    return false;
+  }
+  if (K < I8_BK) {
+    set_error("LQER_Q_MXINT_I8: in_features %lld < 128", (long long)K);
+    return false;
+  }
+  return true;
+}
 // LQER_Q_PASSTHROUGH_F16: a dense fp16 tensor whose extents are already the padded ones IS the activation image
 // (M a multiple of the row padding: the tile kernels read whole row tiles; M <= 64: the small-M kernel and the side
 // GEMM never read past row M - 1 - unless B_out blocks other than 16 send a decode-size call to the tile kernel)
@@ -155,6 +183,57 @@ int lqer_quantize_act_mxint(const void* x, int dtype, int64_t M, int64_t K, int6
   return quantize_dispatch(x, dtype, M, K, ldx, q, o, (hipStream_t)stream);
 }
 
+int lqer_quantize_act_i8(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const lqer_qfmt_t* fmt, void* xq_i8,
+                         void* stream) {
+  if ((!x || !xq_i8) && M * K > 0) {
+    set_error("quantize_act_i8: null pointer");
+    return LQER_E_INVALID;
+  }
+  if (M < 0 || K < 0 || ldx < K) {
+    set_error("quantize_act_i8: bad shape M=%lld K=%lld ldx=%lld", (long long)M, (long long)K, (long long)ldx);
+    return LQER_E_INVALID;
+  }
+  if (!fmt || (fmt->kind != LQER_Q_MXINT && fmt->kind != LQER_Q_MXINT_I8) || fmt->width < 2 || fmt->width > 8 ||
+      !(fmt->block <= 0 || fmt->block >= K)) {
+    set_error("quantize_act_i8: needs block_fp with width <= 8 and one block per row");
+    return LQER_E_UNSUPPORTED;
+  }
+  lqer_qfmt_t f = *fmt;
+  f.kind = LQER_Q_MXINT;
+  f.block = -1;
+  QuantOut o{nullptr, nullptr, nullptr, nullptr, 0, 0};
+  o.xq8 = (int8_t*)xq_i8;
+  o.cols_p8 = padded_k8(K);
+  o.xscale = const_cast<float*>(i8_row_scales(xq_i8, M, K));
+  return quantize_dispatch(x, dtype, M, K, ldx, make_qp(f), o, (hipStream_t)stream);
+}
+
+int lqer_i8_prepare(void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* w_fmt, int32_t* flags, void* stream) {
+  if (!w_packed || !flags || !w_fmt || N <= 0 || K <= 0) {
+    set_error("i8_prepare: bad argument");
+    return LQER_E_INVALID;
+  }
+  lqer_linear_desc_t d;
+  memset(&d, 0, sizeof(d));
+  d.in_features = (int32_t)K, d.out_features = (int32_t)N;
+  d.w_fmt = *w_fmt;
+  d.x_fmt.kind = LQER_Q_MXINT_I8, d.x_fmt.width = 8, d.x_fmt.block = -1;
+  if (!i8_formats_ok(&d)) return LQER_E_UNSUPPORTED;
+  return i8_prepare_dispatch(w_packed, N, K, w_fmt->width - 1, (unsigned char*)w_packed + i8_image_offset(&d), flags,
+                             (hipStream_t)stream);
+}
+
+int lqer_unpack_weight_i8(const void* w_packed, int64_t N, int64_t K, float* w_f32, void* stream) {
+  if (!w_packed || !w_f32 || N <= 0 || K <= 0) {
+    set_error("unpack_weight_i8: bad argument");
+    return LQER_E_INVALID;
+  }
+  lqer_linear_desc_t d;
+  memset(&d, 0, sizeof(d));
+  d.in_features = (int32_t)K, d.out_features = (int32_t)N;
+  return i8_unpack_dispatch((const unsigned char*)w_packed + i8_image_offset(&d), N, K, w_f32, (hipStream_t)stream);
+}
+
 int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_sizes_t* out) {
   if (!d || !out || d->in_features <= 0 || d->out_features <= 0 || d->rank < 0 || m_max < 0) {
     set_error("linear_sizes: bad descriptor");
@@ -166,6 +245,10 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
     return LQER_E_INVALID;
   const size_t xl = act_limbs(d), al = xa_limbs(d);  // pass-through activations: images repeated per limb
   out->w_packed = (Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES * xl;
+  if (x_is_i8(d)) {
+    if (!i8_formats_ok(d)) return LQER_E_UNSUPPORTED;
+    out->w_packed = i8_image_offset(d) + i8_weight_image_bytes(d->out_features, d->in_features);
+  }
   out->a_t = 3 * rp * Kp * 2 * xl;
   out->b_t = 3 * Np * rp * 2 * al;
   out->bias_q = Np * 4;
@@ -175,7 +258,13 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
     const size_t b = d->b_out_fmt.kind == LQER_Q_MXINT ? gemm_scratch_bytes(m_max, d->out_features, make_qp(d->b_out_fmt)) : 0;
     side = align_up(a > b ? a : b, 256);  // the two scratch uses never overlap in time
   }
-  out->workspace = align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256) + side;
+  // (the int8 activation image + row scales of LQER_Q_MXINT_I8 fit the bf16 image's slot: K >= 128)
+  const size_t act = align_up(Mp * Kp * 2 * xl, 256);
+  if (x_is_i8(d) && i8_act_image_bytes(m_max, d->in_features) + Mp * sizeof(float) > act) {
+    set_error("linear_sizes: int8 activation image larger than the bf16 one (K %d)", d->in_features);
+    return LQER_E_UNSUPPORTED;
+  }
+  out->workspace = act + align_up(Mp * rp * 2 * al, 256) + side;
   return LQER_OK;
 }
 
@@ -241,7 +330,7 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
     set_error("lowrank_xa: a_limbs %d outside [0,3]", a_limbs);
     return LQER_E_INVALID;
   }
-  return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, x_is_f16(d) ? 0 : act_limbs(d), (const bf16_t*)a_t, a_limbs, d->rank,
+  return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, x_is_f16(d) ? 0 : (x_is_i8(d) ? -1 : act_limbs(d)), (const bf16_t*)a_t, a_limbs, d->rank,
                              make_qp(d->a_out_fmt), d->a_out_fmt.kind == LQER_Q_PASSTHROUGH ? xa_limbs(d) : 0,
                              (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
 }
@@ -287,6 +376,8 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
   } else if (d->x_fmt.kind == LQER_Q_PASSTHROUGH) {
     if (!passthrough_width_ok(d->x_fmt, "x_quantizer")) return LQER_E_INVALID;
     rc = split_act_dispatch(x, dtype, M, d->in_features, ldx, act_limbs(d), (bf16_t*)xq, (hipStream_t)stream);
+  } else if (x_is_i8(d)) {
+    rc = lqer_quantize_act_i8(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
   } else {
     rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
   }
@@ -323,6 +414,12 @@ static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, Ge
   g.rp = (int)lqer_padded_r(d->rank) * al;
   g.w_mbits = d->w_fmt.width - 1;
   if (lowrank) g.bout = make_qp(d->b_out_fmt);
+  if (x_is_i8(d)) {
+    if (!i8_formats_ok(d)) return LQER_E_UNSUPPORTED;
+    g.Kp = (int)padded_k8(d->in_features);  // row stride of the int8 activation image
+    g.i8_shift = !(d->w_fmt.block <= 0 || d->w_fmt.block >= d->in_features);  // one weight block per row: no shifts at all
+    g.w8 = (const uint8_t*)(uintptr_t)1;  // (route query: "the image exists"; lqer_linear_gemm sets the real pointer)
+  }
   return LQER_OK;
 }
 
@@ -362,6 +459,10 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
   g.xq = (const bf16_t*)xq;
   g.wp = (const uint8_t*)w_packed;
   g.xaq = (const bf16_t*)xaq;
+  if (x_is_i8(d)) {
+    g.w8 = (const uint8_t*)w_packed + i8_image_offset(d);
+    g.xscale = i8_row_scales(xq, M, d->in_features);
+  }
   const int al = lowrank ? xa_limbs(d) : 1;
   if (lowrank && !from_partials && (xaq_ld < lqer_padded_r(d->rank) * al || xaq_ld % 8 != 0 || ((uintptr_t)xaq & 15) != 0)) {
     set_error("linear_gemm: xaq row stride %lld (elements) must be a multiple of 8 and at least the padded rank %lld, "
@@ -397,6 +498,13 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   lqer_linear_sizes_t sz;
   int rc = lqer_linear_sizes(d, M, &sz);
   if (rc) return rc;
+  lqer_linear_desc_t plain;
+  if (x_is_i8(d) && lqer_gemm_route(d, M, dtype) != LQER_ROUTE_TILE256_I8) {
+    // token counts the int8 tile kernel does not serve run the bf16 kernels on the sign-magnitude image (same buffers)
+    plain = *d;
+    plain.x_fmt.kind = LQER_Q_MXINT;
+    d = &plain;
+  }
   if (workspace_bytes < sz.workspace || (!workspace && sz.workspace)) {
     set_error("linear_forward: workspace %zu B < %zu B needed for M=%lld", workspace_bytes, sz.workspace, (long long)M);
     return LQER_E_WORKSPACE;

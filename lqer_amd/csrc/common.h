@@ -146,6 +146,32 @@ __device__ __forceinline__ void mxint16_bf16_fast(const float (&v)[16], int e, c
   }
 }
 
+// The int8 image of 16 values that share the exponent e: the signed mantissas themselves (two's complement bytes), same
+// arithmetic as mxint16_bf16_fast without the final scaling.  Needs mbits <= 7 and mxint16_fast_ok(e, q).
+template <bool FLUSH_TINY>
+__device__ __forceinline__ void mxint16_i8_fast(const float (&v)[16], int e, const QP& q, uint32_t (&w)[4]) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  const float s = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
+  const f2 magic = {12582912.0f, 12582912.0f}, eps = {1e-9f, 1e-9f};
+  uint32_t h[8];  // pairs of int16
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f2 x = {v[2 * i], v[2 * i + 1]};
+    const f2 a = {fabsf(x[0]), fabsf(x[1])};
+    const f2 t = a + eps;
+    f2 r = __builtin_elementwise_fma(t, (f2){s, s}, magic) - magic;
+    r[0] = copysignf(fminf(r[0], q.mmax), x[0]);
+    r[1] = copysignf(fminf(r[1], q.mmax), x[1]);
+    if constexpr (FLUSH_TINY) {
+      r[0] = a[0] <= 1e-8f ? 0.0f : r[0];
+      r[1] = a[1] <= 1e-8f ? 0.0f : r[1];
+    }
+    h[i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)r[0], (int)r[1]));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = __builtin_amdgcn_perm(h[2 * i + 1], h[2 * i], 0x06040200u);  // low bytes of the four int16
+}
+
 // bf16 bits of an exactly representable fp32 value (low 16 bits are zero by construction).
 __device__ __forceinline__ uint32_t exact_bf16_bits(float v) { return __float_as_uint(v) >> 16; }
 
@@ -230,6 +256,24 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 
 
+// ---- the int8 route (gemm_w4a8_i8.hip): per-token 8-bit activations x 4-bit weights with blocks of 128 k or more ----------
+// Activation image: int8 mantissas [Mp][Kp8] (Kp8 = K padded to 128) followed, 256-byte aligned, by the row scales
+// fp32 [Mp] - together never larger than the bf16 image [Mp][Kp] they replace in the workspace (K >= 128).
+constexpr int I8_BK = 128;                  // k per main-loop step = per weight-shift group
+constexpr int I8_WBLOCK = 256 * 64 + 256;   // bytes of one (256-row n tile, 128-k step) block: nibbles + one shift byte per row
+__host__ __device__ inline int64_t padded_k8(int64_t K) { return (K + I8_BK - 1) / I8_BK * I8_BK; }
+__host__ inline size_t i8_act_image_bytes(int64_t M, int64_t K) {
+  return ((size_t)lqer_padded_m(M) * padded_k8(K) + 255) / 256 * 256;
+}
+__host__ inline const float* i8_row_scales(const void* xq8, int64_t M, int64_t K) {
+  return (const float*)((const unsigned char*)xq8 + i8_act_image_bytes(M, K));
+}
+// Weight image: per (n tile of 256 rows, step of 128 k) one block of I8_WBLOCK bytes - 256 rows x 64 B of
+// two's-complement nibbles, then 256 shift bytes -, then the row scales fp32 [Np] (gemm_w4a8_i8.hip has the details).
+__host__ inline size_t i8_weight_image_bytes(int64_t N, int64_t K) {
+  return (size_t)(lqer_padded_n(N) / 256) * (padded_k8(K) / I8_BK) * I8_WBLOCK + (size_t)lqer_padded_n(N) * sizeof(float);
+}
+
 // ---- cross-file declarations ----------------------------------------------------------------------
 struct QuantOut {
   float* deq;      // [rows, cols] or null
@@ -238,6 +282,11 @@ struct QuantOut {
   bf16_t* xq;      // [rows_p, cols_p] exact bf16 image or null
   int64_t cols_p;  // row stride of xq (zero-filled beyond cols)
   int64_t nblk;    // blocks per row (exps row stride)
+  // int8 route (one exponent per row, width <= 8): two's-complement mantissas [rows_p][cols_p8] (cols_p8 a multiple of
+  // 128, zero-filled beyond cols) and the row's scale 2^(e - mbits) - value = code * scale
+  int8_t* xq8 = nullptr;
+  int64_t cols_p8 = 0;
+  float* xscale = nullptr;
 };
 
 struct GemmArgs {
@@ -263,6 +312,10 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   float* bout_amax;     // [Mp][bout_nblk] row-block maxima of xAq @ B (B_out blocks other than 16), else null
   int bout_L, bout_nblk;
+  // int8 route: xq holds the int8 activation image (+ row scales), w8 the two's-complement weight image
+  const uint8_t* w8;
+  const float* xscale;  // [Mp] row scales 2^(e - mbits) of the int8 activation image
+  int i8_shift;         // some weight group carries a non-zero shift (blocks of 128 with differing exponents)
 };
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
@@ -290,6 +343,10 @@ size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
 int gemm_route(const GemmArgs& g, bool lowrank);  // LQER_ROUTE_* the dispatch would take (or an error code)
 bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) rounds with 256 x 256 tiles
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
+bool i8_eligible(const GemmArgs& g, int bout);     // gemm_w4a8_i8.hip: the int8 MFMA main loop (g.w8 set, large M)
+int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
+int i8_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, int mbits, void* w_i8, int32_t* flags, hipStream_t st);
+int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 

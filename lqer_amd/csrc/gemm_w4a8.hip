@@ -704,6 +704,16 @@ static int bout_mode(const GemmArgs& g, bool lowrank, int* L_out) {
 int gemm_route(const GemmArgs& g, bool lowrank) {
   const int bout = bout_mode(g, lowrank, nullptr);
   if (bout < 0) return bout;
+  if (g.w8) {  // LQER_Q_MXINT_I8: the int8 kernel or nothing (the caller falls back to LQER_Q_MXINT on the same buffers)
+    GemmArgs t = g;
+    if (bout == 2) {
+      const int L = (g.bout.block <= 0 || g.bout.block >= g.N) ? g.Np : g.bout.block;
+      t.bout_nblk = (g.Np + L - 1) / L;
+    }
+    if (i8_eligible(t, bout)) return LQER_ROUTE_TILE256_I8;
+    t.w8 = nullptr;
+    return gemm_route(t, lowrank);
+  }
   if (smallm_eligible(g, bout)) return LQER_ROUTE_SMALLM;
   if (m256_eligible(g)) return LQER_ROUTE_TILE256;
   return LQER_ROUTE_TILE128;
@@ -738,6 +748,14 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
         k_bout_amax<2><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
       else
         k_bout_amax<1><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
+  }
+  if (g.w8) {  // LQER_Q_MXINT_I8: xq is the int8 image - only the int8 kernel can read it
+    if (!i8_eligible(g, bout)) {
+      set_error("linear_gemm: LQER_Q_MXINT_I8 is not served for M=%d here (lqer_gemm_route != LQER_ROUTE_TILE256_I8): call with "
+                "LQER_Q_MXINT", g.M);
+      return LQER_E_UNSUPPORTED;
+    }
+    return i8_dispatch(g, dtype, lowrank, bout, st);
   }
   if (smallm_eligible(g, bout)) return smallm_dispatch(g, dtype, lowrank, bout, st);  // decode sizes: HBM-bound variant
   if (m256_eligible(g)) return m256_dispatch(g, dtype, lowrank, bout, st);            // large M: 256 x 256 tiles

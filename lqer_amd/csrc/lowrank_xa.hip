@@ -58,8 +58,27 @@ size_t xa_scratch_bytes(int64_t m_max, int64_t K, int64_t rp) {
 // requested one window ahead as well (a_limbs * NT <= 4 fragment sets = 64 registers; used for rank <= 64): without it
 // every 64-k window waits one L2 latency for them, which - not the activation stream - bounds the kernel at large M
 // (16384 x 13824, rank 64, two limbs: 358 -> 326 us for quantizer + side GEMM; no gain at rank 128, where it is off).
-template <int NT, int RG, bool XF16 = false, bool AFPF = false>
-__global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t M, int64_t Kp,
+// XI8: the activation image holds int8 mantissas ([Mp][Kx] bytes, Kx = the image's row stride; one exponent per row, applied
+// to the row's sum by the reduce pass): the lane's 32 bytes of a window are converted to bf16 (integers up to 127: exact).
+__device__ __forceinline__ void i8x32_to_bf16(const u32x4& lo, const u32x4& hi, bf16x8 (&f)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // fragment i = bytes 8i .. 8i+7
+    const uint32_t w0 = i < 2 ? lo[2 * i] : hi[2 * i - 4], w1 = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t w = j ? w1 : w0;
+      const float f0 = (float)(int)(int8_t)(w & 0xff), f1 = (float)(int)(int8_t)((w >> 8) & 0xff);
+      const float f2 = (float)(int)(int8_t)((w >> 16) & 0xff), f3 = (float)(int)(int8_t)(w >> 24);
+      r[2 * j] = (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u);
+      r[2 * j + 1] = (__float_as_uint(f2) >> 16) | (__float_as_uint(f3) & 0xffff0000u);
+    }
+    f[i] = __builtin_bit_cast(bf16x8, r);
+  }
+}
+
+template <int NT, int RG, bool XF16 = false, bool AFPF = false, bool XI8 = false>
+__global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t M, int64_t Kp, int64_t Kx,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
                                                     float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
@@ -77,19 +96,31 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[u][t][j] = 0.f;
-  const bf16_t* xrow[RG];
+  const bf16_t* xrow[RG];  // (XI8: a byte pointer - the lane's 32 consecutive k of a window are 32 bytes)
 #pragma unroll
   for (int u = 0; u < RG; ++u) {
     const int rg = wr * RG + u < plan.row_groups ? wr * RG + u : plan.row_groups - 1;  // a clamped duplicate is not stored
     const int64_t row = (int64_t)rg * XA_ROWS + r;  // rows past M repeat the last one (never read beyond the tensor: the
-    xrow[u] = xq + (row < M ? row : M - 1) * Kp + 32 * h;  // image may be the caller's own fp16 tensor); their results are unused
+    if constexpr (XI8)                              // image may be the caller's own fp16 tensor); their results are unused
+      xrow[u] = (const bf16_t*)((const uint8_t*)xq + (row < M ? row : M - 1) * Kx + 32 * h);
+    else
+      xrow[u] = xq + (row < M ? row : M - 1) * Kx + 32 * h;
   }
   // the next window's activation loads are issued before this window's MFMAs (the stream from HBM is the bound)
-  bf16x8 xn[RG][4];
+  bf16x8 xn[RG][XI8 ? 2 : 4];  // XI8: the raw 32 bytes
+  auto load_x = [&](int64_t k0) {
 #pragma unroll
-  for (int u = 0; u < RG; ++u)
+    for (int u = 0; u < RG; ++u) {
+      if constexpr (XI8) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k_begin + 8 * i);
+        for (int i = 0; i < 2; ++i) xn[u][i] = *(const bf16x8*)((const uint8_t*)xrow[u] + k0 + 16 * i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k0 + 8 * i);
+      }
+    }
+  };
+  load_x(k_begin);
   constexpr int PAIRS = AFPF ? 4 : 1;  // (limb, tile) fragment sets held one window ahead
   constexpr int LMAX = AFPF ? 4 / NT : 1;
   bf16x8 afn[PAIRS][4];
@@ -115,15 +146,15 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
   for (int64_t k0 = k_begin; k0 < k_end; k0 += 64) {
     bf16x8 xf[RG][4];
 #pragma unroll
-    for (int u = 0; u < RG; ++u)
+    for (int u = 0; u < RG; ++u) {
+      if constexpr (XI8) {
+        i8x32_to_bf16(__builtin_bit_cast(u32x4, xn[u][0]), __builtin_bit_cast(u32x4, xn[u][1]), xf[u]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) xf[u][i] = xn[u][i];
-    if (k0 + 64 < k_end) {
-#pragma unroll
-      for (int u = 0; u < RG; ++u)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k0 + 64 + 8 * i);
+        for (int i = 0; i < 4; ++i) xf[u][i] = xn[u][i];
+      }
     }
+    if (k0 + 64 < k_end) load_x(k0 + 64);
     if constexpr (AFPF) {
       bf16x8 afc[PAIRS][4];
 #pragma unroll
@@ -185,7 +216,7 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
 // lanes of a block (G a power of two <= 64, lanes of one wave) share their max through xor-shuffles.
 template <int G>
 __global__ __launch_bounds__(256) void k_xa_reduce4(const float* __restrict__ part, XaPlan plan, int rp, QP q,
-                                                    bf16_t* __restrict__ xaq) {
+                                                    bf16_t* __restrict__ xaq, const float* __restrict__ rowscale = nullptr) {
   const int64_t total = (int64_t)plan.row_groups * XA_ROWS * rp / 4;  // float4 items (rp/4 per row, a multiple of G)
   const int64_t chunk_stride = (int64_t)plan.row_groups * XA_ROWS * rp;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -206,6 +237,10 @@ __global__ __launch_bounds__(256) void k_xa_reduce4(const float* __restrict__ pa
       const float4 v = *(const float4*)(src + c * chunk_stride);
       s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
     }
+  }
+  if (rowscale && live) {  // int8 activation image: the sums are of mantissas, the row's power-of-two scale comes last (exact)
+    const float sc = rowscale[idx / (rp / 4)];
+    s.x *= sc, s.y *= sc, s.z *= sc, s.w *= sc;
   }
   float amax = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w)));
 #pragma unroll
@@ -230,7 +265,7 @@ __global__ __launch_bounds__(256) void k_xa_reduce4(const float* __restrict__ pa
 // 11 (fp16 tensors) or 8 (bf16) here -, all 24 with three); B^T is repeated LA times along r to match.
 template <int LA>
 __global__ __launch_bounds__(256) void k_xa_reduce_limbs(const float* __restrict__ part, XaPlan plan, int rp,
-                                                         bf16_t* __restrict__ xaq) {
+                                                         bf16_t* __restrict__ xaq, const float* __restrict__ rowscale = nullptr) {
   const int64_t total = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
   const int64_t chunk_stride = (int64_t)plan.row_groups * XA_ROWS * rp;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -252,7 +287,8 @@ __global__ __launch_bounds__(256) void k_xa_reduce_limbs(const float* __restrict
   const int rq = rp / 4;
   const int64_t row = idx / rq;
   const int n0 = (int)(idx - row * rq) * 4;
-  float v[4] = {s.x, s.y, s.z, s.w};
+  const float sc = rowscale ? rowscale[row] : 1.0f;
+  float v[4] = {s.x * sc, s.y * sc, s.z * sc, s.w * sc};
 #pragma unroll
   for (int l = 0; l < LA; ++l) {
     uint32_t w[2];
@@ -269,7 +305,7 @@ __global__ __launch_bounds__(256) void k_xa_reduce_limbs(const float* __restrict
 
 // Generic block length (not 4 * 2^g): one lane per block, serial.
 __global__ __launch_bounds__(256) void k_xa_reduce_blk(const float* __restrict__ part, XaPlan plan, int rp, QP q,
-                                                       bf16_t* __restrict__ xaq) {
+                                                       bf16_t* __restrict__ xaq, const float* __restrict__ rowscale = nullptr) {
   const int L = (q.block <= 0 || q.block >= rp) ? rp : q.block;
   const int nb = rp / L;
   const int64_t total = (int64_t)plan.row_groups * XA_ROWS * nb;
@@ -279,17 +315,19 @@ __global__ __launch_bounds__(256) void k_xa_reduce_blk(const float* __restrict__
     const int b0 = (int)(idx - row * nb) * L;
     const float* src = part + row * rp + b0;
     bf16_t* dst = xaq + row * rp + b0;
+    const float sc = rowscale ? rowscale[row] : 1.0f;
     float amax = 0.f;
     for (int k = 0; k < L; ++k) {
       float sum = src[k];
       for (int c = 1; c < plan.nchunk; ++c) sum += src[c * chunk_stride + k];
-      amax = fmaxf(amax, fabsf(sum));
+      amax = fmaxf(amax, fabsf(sum * sc));
     }
     const bool any = amax > 0.f;
     const int e = any ? block_exponent(amax, q) : 0;
     for (int k = 0; k < L; ++k) {
       float sum = src[k];
       for (int c = 1; c < plan.nchunk; ++c) sum += src[c * chunk_stride + k];
+      sum *= sc;
       const float mv = any ? mxint_mantissa(sum, e, q) : 0.f;
       dst[k] = (bf16_t)exact_bf16_bits(ldexpf(mv, e - q.mbits));
     }
@@ -505,11 +543,16 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
 // x_limbs: the activation image holds that many bf16 limbs side by side ([Mp][x_limbs * Kp], act_limbs.hip) and a_t
 // is repeated as often along k; xa_limbs: limbs of the result when A_out is a pass-through (0 otherwise).
 // x_limbs = 0: xq holds fp16 bits and a_t is ONE fp16 image [rp][Kp] (pack.hip::a_f16_dispatch) - v_mfma_*_f16.
+// x_limbs = -1: xq holds int8 mantissas [Mp][lqer_padded_k8(K)] with the row scales behind them (the int8 route).
 int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, const bf16_t* a_t, int a_limbs, int64_t r,
                         const QP& q, int xa_limbs, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st) {
   const bool x_f16 = x_limbs == 0;
+  const bool x_i8 = x_limbs == -1;
   if (x_f16) x_limbs = 1, a_limbs = 1;
+  if (x_i8) x_limbs = 1;
   const int64_t Kp = lqer_padded_k(K) * x_limbs;
+  const int64_t Kx = x_i8 ? padded_k8(K) : Kp;  // row stride of the activation image (elements)
+  const float* rowscale = x_i8 ? i8_row_scales(xq, M, K) : nullptr;
   const int rp = (int)lqer_padded_r(r);
   const bool pass = q.kind == LQER_Q_PASSTHROUGH;
   if (pass ? (xa_limbs != 2 && xa_limbs != 3) : (q.kind != LQER_Q_MXINT || q.mbits > 8)) {
@@ -542,13 +585,17 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
   case NT:                                                                                                   \
     if (NT <= 2 && a_limbs * NT <= 4 && plan.kc > 64) { /* A^T fragments one window ahead */                 \
       if (x_f16)                                                                                             \
-        k_xa_partial<NT, RG, true, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);  \
+        k_xa_partial<NT, RG, true, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch);  \
+      else if (x_i8)                                                                                         \
+        k_xa_partial<NT, RG, false, (NT <= 2), true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
       else                                                                                                   \
-        k_xa_partial<NT, RG, false, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch); \
+        k_xa_partial<NT, RG, false, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
     } else if (x_f16)                                                                                        \
-      k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);          \
+      k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch);      \
+    else if (x_i8)                                                                                           \
+      k_xa_partial<NT, RG, false, false, true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
     else                                                                                                     \
-      k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, M, Kp, a_t, a_limbs, rp, plan, scratch);                \
+      k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch);            \
     break;
   switch (nt) {
     XA_CASE(1, 2) XA_CASE(2, 2) XA_CASE(3, 2) XA_CASE(4, 2) XA_CASE(5, 1) XA_CASE(6, 1) XA_CASE(7, 1) XA_CASE(8, 1)
@@ -559,25 +606,25 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
     const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
     const unsigned grid2 = (unsigned)((items + 255) / 256);
     if (xa_limbs == 2)
-      k_xa_reduce_limbs<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq);
+      k_xa_reduce_limbs<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq, rowscale);
     else
-      k_xa_reduce_limbs<3><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq);
+      k_xa_reduce_limbs<3><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq, rowscale);
   } else if (L % 4 == 0 && (G & (G - 1)) == 0 && G <= 64) {
     const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
     const unsigned grid2 = (unsigned)((items + 255) / 256);
     switch (G) {
-      case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
-      case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
-      case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
-      case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
-      case 16: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
-      case 32: k_xa_reduce4<32><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
-      default: k_xa_reduce4<64><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq); break;
+      case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
+      case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
+      case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
+      case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
+      case 16: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
+      case 32: k_xa_reduce4<32><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
+      default: k_xa_reduce4<64><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
     }
   } else {
     const int64_t total = (int64_t)plan.row_groups * XA_ROWS * (rp / L);
     const unsigned grid2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    k_xa_reduce_blk<<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq);
+    k_xa_reduce_blk<<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale);
   }
   return check_launch("lowrank_xa");
 }

@@ -59,9 +59,23 @@ __device__ __forceinline__ void emit16(const float (&v)[16], bool any, int e, co
     dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
     return;
   }
+  if (o.xq8 && !o.xq && !o.deq && !o.codes && any && mxint16_fast_ok(e, q)) {  // the int8 image alone: packed-fp32 route
+    uint32_t w[4];
+    mxint16_i8_fast<true>(v, e, q, w);
+    *(uint4*)(o.xq8 + row * o.cols_p8 + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+    return;
+  }
   float m[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) m[i] = any ? mxint_mantissa(v[i], e, q) : 0.0f;
+  if (o.xq8) {  // the int8 image: 16 two's-complement mantissas = one 16-byte store
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = ((uint32_t)(int)m[4 * i] & 0xffu) | (((uint32_t)(int)m[4 * i + 1] & 0xffu) << 8) |
+             (((uint32_t)(int)m[4 * i + 2] & 0xffu) << 16) | (((uint32_t)(int)m[4 * i + 3] & 0xffu) << 24);
+    *(uint4*)(o.xq8 + row * o.cols_p8 + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
   if (o.xq) {
     uint32_t w[8];
 #pragma unroll
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(256) void k_quant_row(const void* __restrict__ x, i
                                                    QP q, QuantOut o, bool vec) {
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
-  const int64_t segs = o.xq ? o.cols_p / 16 : (cols + 15) / 16;
+  const int64_t segs = o.xq8 ? o.cols_p8 / 16 : (o.xq ? o.cols_p / 16 : (cols + 15) / 16);
   const bool keep = segs <= 256 * QR_KEEP;
   float v[QR_KEEP][16];
   float amax = 0.0f;
@@ -162,6 +176,7 @@ __global__ __launch_bounds__(256) void k_quant_row(const void* __restrict__ x, i
     }
   }
   if (o.exps && threadIdx.x == 0) o.exps[row * o.nblk] = (int8_t)(e > 127 ? 127 : e);
+  if (o.xscale && threadIdx.x == 0) o.xscale[row] = any ? ldexpf(1.0f, e - q.mbits) : 1.0f;
 }
 
 // One lane per block of L elements (L a multiple of 16), serial.

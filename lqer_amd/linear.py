@@ -51,6 +51,8 @@ class _LinearBase(nn.Linear):
         self._fw_cache = {}        # token count -> (descriptor, workspace bytes)
         self._x_f16 = False        # pass-through fp16 activations on the fp16 MFMA route (decided when the images are built)
         self.a16_native = True     # False: keep pass-through fp16 activations on the bf16-limb route
+        self._x_i8 = False         # per-token 8-bit activations on the int8 MFMA route (decided when the images are built)
+        self.a8_native = True      # False: keep them on the bf16 route
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
 
@@ -65,8 +67,8 @@ class _LinearBase(nn.Linear):
     def rank(self) -> int:
         return 0
 
-    def _desc(self) -> LinearDesc:
-        """The C descriptor.  Pass-through x / A_out formats (the *-int.toml templates) carry the number of significand
+    def _desc(self, plain: bool = False) -> LinearDesc:
+        """The C descriptor (plain = True: the bf16-route descriptor of a Linear whose images also serve the int8 route).  Pass-through x / A_out formats (the *-int.toml templates) carry the number of significand
         bits the HIP path must preserve: those of the module's dtype for x (8 bf16, 11 fp16, 24 fp32 = 1, 2, 3 bf16
         limbs), 16 for x A under a 16-bit dtype (the reference keeps 11 or 8 there), 24 under fp32."""
         f = self._fmt
@@ -79,6 +81,8 @@ class _LinearBase(nn.Linear):
             q = f.get(role, none)
             if q.kind == _lib.Q_PASSTHROUGH and role == "x" and self._x_f16:
                 return QFmt(_lib.Q_PASSTHROUGH_F16, bits, q.block, q.exp_width, q.exp_bias)
+            if q.kind == _lib.Q_MXINT and role == "x" and self._x_i8 and not plain:
+                return QFmt(_lib.Q_MXINT_I8, q.width, q.block, q.exp_width, q.exp_bias)
             return QFmt(q.kind, bits, q.block, q.exp_width, q.exp_bias) if q.kind == _lib.Q_PASSTHROUGH else q
 
         return LinearDesc(self.in_features, self.out_features, self.rank, int(self.bias is not None),
@@ -95,7 +99,18 @@ class _LinearBase(nn.Linear):
         is then the fp16 tensor itself, A one fp16 image, one copy of W); otherwise, and for bf16 / fp32 tensors, the
         activation is split into bf16 limbs and the images are repeated once per limb."""
         self._x_f16 = False
+        self._x_i8 = False
         self._fw_cache = {}
+        fx, fw, K = self._fmt["x"], self._fmt["w"], self.in_features
+        if (self.a8_native and fx.kind == _lib.Q_MXINT and fx.width <= 8 and (fx.block <= 0 or fx.block >= K) and K >= 128
+                and (fw.block <= 0 or fw.block >= K or fw.block % 128 == 0)):
+            # one activation exponent per token, weight blocks of 128 k or more (the W4A8 INT configurations): integer
+            # accumulation is exact - the int8 MFMA route, if every weight row's sums provably stay inside i32
+            ok, w2 = ops.i8_prepare(p["w"], self.out_features, K, fw)
+            if ok:
+                self._x_i8 = True
+                p = dict(p)
+                p["w"] = w2
         if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native):
             ok, a16 = ops.f16_prepare(p["w"], self.out_features, self.in_features, p.get("a_t"), int(p.get("a_limbs", 0)), self.rank)
             if ok:
@@ -126,6 +141,8 @@ class _LinearBase(nn.Linear):
         if name == "a_t" and "a_t_limbs" in self._packed:  # fp16 route: the limb image is kept next to the fp16 one
             return self._packed["a_t_limbs"].reshape(-1).view(torch.uint8)
         flat = self._packed[name].reshape(-1).view(torch.uint8)
+        if name == "w" and self._x_i8:  # the int8 route's second image lies behind the sign-magnitude one
+            return flat[: rows * rb]
         return flat if c == 1 else flat.view(rows, c, rb)[:, 0].contiguous().reshape(-1)
 
     def __getstate__(self):
@@ -142,6 +159,7 @@ class _LinearBase(nn.Linear):
         self._packed = None
         self._fw_cache = {}
         self._x_f16 = False
+        self._x_i8 = False
         if weight_changed:
             self._w_single = None
             if self.is_ptq:
@@ -426,8 +444,14 @@ class SharedActivation:
         ver = None if x.is_inference() else x._version
         idx = self.members.index(mod)
         fresh = not (x is self._x and ver == self._ver and self._cur is not None and self._cur["M"] == M and idx not in self._served)
+        # members on the int8 route (per-token activations): the shared image is int8 only if every member's GEMM takes the
+        # int8 kernel at this token count, else everybody uses the bf16 image
+        i8 = all(m._x_i8 for m in self.members)
+        if i8:
+            dtc = ops.dtype_code(x2)
+            i8 = all(L.lqer_gemm_route(C.byref(m._desc()), M, dtc) == _lib.ROUTE_TILE256_I8 for m in self.members)
         if fresh:
-            gdesc = m0._desc()
+            gdesc = m0._desc(plain=not i8)
             gdesc.rank = self._cat["rp_total"]
             gdesc.a_out_fmt.block = self._aout_block  # (one block per member row -> blocks of a member's rank)
             Mp, Kp = L.lqer_padded_m(M), L.lqer_padded_k(K)
@@ -448,7 +472,7 @@ class SharedActivation:
         if len(self._served) == len(self.members):
             self._x = None  # every member has been served: do not pin the activation tensor until the next call
         off = self._cat["offs"][idx]
-        desc = mod._desc()
+        desc = mod._desc(plain=not i8)
         p = mod._packed
         gs = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
         scr = ops.workspace(dev, max(gs, 16))

@@ -183,6 +183,48 @@ def f16_prepare(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: Optional[torc
     return (fl[0] == 0 and fl[1] == 0), a16
 
 
+@_on_tensor_device
+def i8_prepare(w_packed: torch.Tensor, N: int, K: int, w_fmt: QFmt):
+    """Eligibility of the int8 MFMA route (include/lqer_hip.h "int8 route") for one packed weight: returns (ok, buffer) -
+    `buffer` holds the sign-magnitude image followed by the int8 main loop's image; ok is False when some row's integer
+    sums could leave the i32 range (the caller keeps the plain image).  Synchronises."""
+    _need_gpu(w_packed)
+    L = _lib.lib()
+    dev = w_packed.device
+    none = QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
+    desc = LinearDesc(K, N, 0, 0, QFmt(_lib.Q_MXINT_I8, 8, -1, 8, 127), w_fmt, none, none, none)
+    sz = linear_sizes(desc, 1)
+    buf = torch.zeros(sz.w_packed, dtype=torch.uint8, device=dev)
+    flat = w_packed.reshape(-1).view(torch.uint8)
+    buf[: flat.numel()] = flat
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    check(L.lqer_i8_prepare(buf.data_ptr(), N, K, C.byref(w_fmt), flags.data_ptr(), _stream(dev)), "lqer_i8_prepare")
+    return flags.tolist()[0] == 0, buf
+
+
+@_on_tensor_device
+def unpack_weight_i8(w_packed: torch.Tensor, N: int, K: int) -> torch.Tensor:
+    """Test hook: the int8 route's weight image (inside the buffer of i8_prepare) -> dequantized fp32 [N, K]."""
+    _need_gpu(w_packed)
+    out = torch.empty(N, K, dtype=torch.float32, device=w_packed.device)
+    check(_lib.lib().lqer_unpack_weight_i8(w_packed.data_ptr(), N, K, out.data_ptr(), _stream(w_packed.device)), "lqer_unpack_weight_i8")
+    return out
+
+
+@_on_tensor_device
+def quantize_act_i8(x2: torch.Tensor, fmt: QFmt):
+    """Test hook: x [M, K] -> (int8 mantissas [Mp, K padded to 128], row scales fp32 [Mp]) of the int8 route's image."""
+    _need_gpu(x2)
+    M, K = x2.shape
+    L = _lib.lib()
+    Mp, Kp8 = L.lqer_padded_m(M), -(-K // 128) * 128
+    img = (Mp * Kp8 + 255) // 256 * 256
+    buf = torch.zeros(img + Mp * 4, dtype=torch.uint8, device=x2.device)
+    check(L.lqer_quantize_act_i8(x2.data_ptr(), dtype_code(x2), M, K, x2.stride(0) if M > 1 else K, C.byref(fmt), buf.data_ptr(),
+                                 _stream(x2.device)), "lqer_quantize_act_i8")
+    return buf[: Mp * Kp8].view(torch.int8).view(Mp, Kp8), buf[img:].view(torch.float32)
+
+
 def desc_limbs(desc: LinearDesc) -> Tuple[int, int]:
     """(bf16 limbs of the activation image, of the x A image): 1, 1 unless x / A_out are pass-through."""
     a, b = C.c_int(1), C.c_int(1)

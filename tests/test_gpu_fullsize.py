@@ -49,6 +49,8 @@ def _run(lq, M, K, N, r, qc, bias, quantize_ab, seed, tol=1e-3, route=None):
     y = mod(xin.to(DEV))
     assert y.shape == (M, N) and torch.isfinite(y).all()
     if route is not None:  # the kernel the bench times at this shape
+        if mod._x_i8 and route == "TILE256":
+            route = "TILE256_I8"
         assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16) == getattr(_lib, "ROUTE_" + route)
     idx = _rows(M)
     got = y[idx.to(DEV)].float().cpu()
@@ -81,7 +83,8 @@ def test_c4_int_rank64_full_size(lq, K, N, wblock):
     from bench import INT_Q, _bfp
 
     qc = dict(INT_Q, w_quantizer=_bfp(4, [1, wblock], False))
-    _run(lq, 16384, K, N, 64, qc, False, False, seed=41, route="TILE256")
+    mod, _ = _run(lq, 16384, K, N, 64, qc, False, False, seed=41, route="TILE256")
+    assert mod._x_i8  # the int8 main loop
 
 
 # C2 / C3: Llama-7B shapes at the bench's M = 2048, rank 32, MXINT blocks of 16.

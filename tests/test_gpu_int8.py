@@ -1,0 +1,193 @@
+"""The int8 MFMA route (lqer_amd/csrc/gemm_w4a8_i8.hip; include/lqer_hip.h "int8 route"): per-token 8-bit activations
+x 4-bit weights in blocks of 128 k or one block per row - the "W4A8 INT" configurations (reference
+experiments/pipeline/sweep_lqer_act_int.sh:83, experiments/configs/template/llama-7b-int.toml:87).
+Bit-exact checks of the two integer images, forward parity against the CPU oracle and against the bf16 route.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lqer_oracle as O  # the checker
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import lqer_amd
+
+    return lqer_amd
+
+
+def _wfmt(ops, block):
+    return ops.make_qfmt(dict(name="block_fp", width=4, exponent_width=8, exponent_bias=None, block_size=[1, block], skip_first_dim=False), "w")
+
+
+@pytest.mark.parametrize("N,K,block", [(256, 512, 128), (300, 1000, 128), (64, 200, -1), (512, 384, 256), (700, 128, 128)])
+def test_int8_weight_image_bit_exact(lq, N, K, block):
+    """The second weight image (two's-complement nibbles + per-group shifts + row scales) dequantizes to exactly what the
+    sign-magnitude image does, i.e. to w_quantizer(W) (block_fp.py:7-82), ragged N / K included; exponents that vary from
+    group to group exercise the shifts."""
+    from lqer_amd import ops
+
+    g = torch.Generator().manual_seed(N + K)
+    W = 0.02 * torch.randn(N, K, generator=g)
+    W *= 2.0 ** torch.randint(-2, 3, (N, -(-K // 128)), generator=g).float().repeat_interleave(128, dim=1)[:, :K]  # shifts 0..4
+    W[5] = 0.0           # an all-zero row
+    W[7, :128] = 0.0     # an all-zero group
+    fmt = _wfmt(ops, block)
+    packed = ops.pack_weight(W.to(DEV), fmt)
+    ok, buf = ops.i8_prepare(packed, N, K, fmt)
+    assert ok
+    got = ops.unpack_weight_i8(buf, N, K).cpu()
+    sm = ops.unpack_weight(packed, N, K, fmt).cpu()
+    assert torch.equal(got, sm)
+    ref = O.get_quantizer(dict(name="block_fp", width=4, exponent_width=8, exponent_bias=None, block_size=[1, block], skip_first_dim=False))(W)
+    assert torch.equal(got, torch.where(W.abs() <= 1e-8, torch.zeros_like(ref), ref))
+    assert torch.equal(buf[: packed.numel()].cpu(), packed.cpu())  # the first image is untouched
+
+
+def test_int8_weight_image_refuses_what_i32_cannot_hold(lq):
+    """A row whose group exponents span 2^21 could overflow the integer accumulator: lqer_i8_prepare must say so, and the
+    module must then stay on the bf16 route (and stay exact).  Weight blocks shorter than 128 are refused by format."""
+    from bench import INT_Q, make_case
+    from lqer_amd import _lib, ops
+
+    M, K, N, r = 600, 512, 512, 16
+    x, W, A, B = make_case(M, K, N, r, seed=2, quantize_ab=False)
+    W[3, :128] *= 2.0 ** 22
+    fmt = _wfmt(ops, 128)
+    ok, _ = ops.i8_prepare(ops.pack_weight(W.to(DEV), fmt), N, K, fmt)
+    assert not ok
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=INT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV)
+    y = mod(x.to(DEV)).cpu()
+    assert not mod._x_i8
+    ref = O.lqer_linear_forward(x, W, None, A, B, INT_Q)
+    assert (y - ref).norm() / ref.norm() <= 2e-5
+    with pytest.raises(_lib.LqerHipError):
+        ops.i8_prepare(ops.pack_weight(W.to(DEV), _wfmt(ops, 16)), N, K, _wfmt(ops, 16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+def test_int8_activation_image_bit_exact(lq, dtype):
+    """mantissa * row scale == x_quantizer(x) for one block per row (block_fp.py:7-82), K padding zero."""
+    from lqer_amd import ops
+
+    torch.manual_seed(5)
+    for M, K in ((5, 200), (300, 4096), (1, 128)):
+        x = (torch.randn(M, K) * 3).to(dtype)
+        x[:, 3] *= 30
+        if M > 2:
+            x[2] = 0  # an all-zero row
+        fmt = ops.make_qfmt(dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[1, -1], skip_first_dim=True), "x")
+        codes, scales = ops.quantize_act_i8(x.to(DEV), fmt)
+        codes, scales = codes.cpu(), scales.cpu()
+        ref = O.mxint_quantize(x.float(), width=8, block_size=[1, -1], skip_first_dim=True)
+        assert torch.equal(codes[:M, :K].float() * scales[:M, None], ref)
+        assert not codes[:M, K:].any() and codes.shape[1] % 128 == 0 and int(codes.abs().max()) <= 127
+
+
+def _mod(lq, K, N, r, qc, bias, seed, dtype, M):
+    from bench import make_case
+
+    case = make_case(M, K, N, r, seed=seed, bias=bias, quantize_ab=False)
+    x, W, A, B = case[:4]
+    b = case[4] if bias else None
+    mod = lq.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = b
+    mod.load_state_dict(sd)
+    return mod.to(DEV).to(dtype), x, W, A, B, b
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 5e-3)])
+@pytest.mark.parametrize("M,K,N,r,wblock,bias", [(2048, 512, 8192, 64, 128, False), (2304, 200, 8000, 32, -1, True),
+                                                 (4096, 1000, 4352, 16, 128, False), (2100, 384, 8192, 128, 256, True)])
+def test_int8_route_forward_vs_oracle_and_bf16_route(lq, dtype, tol, M, K, N, r, wblock, bias):
+    """The int8 kernel (asserted through lqer_gemm_route) against the CPU oracle, and against the SAME module on the bf16
+    route: both multiply the same exact operands, so they may differ only by fp32 summation order."""
+    from bench import INT_Q, _bfp
+    from lqer_amd import _lib
+
+    qc = dict(INT_Q, w_quantizer=_bfp(4, [1, wblock], False), b_quantizer=_bfp(8, [-1], False))
+    mod, x, W, A, B, b = _mod(lq, K, N, r, qc, bias, seed=M + K, dtype=dtype, M=M)
+    xin = x.to(dtype)
+    y = mod(xin.to(DEV))
+    assert mod._x_i8 and y.dtype == dtype
+    L = _lib.lib()
+    assert L.lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16 if dtype != torch.float32 else _lib.F32) == _lib.ROUTE_TILE256_I8
+    assert L.lqer_gemm_route(C.byref(mod._desc()), 40, _lib.F16) != _lib.ROUTE_TILE256_I8  # small token counts keep the bf16 kernels
+    cast = lambda t: None if t is None else t.to(dtype).float()
+    ref = O.lqer_linear_forward(xin.float(), cast(W), cast(b), cast(A), cast(B), qc)
+    err = float((y.float().cpu() - ref).norm() / ref.norm())
+    assert err <= tol, err
+    mod.a8_native = False
+    mod.invalidate_packed()
+    y2 = mod(xin.to(DEV))
+    assert not mod._x_i8
+    d = float((y.float() - y2.float()).norm() / y2.float().norm())
+    assert d <= (1e-6 if dtype == torch.float32 else tol / 4), d
+    if dtype != torch.float32:  # 16-bit outputs: the two routes round the same fp32 sums - almost every element identical
+        assert float((y != y2).float().mean()) <= 0.01
+    # rows are independent: a slice that runs the small tiles of the bf16 route gives the bf16 route's bits
+    mod.a8_native = True
+    mod.invalidate_packed()
+    y3 = mod(xin[:100].to(DEV))
+    assert mod._x_i8 and torch.equal(y3, y2[:100])
+
+
+def test_int8_route_run_to_run_bit_stability(lq):
+    """Race screen of the new main loop (loads in flight across barriers, hand-counted waits): 20 launches, same bits."""
+    from bench import INT_Q
+
+    for (M, K, N, r) in ((2048, 1280, 8192, 64), (2304, 640, 8192, 32)):
+        mod, x, *_ = _mod(lq, K, N, r, INT_Q, False, seed=3, dtype=torch.float16, M=M)
+        xd = x.half().to(DEV)
+        y0 = mod(xd).clone()
+        assert mod._x_i8
+        for _ in range(20):
+            assert torch.equal(mod(xd), y0), (M, K, N)
+        perm = torch.randperm(M, device=DEV)
+        assert torch.equal(mod(xd[perm]), y0[perm])
+
+
+def test_int8_route_shared_qkv_and_checkpoint(lq, tmp_path):
+    """q/k/v handed the same tensor share ONE int8 activation image; a packed checkpoint stores only the sign-magnitude
+    image and rebuilds the int8 one at load."""
+    from bench import INT_Q, make_case
+    from lqer_amd.linear import SharedActivation
+
+    M, K, r = 2048, 512, 64
+    mods = []
+    for i, N in enumerate((8192, 8192, 8192)):
+        x, W, A, B = make_case(M, K, N, r, seed=60 + i, quantize_ab=False)
+        m = lq.LinearFlexibleLqer(K, N, bias=False, q_config=INT_Q, l_config={"rank": r})
+        m.load_state_dict({"weight": W, "A": A, "B": B})
+        mods.append(m.to(DEV).half())
+    xd = x.half().to(DEV)
+    alone = [m(xd).clone() for m in mods]
+    assert all(m._x_i8 for m in mods)
+    grp = SharedActivation(mods)
+    assert grp.enabled
+    with torch.no_grad():
+        got = [m(xd) for m in mods]
+    for a, g in zip(alone, got):
+        assert (a.float() - g.float()).norm() / a.float().norm() <= 2e-3
+    small = [m(xd[:50]) for m in mods]  # the group at a size the int8 kernel does not serve: bf16 image for everybody
+    for a, g in zip(alone, small):
+        assert (a[:50].float() - g.float()).norm() / a[:50].float().norm() <= 2e-3
+    st = mods[0].packed_state()
+    Kp, Np = 512, 8192
+    assert st["w"].numel() == (Np // 16) * (Kp // 64) * 576
+    m2 = lq.LinearFlexibleLqer(K, 8192, bias=False, q_config=INT_Q, l_config={"rank": r}).half()
+    m2.load_packed_state({k: v.cpu() for k, v in st.items()}, DEV)
+    m2 = m2.to(DEV)
+    assert torch.equal(m2(xd), alone[0]) and m2._x_i8

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""The int8 main loop against the bf16 256-row kernel on the SAME Linear (W4, per-token A8, rank r, fp16 A / B, per-row
+B_out: the C4 configuration), interleaved rounds in one process: lqer_linear_gemm alone (activation images prepared
+once per route), and the whole forward (quantizer + side GEMM + pre-pass + GEMM).
+usage: python tools/ab_i8.py [--M 16384 --K 5120 --N 5120 --r 64 --wblock 128] [--rounds 8 --iters 10]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lqer_amd  # noqa: E402
+from bench import INT_Q, _bfp, make_case  # noqa: E402
+from lqer_amd import _lib, ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--M", type=int, default=16384)
+    ap.add_argument("--K", type=int, default=5120)
+    ap.add_argument("--N", type=int, default=5120)
+    ap.add_argument("--r", type=int, default=64)
+    ap.add_argument("--wblock", type=int, default=128)
+    ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    M, K, N, r = a.M, a.K, a.N, a.r
+    qc = dict(INT_Q, w_quantizer=_bfp(4, [1, a.wblock], False))
+    x, W, A, B = make_case(M, K, N, r, seed=0, quantize_ab=False)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(dev).half()
+    xd = x.half().to(dev)
+    y = mod(xd)
+    assert mod._x_i8, "the weight is not eligible for the int8 route"
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    p = mod._packed
+    Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
+    routes = {}
+    for name, desc in (("int8", mod._desc()), ("bf16", mod._desc(plain=True))):
+        ws = torch.empty(ops.linear_sizes(desc, M).workspace, dtype=torch.uint8, device=dev)
+        xq = ws.data_ptr()
+        xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256
+        scr = xaq + ((Mp * rp * 2 + 255) // 256) * 256
+        nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
+        gscr = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+        routes[name] = dict(desc=desc, ws=ws, xq=xq, xaq=xaq, scr=scr, nscr=nscr, gscr=gscr, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16))
+
+    def quant(rt):
+        _lib.check(L.lqer_quantize_act_xa(C.byref(rt["desc"]), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], rt["xq"],
+                                          rt["xaq"], rt["scr"], rt["nscr"], st), "quantize_act_xa")
+
+    def gemm(rt):
+        _lib.check(L.lqer_linear_gemm(C.byref(rt["desc"]), rt["xq"], M, p["w"].data_ptr(), rt["xaq"], p["b_t"].data_ptr(), p["b_limbs"],
+                                      None, y.data_ptr(), _lib.F16, N, rt["scr"], rt["gscr"], st), "linear_gemm")
+
+    print("routes:", {k: v["route"] for k, v in routes.items()}, "(3 = int8 tile kernel, 2 = bf16 256-row kernel)")
+    outs = {}
+    for name, rt in routes.items():
+        quant(rt)
+        gemm(rt)
+        torch.cuda.synchronize()
+        outs[name] = y.clone()
+    d = (outs["int8"].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
+    print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs['int8'] != outs['bf16']).float().mean()):.2e}")
+    fl = 2.0 * M * K * N + 2.0 * M * r * N
+    for what, fn in (("GEMM alone (incl. B_out pre-pass)", lambda rt: gemm(rt)), ("whole forward", lambda rt: (quant(rt), gemm(rt)))):
+        times = {k: [] for k in routes}
+        for _ in range(a.rounds):
+            for name, rt in routes.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    fn(rt)
+                e1.record()
+                torch.cuda.synchronize()
+                times[name].append(e0.elapsed_time(e1) / a.iters * 1e3)
+        for name in routes:
+            t = sorted(times[name])
+            med = t[len(t) // 2]
+            print(f"{what:36s} {name:5s} median {med:9.1f} us  min {t[0]:9.1f} us   {fl / med / 1e6:8.1f} T(FL)OP/s")
+
+
+if __name__ == "__main__":
+    main()
