@@ -39,17 +39,27 @@ constexpr int OFF_A = 0;
 constexpr int OFF_W = NSLOT * A_SLOT;
 constexpr int GEMM_LDS = OFF_W + NSLOT * W_SLOT;  // 148224 B
 // epilogue regions (the ring is free then)
-constexpr int EP_STAGE = 0;              // xAq tile: up to two 64-column panels of 32 KiB
-constexpr int EP_TAB = 65536;            // x row scales fp32 [256], B_out row exponents int [256]
-constexpr int EP_OUT = EP_TAB + 2048;    // per wave: 64 rows x 80 B (32 fp16 columns + pad)
+constexpr int EP_STAGE = 0;              // xAq tile: up to two 64-column panels of 32 KiB (filled by LDS-DMA)
+constexpr int EP_OUT = 65536;            // per wave: 64 rows x 80 B (32 fp16 columns + pad)
 constexpr int EP_OUT_WAVE = 64 * 80;
 static_assert(EP_OUT + 8 * EP_OUT_WAVE <= GEMM_LDS, "epilogue regions exceed the ring");
+// behind the ring, written at the start of the kernel: per-row constants of the epilogue - the x row scales, the B_out
+// scales 2^(mbits - e[m]) and 2^(e[m] - mbits) - fp32 [256] each
+constexpr int EP_TAB = GEMM_LDS;
+constexpr int KERNEL_LDS = GEMM_LDS + 3 * 1024;
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+#ifdef LQER_CLOCKPROBE
+// diagnostic build (tools/clock_probe_i8.py): shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) at the start of the
+// kernel, around the main loop and at the end, written to a buffer nothing else reads
+__device__ unsigned long long* g_i8_stamp_buf = nullptr;
+#define I8_STAMP(c, r) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory")
+#endif
 
 // ---- weight image ---------------------------------------------------------------------------------------------------
 // Block (n tile tn, step s) at (tn * nk8 + s) * I8_WBLOCK: 256 rows x 64 B of nibbles, then 256 shift bytes.  A row's
@@ -177,6 +187,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
+#ifdef LQER_CLOCKPROBE
+  unsigned long long cp_c[4], cp_r[4], cp_e1 = 0, cp_e1r = 0, cp_e2 = 0, cp_e2r = 0;
+  I8_STAMP(cp_c[0], cp_r[0]);
+#endif
 
   const int nt = g.tiles_m * g.tiles_n;
   int tile;
@@ -245,8 +259,29 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + slot * W_SLOT + 256 * 64), 4, s_voff, kt * I8_WBLOCK,
                                                0, 0);
   };
+  // per-row constants of the epilogue: requested now, written to LDS (asm: invisible to hipcc's waitcnt pass, which would
+  // drain the ring fill in front of a visible LDS store) once the ring fill has been issued
+  float t_xs = 0.f, t_amax = 0.f;
+  if (tid < 256) {
+    t_xs = g.xscale[m0 + tid];
+    if constexpr (LOWRANK && BOUT == 2) t_amax = g.bout_amax[(int64_t)(m0 + tid) * g.bout_nblk];
+  }
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue_step(d, d);  // (past the end of K: dropped by the buffer range check)
+  if (tid < 256) {
+    const uint32_t ta = lds0 + EP_TAB + 4 * tid;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(ta), "v"(t_xs) : "memory");
+    if constexpr (LOWRANK && BOUT == 2) {
+      // both B_out scales as normal floats: mbits - e lies in [-121, 134] for an 8-bit exponent field; rows with
+      // e < mbits - 126 have |s| < 2^-119 <= 1e-8 everywhere (a zero row: e = -127), i.e. every element takes the
+      // pass-through whatever the scale - clamp, the result does not change
+      int up = g.bout.mbits - block_exponent(t_amax, g.bout);
+      up = up > 126 ? 126 : (up < -126 ? -126 : up);
+      asm volatile("ds_write_b32 %0, %1 offset:1024\n\tds_write_b32 %0, %2 offset:2048" ::"v"(ta),
+                   "v"((uint32_t)(127 + up) << 23), "v"((uint32_t)(127 - up) << 23)
+                   : "memory");
+    }
+  }
 
   i32x16 R[8];
 #pragma unroll
@@ -262,16 +297,29 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // batch of step kt+1 has landed (the batch of kt+2 - 6 loads, wave 0: 7 - may stay in flight), then passes a barrier before
   // anyone reads step kt+1.
   const bool late = wave >= 4;
-  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");  // step 0 landed
+  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // step 0 landed, the tables written
   if (late) asm volatile("s_barrier" ::: "memory");
+#ifdef LQER_CLOCKPROBE
+  I8_STAMP(cp_c[1], cp_r[1]);
+#endif
   i32x4 wf[4];     // the step's expanded weight fragments (slices 0..3): live across both half-steps
   uint32_t sv = 0;  // this lane's (column's) shift of the step's 128-k group
+  // SHIFT: the group sums of a half-step's LAST token tile are folded at the head of the next half-step's LOAD section - the
+  // partner wave of the SIMD is computing then and the vector ALU is idle -, those of the other three tiles under the MFMAs
+  // of the tile after them (4 folds per MFMA slot, from two slots behind the tile's last MFMA: its results have landed)
+  i32x16 Gd = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   auto half_step = [&](int kt, auto slot_c, auto half_c) {
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr int P = decltype(half_c)::value;
     constexpr int slot_new = (SLOT + DEPTH) % NSLOT;
     constexpr int A_IMM = (SLOT == 2 ? 0 : SLOT * A_SLOT) + 4 * P * 4096;  // tile t of this half: + 4096 t
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (SHIFT) {  // the previous half-step's last tile (sv still holds that step's shift: the asm below updates it)
+      constexpr int prev = 4 * (1 - P) + 3;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) R[prev][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[prev][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
     const int a_soff = ktn * I8_BK, w_soff = ktn * I8_WBLOCK;
     const uint32_t m0a0 = m0_a + slot_new * A_SLOT + (2 * P) * 1024, m0a1 = m0a0 + 1024;
@@ -347,14 +395,28 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         for (int t = 0; t < 4; ++t) R[4 * P + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][ks], wf[ks], R[4 * P + t], 0, 0, 0);
     } else {
       const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      i32x16 G[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        i32x16 G = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][0], wf[0], z, 0, 0, 0);
+        G[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][0], wf[0], z, 0, 0, 0);
 #pragma unroll
-        for (int ks = 1; ks < 4; ++ks) G = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][ks], wf[ks], G, 0, 0, 0);
+        for (int ks = 1; ks < 4; ++ks) G[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][ks], wf[ks], G[t], 0, 0, 0);
+        if (t > 0) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) R[4 * P + t][j] = (int)(((uint32_t)G[j] << sv) + (uint32_t)R[4 * P + t][j]);
+          for (int j = 0; j < 16; ++j) R[4 * P + t - 1][j] = (int)(((uint32_t)G[t - 1][j] << sv) + (uint32_t)R[4 * P + t - 1][j]);
+        }
       }
+      Gd = G[3];
+      // issue order: one MFMA, then the vector instructions that fit its shadow - the expands of the step's remaining weight
+      // fragments first (P = 0: needed by the MFMAs of slots 1..3), the folds of tile t from slot 4 t + 5 on
+#define I8_SLOT(NV)                                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+      if constexpr ((NV) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);
+      I8_SLOT(P == 0 ? 6 : 0) I8_SLOT(P == 0 ? 6 : 0) I8_SLOT(P == 0 ? 6 : 0) I8_SLOT(0)
+      I8_SLOT(0) I8_SLOT(4) I8_SLOT(4) I8_SLOT(4)
+      I8_SLOT(4) I8_SLOT(4) I8_SLOT(4) I8_SLOT(4)
+      I8_SLOT(4) I8_SLOT(5) I8_SLOT(5) I8_SLOT(6)
+#undef I8_SLOT
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
@@ -375,96 +437,205 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetches issued past the end of K have drained
   if (!late) asm volatile("s_barrier" ::: "memory");
+#ifdef LQER_CLOCKPROBE
+  I8_STAMP(cp_c[2], cp_r[2]);
+#endif
+  if constexpr (SHIFT) {  // the last half-step's last tile
+#pragma unroll
+    for (int j = 0; j < 16; ++j) R[7][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[7][j]);
+  }
   // every wave is past its last LDS read of the ring: the epilogue may overwrite it after one more barrier
   asm volatile("s_barrier" ::: "memory");
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------------
   // lane: output column n = n0 + 32 wave + (lane & 31); register j of tile i: token row m0 + 32 i + (j&3) + 8 (j>>2) + 4 lh.
+  // Everything per row is tabulated in LDS once (row scale, B_out exponent differences), everything per column is a lane
+  // constant; the side product's code is fully static per (limbs, slices) pair.
   const int n = n0 + wave * 32 + l31;
-  const float* const xscale = g.xscale;
   const float* const wscale = (const float*)(g.w8 + (size_t)g.tiles_n * nk * I8_WBLOCK);
-  float* const tab_xs = (float*)(smem + EP_TAB);
-  int* const tab_be = (int*)(smem + EP_TAB + 1024);
-  if (tid < 256) {
-    tab_xs[tid] = xscale[m0 + tid];
-    if constexpr (LOWRANK && BOUT == 2) tab_be[tid] = block_exponent(g.bout_amax[(int64_t)(m0 + tid) * g.bout_nblk], g.bout);
-  }
-  // the side product's operands: the tile's rows of xAq through LDS (panels of 64 columns, the activation tile's swizzle);
-  // this wave's B^T fragments in registers when there are at most 8 (limb, 16-deep slice) pairs - rank 64 with fp16 A / B,
-  // rank 128 with 8-bit A / B -, else re-fetched from L2 for every token tile
+  // (EP_TAB + 0: 2^(ex[m] - mbits), read in the conversion pass below)
+  const float* const tab_up = (const float*)(smem + EP_TAB + 1024);  // B_out: 2^(mbits - e[m]) ...
+  const float* const tab_dn = (const float*)(smem + EP_TAB + 2048);  // ... and 2^(e[m] - mbits)
+  // the side product's operands: the tile's rows of xAq by LDS-DMA into the ring's place (panels of 64 columns, the
+  // activation tile's row pitch and swizzle); this wave's B^T fragments in registers when there are at most 8 (limb,
+  // 16-deep slice) pairs - rank 64 with fp16 A / B, rank 128 with 8-bit A / B -, else re-fetched from L2 for every token
+  // tile.  Their latency passes under the conversion of the integer tile (below).
   bf16x8 sb[LOWRANK ? 8 : 1];
   const int nslices = LOWRANK ? g.rp / 16 : 0;  // 16-deep slices per limb
-  const int nfrag = LOWRANK ? g.b_limbs * nslices : 0;
-  const bool sbreg = nfrag <= 8;  // (wave-uniform)
+  const bf16_t* const bt_lane = LOWRANK ? g.bt + (int64_t)n * g.rp + 8 * lh : nullptr;  // + l * Np * rp + 16 ks
+  const int64_t bt_limb = (int64_t)g.Np * g.rp;
   if constexpr (LOWRANK) {
-    const int cpr = g.rp >> 3;  // 16-byte chunks per row
-    for (int c = tid; c < BM * cpr; c += 512) {
-      const int row = c / cpr, ch = c - row * cpr;
-      const u32x4 v = *(const u32x4*)(g.xaq + (int64_t)(m0 + row) * g.xaq_ld + 8 * ch);
-      *(u32x4*)(smem + EP_STAGE + (ch >> 3) * 32768 + swz(row, ch & 7)) = v;
-    }
+    // (exact range: the 128-byte pieces of a narrow xAq run into the next row, past the last row of the buffer they read 0)
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xaq + (int64_t)m0 * g.xaq_ld), 0, BM * g.xaq_ld * 2, 0x00020000);
+    const int npanel = (g.rp + 63) >> 6;
+    for (int pn = 0; pn < npanel; ++pn)
 #pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      const int l = f / (nslices > 0 ? nslices : 1), ks = f - l * nslices;
-      sb[f] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (sbreg && l < g.b_limbs) sb[f] = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n) * g.rp + ks * 16 + 8 * lh);
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + EP_STAGE + pn * 32768 + wave * 32 * 128 + i * 1024), 16,
+                                                 row * g.xaq_ld * 2 + chunk * 16, pn * 128, 0, 0);
+      }
+  }
+  // B^T fragments of the common (limbs, slices per limb) pairs: static code (no runtime divisions, no exec masks)
+  auto load_sb = [&](auto nl_c, auto nsl_c) {
+    constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value;
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int ks = 0; ks < NSL; ++ks) sb[l * NSL + ks] = *(const bf16x8*)(bt_lane + l * bt_limb + ks * 16);
+  };
+  const int side_key = LOWRANK ? g.b_limbs * 16 + nslices : 0;  // (wave-uniform)
+  if constexpr (LOWRANK) {
+    using std::integral_constant;
+    switch (side_key) {
+      case 16 + 1: load_sb(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+      case 16 + 2: load_sb(integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
+      case 16 + 4: load_sb(integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+      case 16 + 8: load_sb(integral_constant<int, 1>{}, integral_constant<int, 8>{}); break;
+      case 32 + 1: load_sb(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+      case 32 + 2: load_sb(integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+      case 32 + 4: load_sb(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+      default: break;
     }
   }
-  __syncthreads();
   const float ws = wscale[n];
   const float bv = g.bias ? g.bias[n] : 0.f;
+#ifdef LQER_CLOCKPROBE
+  unsigned long long cp_a, cp_b, cp_cc, cp_x;
+  I8_STAMP(cp_a, cp_x);
+#endif
+  // the integer tile -> v = float(R) * xs[m] * ws[n] + bias[n], in place, two elements per packed fp32 instruction
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  {
+    const f2 ws2 = {ws, ws}, bv2 = {bv, bv};
+    const uint32_t txs = lds0 + EP_TAB + 16 * lh;  // row 32 i + 8 q + 4 lh: + 128 i + 32 q bytes
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      // (asm: a table read hipcc can see would be preceded by a vmcnt(0), i.e. wait for the DMA and the loads just issued)
+      f32x4 xs[4];
+      asm volatile("ds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c5+32\n\tds_read_b128 %2, %4 offset:%c5+64\n\t"
+                   "ds_read_b128 %3, %4 offset:%c5+96\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(xs[0]), "=&v"(xs[1]), "=&v"(xs[2]), "=&v"(xs[3])
+                   : "v"(txs), "i"(128 * i)
+                   : "memory");
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          const int j = 4 * q + t;
+          const f2 rf = {(float)R[i][j], (float)R[i][j + 1]};
+          const f2 v = __builtin_elementwise_fma(rf * (f2){xs[q][t], xs[q][t + 1]}, ws2, bv2);
+          R[i][j] = __float_as_int(v[0]), R[i][j + 1] = __float_as_int(v[1]);
+        }
+    }
+  }
+#ifdef LQER_CLOCKPROBE
+  asm volatile("" ::"v"(R[0][0]), "v"(R[7][15]));
+  I8_STAMP(cp_b, cp_x);
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LQER_CLOCKPROBE
+  I8_STAMP(cp_cc, cp_x);
+#endif
+  __syncthreads();  // the xAq tile has landed for every wave
+#ifdef LQER_CLOCKPROBE
+  I8_STAMP(cp_e1, cp_e1r);
+#endif
+  // xAq fragment addresses: row l31 (+ 32 i: + 4096 B), chunk 2 (ks & 3) + lh, panel ks >> 2
+  uint32_t xaddr[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) xaddr[c] = EP_STAGE + swz(l31, 2 * c + lh);
+  // the side product of token tile i: static code for the common (limbs, slices per limb) pairs
+  auto side_static = [&](int i, auto nl_c, auto nsl_c) {
+    constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value;
+    f32x16 sp;
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int ks = 0; ks < NSL; ++ks) {
+        const bf16x8 xf = *(const bf16x8*)(smem + xaddr[ks & 3] + (ks >> 2) * 32768 + i * 4096);
+        if (l == 0 && ks == 0) {
+          const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sb[0], z, 0, 0, 0);
+        } else {
+          sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sb[l * NSL + ks], sp, 0, 0, 0);
+        }
+      }
+    return sp;
+  };
+  auto side = [&](int i) -> f32x16 {
+    using std::integral_constant;
+    switch (side_key) {
+      case 16 + 1: return side_static(i, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+      case 16 + 2: return side_static(i, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+      case 16 + 4: return side_static(i, integral_constant<int, 1>{}, integral_constant<int, 4>{});
+      case 16 + 8: return side_static(i, integral_constant<int, 1>{}, integral_constant<int, 8>{});
+      case 32 + 1: return side_static(i, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+      case 32 + 2: return side_static(i, integral_constant<int, 2>{}, integral_constant<int, 2>{});
+      case 32 + 4: return side_static(i, integral_constant<int, 2>{}, integral_constant<int, 4>{});
+      default: break;
+    }
+    f32x16 sp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < g.b_limbs; ++l)  // (the same order: limb-major, slices ascending)
+      for (int ks = 0; ks < nslices; ++ks) {
+        const bf16x8 bf = *(const bf16x8*)(bt_lane + l * bt_limb + ks * 16);
+        const bf16x8 xf = *(const bf16x8*)(smem + EP_STAGE + (ks >> 2) * 32768 + swz(l31 + 32 * i, 2 * (ks & 3) + lh));
+        sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, bf, sp, 0, 0, 0);
+      }
+    return sp;
+  };
   unsigned char* const out_w = smem + EP_OUT + wave * EP_OUT_WAVE;
-  const bool aligned16 = (((uintptr_t)g.y) & 15) == 0;
   const int nb = n0 + wave * 32;
-  const bool wide = DT != LQER_F32 && (g.ldy & 7) == 0 && nb + 32 <= g.N && aligned16;  // wave-uniform
+  const bool wide = DT != LQER_F32 && (g.ldy & 7) == 0 && nb + 32 <= g.N && (((uintptr_t)g.y) & 15) == 0;  // wave-uniform
+  // 16-byte stores of whole 8-column pieces through a buffer descriptor whose range ends with row M - 1: rows of the
+  // tile beyond M are dropped by the range check, no per-row branch
+  const int rows_left = g.M - m0 < BM ? g.M - m0 : BM;
+  const auto y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((bf16_t*)g.y + (int64_t)m0 * g.ldy + nb), 0,
+                                                        (int)((int64_t)(rows_left - 1) * g.ldy * 2 + 64), 0x00020000);
+  // per element, two at a time in packed fp32 (v_pk_mul / v_pk_add / v_pk_fma_f32):
+  //   v = float(R) * xs[m] * ws[n] + bias[n]
+  //   B_out (block_fp.py:55-65 on the signed value - every step is odd-symmetric): t = (s +- 1e-9) * 2^(mbits-e);
+  //   r = rne(t) = (t + 1.5 * 2^23) - 1.5 * 2^23 (|t| <= 256); q = clamp(r, +-mmax) * 2^(e-mbits); |s| <= 1e-8 keeps s
+  const float mmax = g.bout.mmax;
+  const f2 magic = {12582912.0f, 12582912.0f};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     float yv[16];
     f32x16 sp;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) sp[j] = 0.f;
-    if constexpr (LOWRANK) {
-      if (sbreg) {
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          const int l = f / (nslices > 0 ? nslices : 1), ks = f - l * nslices;
-          if (l < g.b_limbs) {
-            const bf16x8 xf = *(const bf16x8*)(smem + EP_STAGE + (ks >> 2) * 32768 + swz(l31 + 32 * i, 2 * (ks & 3) + lh));
-            sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sb[f], sp, 0, 0, 0);
-          }
-        }
-      } else {
-        for (int l = 0; l < g.b_limbs; ++l)  // (the same order: limb-major, slices ascending)
-          for (int ks = 0; ks < nslices; ++ks) {
-            const bf16x8 bf = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n) * g.rp + ks * 16 + 8 * lh);
-            const bf16x8 xf = *(const bf16x8*)(smem + EP_STAGE + (ks >> 2) * 32768 + swz(l31 + 32 * i, 2 * (ks & 3) + lh));
-            sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, bf, sp, 0, 0, 0);
-          }
-      }
-    }
+    if constexpr (LOWRANK) sp = side(i);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rloc = 32 * i + 8 * q + 4 * lh;  // + (j & 3)
-      const f32x4 xs4 = *(const f32x4*)(tab_xs + rloc);
-      i32x4 be4 = {0, 0, 0, 0};
-      if constexpr (LOWRANK && BOUT == 2) be4 = *(const i32x4*)(tab_be + rloc);
+      f32x4 up4 = {0, 0, 0, 0}, dn4 = {0, 0, 0, 0};
+      if constexpr (LOWRANK && BOUT == 2) up4 = *(const f32x4*)(tab_up + rloc), dn4 = *(const f32x4*)(tab_dn + rloc);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 4; t += 2) {
         const int j = 4 * q + t;
-        float v = (float)R[i][j] * (ws * xs4[t]) + bv;
+        f2 v = {__int_as_float(R[i][j]), __int_as_float(R[i][j + 1])};
         if constexpr (LOWRANK) {
-          float s = sp[j];
+          f2 sv2 = {sp[j], sp[j + 1]};
           if constexpr (BOUT == 2) {
-            const int e = be4[t], mb = g.bout.mbits;
-            const float m = fminf(rintf(ldexpf(fabsf(s) + 1e-9f, mb - e)), g.bout.mmax);
-            const float qv = copysignf(ldexpf(m, e - mb), s);
-            s = fabsf(s) <= 1e-8f ? s : qv;
+            const f2 eps = {copysignf(1e-9f, sv2[0]), copysignf(1e-9f, sv2[1])};
+            const f2 tt = (sv2 + eps) * (f2){up4[t], up4[t + 1]};
+            f2 r = (tt + magic) - magic;
+            r[0] = __builtin_amdgcn_fmed3f(r[0], -mmax, mmax);
+            r[1] = __builtin_amdgcn_fmed3f(r[1], -mmax, mmax);
+            const f2 qv = r * (f2){dn4[t], dn4[t + 1]};
+            sv2[0] = fabsf(sv2[0]) <= 1e-8f ? sv2[0] : qv[0];
+            sv2[1] = fabsf(sv2[1]) <= 1e-8f ? sv2[1] : qv[1];
           }
-          v += s;
+          v += sv2;
         }
-        yv[j] = v;
+        yv[j] = v[0], yv[j + 1] = v[1];
       }
     }
+#ifdef LQER_CLOCKPROBE
+    if (i == 1) {  // tiles 0 and 1 computed (not yet stored)
+      asm volatile("" ::"v"(yv[0]), "v"(yv[15]));
+      I8_STAMP(cp_e2, cp_e2r);
+    }
+#endif
     if constexpr (DT == LQER_F32) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -473,36 +644,44 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       }
     } else {
       // 16-bit outputs: two tiles (64 rows x 32 columns) at a time through this wave's LDS region, then 16-byte stores
-      unsigned char* const dst = out_w + (i & 1) * 32 * 80 + l31 * 2;
+      unsigned char* const dst = out_w + (i & 1) * 32 * 80 + l31 * 2 + 4 * lh * 80;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int rl = (j & 3) + 8 * (j >> 2) + 4 * lh;
         uint16_t hv;
         if constexpr (DT == LQER_BF16) hv = f32_to_bf16_rne(yv[j]);
         else hv = __builtin_bit_cast(uint16_t, (_Float16)yv[j]);
-        *(uint16_t*)(dst + rl * 80) = hv;
+        *(uint16_t*)(dst + ((j & 3) + 8 * (j >> 2)) * 80) = hv;
       }
       if (i & 1) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int row = u * 16 + (lane >> 2), ch = lane & 3;
-          const uint4 v = *(const uint4*)(out_w + row * 80 + ch * 16);
-          const int m = m0 + 32 * (i - 1) + row;
-          if (m < g.M) {
-            bf16_t* gdst = (bf16_t*)g.y + (int64_t)m * g.ldy + nb + 8 * ch;
-            if (wide) {
-              *(uint4*)gdst = v;
-            } else {
-              const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+          const u32x4 v = *(const u32x4*)(out_w + row * 80 + ch * 16);
+          const int mrow = 32 * (i - 1) + row;  // row within the tile
+          if (wide) {
+            __builtin_amdgcn_raw_buffer_store_b128(v, y_rsrc, (mrow * (int)g.ldy + 8 * ch) * 2, 0, 0);
+          } else if (m0 + mrow < g.M) {
+            bf16_t* gdst = (bf16_t*)g.y + (int64_t)(m0 + mrow) * g.ldy + nb + 8 * ch;
 #pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (nb + 8 * ch + e < g.N) gdst[e] = (bf16_t)(w4[e >> 1] >> (16 * (e & 1)));
-            }
+            for (int e = 0; e < 8; ++e)
+              if (nb + 8 * ch + e < g.N) gdst[e] = (bf16_t)(v[e >> 1] >> (16 * (e & 1)));
           }
         }
       }
     }
   }
+#ifdef LQER_CLOCKPROBE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  I8_STAMP(cp_c[3], cp_r[3]);
+  if (g_i8_stamp_buf && lane == 0) {
+    unsigned long long* o = g_i8_stamp_buf + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = cp_c[2] - cp_c[1], o[1] = cp_r[2] - cp_r[1];  // main loop: cycles, 100 MHz ticks
+    o[2] = cp_c[1] - cp_c[0];                            // prologue (ring fill)
+    o[3] = ((cp_a - cp_c[2]) & 0xffff) | (((cp_b - cp_a) & 0xffff) << 16) | (((cp_cc - cp_b) & 0xffff) << 32) | (((cp_e1 - cp_cc) & 0xffff) << 48);
+    o[4] = cp_c[3] - cp_c[2], o[5] = cp_r[3] - cp_r[2];  // epilogue
+    o[6] = cp_e1 - cp_c[2], o[7] = cp_e2 - cp_e1;         // epilogue: staging + barrier; the first two tiles' math
+  }
+#endif
 }
 
 template <int DT>
@@ -514,12 +693,12 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
   do {                                                                                            \
     if (g.i8_shift) {                                                                             \
       static LdsLimitOnce lds_once;                                                               \
-      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, true>, GEMM_LDS);                      \
-      k_lqer_gemm_i8<DT, LR, BO, true><<<grid, 512, GEMM_LDS, st>>>(g);                           \
+      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, true>, KERNEL_LDS);                      \
+      k_lqer_gemm_i8<DT, LR, BO, true><<<grid, 512, KERNEL_LDS, st>>>(g);                           \
     } else {                                                                                      \
       static LdsLimitOnce lds_once;                                                               \
-      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false>, GEMM_LDS);                     \
-      k_lqer_gemm_i8<DT, LR, BO, false><<<grid, 512, GEMM_LDS, st>>>(g);                          \
+      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false>, KERNEL_LDS);                     \
+      k_lqer_gemm_i8<DT, LR, BO, false><<<grid, 512, KERNEL_LDS, st>>>(g);                          \
     }                                                                                             \
   } while (0)
   if (!lowrank)
@@ -533,6 +712,12 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
 }
 
 }  // namespace i8
+
+#ifdef LQER_CLOCKPROBE
+extern "C" int lqer_debug_set_i8_stamp_buffer(void* p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(i8::g_i8_stamp_buf), &p, sizeof(p));
+}
+#endif
 
 // The int8 main loop needs: the int8 images (g.w8 set by the caller for an LQER_Q_MXINT_I8 descriptor), M large enough for
 // 256-row tiles to fill the chip in rounds that beat the 128-row bf16 kernel (an int8 256 x 256 tile costs about 1.15

@@ -134,7 +134,8 @@ def test_int8_route_forward_vs_oracle_and_bf16_route(lq, dtype, tol, M, K, N, r,
     y2 = mod(xin.to(DEV))
     assert not mod._x_i8
     d = float((y.float() - y2.float()).norm() / y2.float().norm())
-    assert d <= (1e-6 if dtype == torch.float32 else tol / 4), d
+    # (fp32: the bf16 route rounds its fp32 accumulator at every MFMA, the int8 route once at the end)
+    assert d <= (1e-5 if dtype == torch.float32 else tol / 4), d
     if dtype != torch.float32:  # 16-bit outputs: the two routes round the same fp32 sums - almost every element identical
         assert float((y != y2).float().mean()) <= 0.01
     # rows are independent: a slice that runs the small tiles of the bf16 route gives the bf16 route's bits

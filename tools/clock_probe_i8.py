@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the int8 GEMM (a -DLQER_CLOCKPROBE build stamps s_memtime / s_memrealtime at the start, around the
+main loop and at the end of every wave): ring fill, main loop (cycles per 128-k step, sustained clock), epilogue, and the
+spread of tile start times inside a launch.  Runs >= 2 s of back-to-back launches first (DVFS settles).
+usage: python tools/clock_probe_i8.py build/abl/liblqer_clockprobe.so [--K 5120 --N 5120 --M 16384 --wblock 128]
+(build:  cd lqer_amd/csrc && make -s -j8 EXTRA=-DLQER_CLOCKPROBE OUT=../../build/abl/liblqer_clockprobe.so OBJDIR=../../build/obj_cp)"""
+import argparse, ctypes as C, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("lib")
+ap.add_argument("--M", type=int, default=16384)
+ap.add_argument("--K", type=int, default=5120)
+ap.add_argument("--N", type=int, default=5120)
+ap.add_argument("--r", type=int, default=64)
+ap.add_argument("--wblock", type=int, default=128)
+a = ap.parse_args()
+from lqer_amd import _lib
+_lib.LIB_PATH = os.path.abspath(a.lib)  # the module and every helper bind the diagnostic build
+import lqer_amd
+from bench import INT_Q, _bfp, make_case
+from lqer_amd import ops
+L = _lib.lib()
+L.lqer_debug_set_i8_stamp_buffer.argtypes = [C.c_void_p]
+dev = torch.device("cuda:0")
+M, K, N, r = a.M, a.K, a.N, a.r
+qc = dict(INT_Q, w_quantizer=_bfp(4, [1, a.wblock], False))
+x, W, A, B = make_case(M, K, N, r, seed=0, quantize_ab=False)
+mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+mod.load_state_dict({"weight": W, "A": A, "B": B})
+mod = mod.to(dev).half()
+xd = x.half().to(dev)
+y = mod(xd)
+assert mod._x_i8
+tiles = (-(-M // 256)) * (-(-N // 256))
+buf = torch.zeros(tiles * 8 * 8, dtype=torch.int64, device=dev)
+assert L.lqer_debug_set_i8_stamp_buffer(buf.data_ptr()) == 0
+desc = mod._desc()
+p = mod._packed
+st = torch.cuda.current_stream().cuda_stream
+Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
+ws = torch.empty(ops.linear_sizes(desc, M).workspace, dtype=torch.uint8, device=dev)
+xq = ws.data_ptr(); xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256; scr = xaq + ((Mp * rp * 2 + 255) // 256) * 256
+nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M); gscr = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+_lib.check(L.lqer_quantize_act_xa(C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], xq, xaq, scr, nscr, st), "q")
+def launch():
+    _lib.check(L.lqer_linear_gemm(C.byref(desc), xq, M, p["w"].data_ptr(), xaq, p["b_t"].data_ptr(), p["b_limbs"], None, y.data_ptr(), _lib.F16, N, scr, gscr, st), "g")
+t0 = time.time()
+while time.time() - t0 < 2.5:
+    for _ in range(20): launch()
+    torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): launch()
+e1.record(); torch.cuda.synchronize()
+b = buf.cpu().view(tiles, 8, 8).double()
+steps = -(-K // 128)
+cyc, rt = b[:, :, 0], b[:, :, 1]
+clk = (cyc / rt * 100e6).median().item()
+med = lambda t: t.median().item()
+print(f"M={M} K={K} N={N} r={r} wblock={a.wblock}: call (pre-pass + GEMM) {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, {tiles} tiles = {tiles / 256:.2f} rounds")
+print(f"  main loop   {med(cyc):9.0f} cycles = {med(cyc) / steps:6.0f} per 128-k step (2048 = MFMA-bound), {med(rt) / 100:7.2f} us; clock {clk / 1e9:.3f} GHz")
+print(f"  ring fill   {med(b[:, :, 2]):9.0f} cycles")
+pk = buf.cpu().view(tiles, 8, 8)[:, :, 3]
+parts = [((pk >> (16 * i)) & 0xffff).double() for i in range(4)]
+for w in (0, 4):
+    print(f"  wave {w}: issue of DMA + loads {parts[0][:, w].median().item():.0f}, conversion pass {parts[1][:, w].median().item():.0f}, "
+          f"vmcnt(0) {parts[2][:, w].median().item():.0f}, barrier {parts[3][:, w].median().item():.0f} cycles")
+print(f"  epilogue    {med(b[:, :, 4]):9.0f} cycles, {med(b[:, :, 5]) / 100:7.2f} us")
+print(f"     of which staging + barrier {med(b[:, :, 6]):7.0f} cycles, math of the first two of eight tiles {med(b[:, :, 7]):7.0f} cycles")
