@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--sweep", default="auto", choices=["auto", "weak", "strong"],
                     help="multi-GPU: strong = the model's layers split over the ranks (default for c3/c4/c5), weak = every "
                          "rank runs the full unit list (default for single-Linear workloads)")
+    ap.add_argument("--layers", type=int, default=0, help="override the model's decoder layer count (profiling runs: --layers 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle comparison of the timed outputs")
     ap.add_argument("--no-module", action="store_true", help="skip the second timed region through the nn.Module")
@@ -212,6 +213,9 @@ def main():
     from lqer_amd import _lib, ops, sweep
 
     desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS[args.workload]
+    if args.layers > 0:
+        layers = args.layers
+        desc_txt += f" [--layers {layers}]"
     big = M >= 8192
     if args.steps is None:
         args.steps = 4 if big else 50

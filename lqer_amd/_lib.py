@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8 = 0, 1, 2, 3
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
@@ -73,6 +73,8 @@ SIGNATURES = {
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),
     "lqer_unpack_weight_i8": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "lqer_quantize_act_i8": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp]),
+    "lqer_matmul_q_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "lqer_matmul_q": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _qp, _qp, _vp, _sz, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

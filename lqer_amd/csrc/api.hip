@@ -552,6 +552,41 @@ int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t
   return f16_prepare_dispatch(w_packed, N, K, a_t_limbs, a_limbs, r, a_t_f16, flags, (hipStream_t)stream);
 }
 
+size_t lqer_matmul_q_workspace_bytes(int64_t batch, int64_t K, int64_t S2) {
+  return (batch > 0 && K > 0 && S2 > 0) ? qmatmul_workspace_bytes(batch, K, S2) : 0;
+}
+
+int lqer_matmul_q(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs,
+                  int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const lqer_qfmt_t* x_fmt, const lqer_qfmt_t* y_fmt,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (batch < 0 || S1 < 0 || K <= 0 || S2 < 0) {
+    set_error("matmul_q: bad shape batch=%lld S1=%lld K=%lld S2=%lld", (long long)batch, (long long)S1, (long long)K, (long long)S2);
+    return LQER_E_INVALID;
+  }
+  if (batch == 0 || S1 == 0 || S2 == 0) return LQER_OK;
+  if (!x || !y || !out || !workspace) {
+    set_error("matmul_q: null pointer");
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(x_fmt, "matmul x_quantizer", 8) || !fmt_ok(y_fmt, "matmul w_quantizer", 8)) return LQER_E_UNSUPPORTED;
+  if (x_fmt->kind != LQER_Q_MXINT || y_fmt->kind != LQER_Q_MXINT || x_fmt->block != 16 || y_fmt->block != 16) {
+    set_error("matmul_q: both quantizers must be block_fp with blocks of 16 along the last dim (got kinds %d / %d, blocks %d / %d)",
+              x_fmt->kind, y_fmt->kind, x_fmt->block, y_fmt->block);
+    return LQER_E_UNSUPPORTED;
+  }
+  if (x_rs < K || (y_ks != 1 && y_js != 1)) {
+    set_error("matmul_q: x rows must be dense along k (row stride %lld < K) and y dense along k or along j (strides %lld, %lld)",
+              (long long)x_rs, (long long)y_ks, (long long)y_js);
+    return LQER_E_INVALID;
+  }
+  if (workspace_bytes < qmatmul_workspace_bytes(batch, K, S2)) {
+    set_error("matmul_q: workspace %zu B < %zu B", workspace_bytes, qmatmul_workspace_bytes(batch, K, S2));
+    return LQER_E_WORKSPACE;
+  }
+  return qmatmul_dispatch(x, y, out, dtype, batch, S1, K, S2, x_bs, x_rs, y_bs, y_ks, y_js, make_qp(*x_fmt), make_qp(*y_fmt), workspace,
+                          (hipStream_t)stream);
+}
+
 int lqer_replicate_rows(const void* src, void* dst, int64_t rows, int64_t row_bytes, int copies, void* stream) {
   if (!src || !dst || rows < 0 || row_bytes < 0 || copies < 1) {
     set_error("replicate_rows: bad argument");

@@ -350,6 +350,10 @@ int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipSt
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 
+size_t qmatmul_workspace_bytes(int64_t batch, int64_t K, int64_t S2);  // matmul_q.hip
+int qmatmul_dispatch(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs,
+                     int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const QP& qx, const QP& qy, void* workspace, hipStream_t st);
+
 // ---- kernel attributes (host) -----------------------------------------------------------------------
 // Raising a kernel's dynamic-LDS limit is idempotent but not free: done once per kernel instantiation and device,
 // thread-safely (the only process-wide state of the library besides the thread-local error text).

@@ -1,0 +1,351 @@
+// Quantized attention products (reference quantized_functions/matmul.py:12-37; call sites models/llama_decoder.py:263,294,
+// opt_decoder.py:125,190):      out[b] = x_quantizer(x[b]) @ w_quantizer(y[b])
+// with block_fp quantizers whose blocks of 16 run along the LAST dim of each operand: for x [.., S1, K] that is the
+// contraction dim, for y [.., K, S2] it is NOT (llama-7b.toml:110-126) - in Q K^T the 16 elements of a block of y = K^T
+// are 16 consecutive tokens of one head feature.
+//
+//   k_qmm_bimage_*   y -> bf16 image [b][j][k] of w_quantizer(y) (every 8-bit MXINT value is exact in bf16), k contiguous -
+//                    the layout an MFMA operand fragment reads - whatever y's own layout: j-contiguous (P V: y = V
+//                    [tokens, head_dim], transposed through LDS) or k-contiguous (Q K^T: y is the transposed VIEW of K; one
+//                    thread holds 16 consecutive tokens x 8 features in registers, so the block maxima need no cross-lane work)
+//   k_qmatmul        batched GEMM on v_mfma_f32_32x32x16_bf16 whose first operand is quantized IN THE LOAD PATH: a thread
+//                    loads one block of 16 (32 B, four threads cover 128 B of a row), quantizes it in registers and writes
+//                    the bf16 image to an LDS slab - x (the attention probabilities in P V: the big operand) is read from HBM
+//                    exactly once and no quantized copy of it ever exists in HBM.  fp32 accumulation of exact products.
+#include "common.h"
+
+namespace lqer {
+
+namespace qmm {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// 16 consecutive elements (or fewer at the end of a row), 128-bit loads when the piece is aligned and complete
+template <int DT>
+__device__ __forceinline__ void load16(const void* base, int64_t off, int64_t valid, bool vec, float (&v)[16]) {
+  if (vec && valid >= 16) {
+    if constexpr (DT == LQER_F32) {
+      const float4* p = (const float4*)((const float*)base + off);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 t = p[i];
+        v[4 * i] = t.x, v[4 * i + 1] = t.y, v[4 * i + 2] = t.z, v[4 * i + 3] = t.w;
+      }
+    } else {
+      const uint4* p = (const uint4*)((const bf16_t*)base + off);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 t = p[i];
+        const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (DT == LQER_F16) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            const h2 h = __builtin_bit_cast(h2, w[j]);
+            v[8 * i + 2 * j] = (float)h[0], v[8 * i + 2 * j + 1] = (float)h[1];
+          } else {
+            v[8 * i + 2 * j] = __uint_as_float(w[j] << 16), v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = i < valid ? load_elem<DT>(base, off + i) : 0.0f;
+  }
+}
+
+// one block of 16 -> 16 exact bf16 values (block_fp.py:7-82; zero block -> zeros; |x| <= 1e-8 flushed to 0)
+__device__ __forceinline__ void quant16_bf16(const float (&v)[16], const QP& q, uint32_t (&w)[8]) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = 0;
+  if (amax > 0.f) {
+    const int e = block_exponent(amax, q);
+    if (mxint16_fast_ok(e, q)) {
+      mxint16_bf16_fast<true>(v, e, q, w);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t lo = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i], e, q), e - q.mbits));
+        const uint32_t hi = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i + 1], e, q), e - q.mbits));
+        w[i] = lo | (hi << 16);
+      }
+    }
+  }
+}
+
+// ---- y [b][k][j], j contiguous -> img [b][S2p][Kp] (blocks of 16 along j), transposed through LDS -------------------------
+// One workgroup = 64 k x 64 j.  Thread t quantizes the block (k = t / 4, j = 16 (t % 4) ..): four threads read 128 B of a
+// k row; the bf16 values go to an LDS tile [j][k] and leave as 32-byte pieces of the image's j rows.
+template <int DT>
+__global__ __launch_bounds__(256) void k_qmm_bimage_j(const void* __restrict__ y, int64_t K, int64_t S2, int64_t y_bs, int64_t y_ks, QP q,
+                                                      bf16_t* __restrict__ img, int64_t S2p, int64_t Kp, bool vec) {
+  __shared__ bf16_t tile[64][64 + 2];  // (+2: the 16 two-byte stores of a thread walk 16 rows - spread them over banks)
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.z, k0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
+  {
+    const int kl = tid >> 2, jb = (tid & 3) * 16;
+    float v[16];
+    const int64_t k = k0 + kl, j = j0 + jb;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k < K && j < S2) {
+      load16<DT>(y, b * y_bs + k * y_ks + j, S2 - j, vec, v);
+      quant16_bf16(v, q, w);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      tile[jb + 2 * i][kl] = (bf16_t)(w[i] & 0xffff);
+      tile[jb + 2 * i + 1][kl] = (bf16_t)(w[i] >> 16);
+    }
+  }
+  __syncthreads();
+  {
+    const int jl = tid >> 2, kc = (tid & 3) * 16;
+    if (j0 + jl < S2p && k0 + kc < Kp) {
+      bf16_t* dst = img + (b * S2p + j0 + jl) * Kp + k0 + kc;
+      uint32_t w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = (uint32_t)tile[jl][kc + 2 * i] | ((uint32_t)tile[jl][kc + 2 * i + 1] << 16);
+      ((uint4*)dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      ((uint4*)dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+}
+
+// ---- y [b][k][j], k contiguous (the transposed view of a [j][k] tensor) -> img [b][S2p][Kp] -------------------------------
+// One thread = 16 consecutive j x 8 consecutive k: 16 loads of 16 B; the block of 16 along j of each of its 8 k is entirely in
+// its registers.  Consecutive threads take consecutive pieces of 8 k: the loads of a j row are contiguous.
+template <int DT>
+__global__ __launch_bounds__(256) void k_qmm_bimage_k(const void* __restrict__ y, int64_t K, int64_t S2, int64_t y_bs, int64_t y_js, QP q,
+                                                      bf16_t* __restrict__ img, int64_t S2p, int64_t Kp, bool vec) {
+  const int64_t kp8 = Kp / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (j block, piece of 8 k)
+  const int64_t b = blockIdx.z;
+  if (idx >= (S2p / 16) * kp8) return;
+  const int64_t jb = idx / kp8 * 16, k = (idx - idx / kp8 * kp8) * 8;
+  float v[16][8];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t j = jb + r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[r][c] = 0.f;
+    if (j < S2 && k < K) {
+      const int64_t off = b * y_bs + j * y_js + k;
+      if (vec && k + 8 <= K) {
+        if constexpr (DT == LQER_F32) {
+          const float4 a = ((const float4*)((const float*)y + off))[0], c4 = ((const float4*)((const float*)y + off))[1];
+          v[r][0] = a.x, v[r][1] = a.y, v[r][2] = a.z, v[r][3] = a.w, v[r][4] = c4.x, v[r][5] = c4.y, v[r][6] = c4.z, v[r][7] = c4.w;
+        } else {
+          const uint4 t = *(const uint4*)((const bf16_t*)y + off);
+          const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if constexpr (DT == LQER_F16) {
+              typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+              const h2 h = __builtin_bit_cast(h2, w[c]);
+              v[r][2 * c] = (float)h[0], v[r][2 * c + 1] = (float)h[1];
+            } else {
+              v[r][2 * c] = __uint_as_float(w[c] << 16), v[r][2 * c + 1] = __uint_as_float(w[c] & 0xffff0000u);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[r][c] = k + c < K ? load_elem<DT>(y, off + c) : 0.f;
+      }
+    }
+  }
+  // per k: the block of 16 along j
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(v[r][c]));
+    const bool any = amax > 0.f;
+    const int e = any ? block_exponent(amax, q) : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r][c] = any ? ldexpf(mxint_mantissa(v[r][c], e, q), e - q.mbits) : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    uint32_t w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = exact_bf16_bits(v[r][2 * c]) | (exact_bf16_bits(v[r][2 * c + 1]) << 16);
+    *(uint4*)(img + (b * S2p + jb + r) * Kp + k) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// ---- the product ----------------------------------------------------------------------------------------------------------
+// One workgroup = one 128 (i) x 128 (j) tile of out[b]; 4 waves as 2 x 2, each 64 x 64 = 2 x 2 tiles of 32 x 32.
+// The MFMA is issued with the image rows (j) as the A operand and the token rows (i) as the B operand, so a lane owns one
+// output row i and 4 consecutive columns j per accumulator quad (the store pattern of gemm_w4a8.hip).
+template <int DT>
+__global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
+                                                 int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs, int64_t S2p, int64_t Kp,
+                                                 QP q, bool vec) {
+  __shared__ __attribute__((aligned(16))) unsigned char sa[BM * BK * 2];  // x tile, quantized: 128 rows x 128 B
+  __shared__ __attribute__((aligned(16))) unsigned char sb[BN * BK * 2];  // image tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int64_t b = blockIdx.z, i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
+  const bf16_t* const ib = img + (b * S2p + j0) * Kp;
+  f32x16 acc[2][2];  // [j tile][i tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  const int nkc = (int)(Kp / BK);
+  // this thread's two blocks of the x tile (rows tid / 4 and 64 + tid / 4, block tid % 4) and four 16-byte pieces of the image tile
+  float xv[2][16];
+  uint4 bv[4];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = (tid >> 2) + 64 * u;
+      const int64_t i = i0 + row, k = (int64_t)kc * BK + (tid & 3) * 16;
+      if (i < S1 && k < K) {
+        load16<DT>(x, b * x_bs + i * x_rs + k, K - k, vec, xv[u]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xv[u][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = tid + 256 * u, row = p >> 3, ch = p & 7;
+      bv[u] = *(const uint4*)(ib + (int64_t)row * Kp + (int64_t)kc * BK + ch * 8);  // (rows up to S2p exist, zero beyond S2)
+    }
+  };
+  fetch(0);
+  for (int kc = 0; kc < nkc; ++kc) {
+    uint32_t w[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) quant16_bf16(xv[u], q, w[u]);
+    __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = (tid >> 2) + 64 * u, c = 2 * (tid & 3);
+      *(uint4*)(sa + swz(row, c)) = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
+      *(uint4*)(sa + swz(row, c + 1)) = make_uint4(w[u][4], w[u][5], w[u][6], w[u][7]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = tid + 256 * u;
+      *(uint4*)(sb + swz(p >> 3, p & 7)) = bv[u];
+    }
+    __syncthreads();
+    if (kc + 1 < nkc) fetch(kc + 1);  // the next chunk's loads travel under this chunk's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fj[2], fi[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fj[t] = *(const bf16x8*)(sb + swz(wn * 64 + t * 32 + l31, 2 * ks + lh));
+        fi[t] = *(const bf16x8*)(sa + swz(wm * 64 + t * 32 + l31, 2 * ks + lh));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fj[a], fi[c], acc[a][c], 0, 0, 0);
+    }
+  }
+  // ---- store: lane = output row, register r of tile (a, c): column (r & 3) + 8 (r >> 2) + 4 lh
+  const int esz = DT == LQER_F32 ? 4 : 2;
+  const bool aligned = (((uintptr_t)out) & 15) == 0 && (S2 * esz) % 16 == 0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int64_t i = i0 + wm * 64 + c * 32 + l31;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int64_t jb = j0 + wn * 64 + a * 32;
+      if (i >= S1) continue;
+      if constexpr (DT == LQER_F32) {
+        float* dst = (float*)out + (b * S1 + i) * S2;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int64_t j = jb + 8 * qd + 4 * lh;
+          if (aligned && j + 3 < S2) {
+            *(float4*)(dst + j) = make_float4(acc[a][c][4 * qd], acc[a][c][4 * qd + 1], acc[a][c][4 * qd + 2], acc[a][c][4 * qd + 3]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (j + t < S2) dst[j + t] = acc[a][c][4 * qd + t];
+          }
+        }
+      } else {
+        bf16_t* dst = (bf16_t*)out + (b * S1 + i) * S2;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int64_t j = jb + 8 * qd + 4 * lh;
+          uint32_t pk[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float v0 = acc[a][c][4 * qd + 2 * h], v1 = acc[a][c][4 * qd + 2 * h + 1];
+            if constexpr (DT == LQER_F16) {
+              typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+              const h2 hv = {(_Float16)v0, (_Float16)v1};
+              pk[h] = __builtin_bit_cast(uint32_t, hv);
+            } else {
+              pk[h] = (uint32_t)f32_to_bf16_rne(v0) | ((uint32_t)f32_to_bf16_rne(v1) << 16);
+            }
+          }
+          if (aligned && j + 3 < S2) {
+            *(uint2*)(dst + j) = make_uint2(pk[0], pk[1]);
+          } else {
+            if (j < S2) dst[j] = (bf16_t)(pk[0] & 0xffff);
+            if (j + 1 < S2) dst[j + 1] = (bf16_t)(pk[0] >> 16);
+            if (j + 2 < S2) dst[j + 2] = (bf16_t)(pk[1] & 0xffff);
+            if (j + 3 < S2) dst[j + 3] = (bf16_t)(pk[1] >> 16);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace qmm
+
+size_t qmatmul_workspace_bytes(int64_t batch, int64_t K, int64_t S2) {
+  const int64_t S2p = (S2 + qmm::BN - 1) / qmm::BN * qmm::BN, Kp = (K + qmm::BK - 1) / qmm::BK * qmm::BK;
+  return (size_t)batch * S2p * Kp * sizeof(bf16_t);
+}
+
+template <int DT>
+static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs,
+                      int64_t y_bs, int64_t y_ks, int64_t y_js, const QP& qx, const QP& qy, bf16_t* img, hipStream_t st) {
+  const int64_t S2p = (S2 + qmm::BN - 1) / qmm::BN * qmm::BN, Kp = (K + qmm::BK - 1) / qmm::BK * qmm::BK;
+  const int esz = DT == LQER_F32 ? 4 : 2;
+  auto al16 = [&](const void* p, int64_t a, int64_t c) { return ((uintptr_t)p % 16 == 0) && (a * esz) % 16 == 0 && (c * esz) % 16 == 0; };
+  if (y_js == 1) {
+    const dim3 grid((unsigned)(S2p / 64), (unsigned)(Kp / 64), (unsigned)batch);
+    qmm::k_qmm_bimage_j<DT><<<grid, 256, 0, st>>>(y, K, S2, y_bs, y_ks, qy, img, S2p, Kp, al16(y, y_bs, y_ks));
+  } else {
+    const int64_t items = (S2p / 16) * (Kp / 8);
+    const dim3 grid((unsigned)((items + 255) / 256), 1, (unsigned)batch);
+    qmm::k_qmm_bimage_k<DT><<<grid, 256, 0, st>>>(y, K, S2, y_bs, y_js, qy, img, S2p, Kp, al16(y, y_bs, y_js));
+  }
+  const dim3 grid((unsigned)(S2p / qmm::BN), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
+  qmm::k_qmatmul<DT><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, al16(x, x_bs, x_rs));
+  return check_launch("lqer_matmul_q");
+}
+
+int qmatmul_dispatch(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs,
+                     int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const QP& qx, const QP& qy, void* workspace, hipStream_t st) {
+  if (batch == 0 || S1 == 0 || S2 == 0) return LQER_OK;
+  switch (dtype) {
+    case LQER_F32: return launch_qmm<LQER_F32>(x, y, out, batch, S1, K, S2, x_bs, x_rs, y_bs, y_ks, y_js, qx, qy, (bf16_t*)workspace, st);
+    case LQER_F16: return launch_qmm<LQER_F16>(x, y, out, batch, S1, K, S2, x_bs, x_rs, y_bs, y_ks, y_js, qx, qy, (bf16_t*)workspace, st);
+    case LQER_BF16: return launch_qmm<LQER_BF16>(x, y, out, batch, S1, K, S2, x_bs, x_rs, y_bs, y_ks, y_js, qx, qy, (bf16_t*)workspace, st);
+  }
+  set_error("unknown dtype %d", dtype);
+  return LQER_E_INVALID;
+}
+
+}  // namespace lqer

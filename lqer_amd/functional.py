@@ -2,10 +2,12 @@
 (src/lqer/quantize/quantized_functions/matmul.py:12-37, __init__.py:3-21; call sites llama_decoder.py:263,294 and
 opt_decoder.py:125,190):   product = matmul(x_quantizer(x), w_quantizer(y)).
 
-Both operands are quantized by the library's HIP quantizer kernels (blocks along the last dim of each operand, which
-for y is NOT the contraction dim - llama-7b.toml:110-126); the product of the two quantized images is a plain GEMM and
-goes through torch.matmul / torch.bmm (rocBLAS / hipBLASLt) in the operands' dtype, like the reference's.  Quantizer
-settings outside what the kernels implement raise - there is no software fallback.
+Blocks run along the last dim of each operand, which for y is NOT the contraction dim (llama-7b.toml:110-126).  With the
+templates' settings (block_fp, width <= 8, blocks of 16) the whole product is ONE fused HIP GEMM (lqer_matmul_q,
+csrc/matmul_q.hip): x is quantized in the GEMM's load path - read from HBM once, no quantized copy -, y through a small bf16
+image, bf16 MFMA with fp32 accumulation of exact products.  Other block lengths run the library's quantizer kernels on both
+operands and hand the two quantized images to torch.matmul / torch.bmm.  Quantizer settings outside what the kernels
+implement raise - there is no software fallback.
 """
 from __future__ import annotations
 
@@ -13,7 +15,9 @@ from copy import deepcopy
 
 import torch
 
-from . import ops
+import ctypes as C
+
+from . import _lib, ops
 
 MATMUL_MAP = {"matmul": torch.matmul, "bmm": torch.bmm}
 
@@ -30,11 +34,50 @@ def _quantize(t: torch.Tensor, cfg: dict) -> torch.Tensor:
     return ops.quantize_mxint(t, fmt, want=("deq",))["deq"].to(t.dtype)
 
 
+def _fused_fmt(cfg: dict):
+    """The lqer_qfmt_t of a quantizer the fused kernel covers (block_fp, width <= 8, blocks of 16 along the last dim), else None."""
+    if cfg.get("name") != "block_fp" or int(cfg.get("width", 12)) > 8:
+        return None
+    try:
+        fmt = ops.make_qfmt(cfg, "x")
+    except NotImplementedError:
+        return None
+    return fmt if fmt.block == 16 else None
+
+
+@torch.no_grad()
+def _matmul_fused(x: torch.Tensor, y: torch.Tensor, fx, fy) -> torch.Tensor:
+    """x [b, S1, K] @ y [b, K, S2] (or both 2-D) through lqer_matmul_q."""
+    squeeze = x.dim() == 2
+    x3, y3 = (x[None], y[None]) if squeeze else (x, y)
+    b, S1, K = x3.shape
+    S2 = y3.shape[2]
+    if x3.stride(2) != 1 or x3.stride(1) < K:
+        x3 = x3.contiguous()
+    if y3.stride(1) != 1 and y3.stride(2) != 1:  # (the kernel reads y dense along k - the transposed view of K - or along j)
+        y3 = y3.contiguous()
+    out = torch.empty(b, S1, S2, dtype=x.dtype, device=x.device)
+    L = _lib.lib()
+    nws = L.lqer_matmul_q_workspace_bytes(b, K, S2)
+    with torch.cuda.device(x.device):
+        ws = ops.workspace(x.device, max(nws, 16))
+        ys = y3.stride()
+        _lib.check(L.lqer_matmul_q(x3.data_ptr(), y3.data_ptr(), out.data_ptr(), ops.dtype_code(x3), b, S1, K, S2, x3.stride(0), x3.stride(1),
+                                   ys[0], ys[1], ys[2], C.byref(fx), C.byref(fy), ws.data_ptr(), ws.numel(), ops._stream(x.device)),
+                   "lqer_matmul_q")
+    return out[0] if squeeze else out
+
+
 def generic_matmul_flexible(x: torch.Tensor, y: torch.Tensor, q_config: dict, style: str = "matmul") -> torch.Tensor:
     matmul = MATMUL_MAP[style]
     # q_config["default"] is evaluated eagerly, as in the reference (matmul.py:15-16)
     x_cfg = deepcopy(q_config.get("x_quantizer", q_config["default"]))
     w_cfg = deepcopy(q_config.get("w_quantizer", q_config["default"]))
+    fx, fy = _fused_fmt(x_cfg), _fused_fmt(w_cfg)
+    if (fx is not None and fy is not None and x.dtype == y.dtype and x.dtype in ops._DT and x.dim() == y.dim() and x.dim() in (2, 3)
+            and x.shape[-1] == y.shape[-2] and (x.dim() == 2 or x.shape[0] == y.shape[0]) and x.numel() > 0 and y.numel() > 0):
+        ops._need_gpu(x, y)
+        return _matmul_fused(x, y, fx, fy)
     return matmul(_quantize(x, x_cfg), _quantize(y, w_cfg))
 
 

@@ -306,7 +306,7 @@ def test_small_m_kernel_vs_oracle(ops, M, cfg, K, N, r, bias):
 
 
 def test_quantized_attention_matmuls_vs_reference_vectors(ops):
-    """lqer_amd.matmul_flexible / bmm_flexible (quantizers on the GPU, product through torch) against the reference's
+    """lqer_amd.matmul_flexible / bmm_flexible (the fused HIP GEMM for the templates' blocks of 16) against the reference's
     outputs; the second operand of Q K^T is passed as the transposed view the model code uses."""
     import json
     import os
@@ -329,6 +329,45 @@ def test_quantized_attention_matmuls_vs_reference_vectors(ops):
         lqer_amd.matmul_flexible(t("pv/x"), t("pv/y"), {"name": "flexible", "x_quantizer": qc["x_quantizer"]})
     with pytest.raises(RuntimeError):  # no software fallback
         lqer_amd.matmul_flexible(t("pv/x").cpu(), t("pv/y").cpu(), qc)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 5e-3)])
+@pytest.mark.parametrize("bh,s1,s2,d", [(3, 300, 200, 128), (2, 129, 70, 64), (1, 16, 16, 40), (4, 2048, 2048, 128)])
+def test_fused_quantized_matmul_vs_oracle(ops, dtype, tol, bh, s1, s2, d):
+    """lqer_matmul_q (x quantized in the GEMM's load path, y through a bf16 image) against the oracle's
+    matmul(x_quantizer(x), w_quantizer(y)) for both attention products: Q K^T with y the transposed VIEW of K (blocks of 16
+    consecutive tokens per head feature) and P V with y = V (blocks along the head dim); ragged s / d, three dtypes."""
+    import json
+
+    import lqer_amd
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    qc = json.load(open(os.path.join(here, "matmul_config.json")))
+    g = torch.Generator().manual_seed(bh * 1000 + s1 + d)
+    q = torch.randn(bh, s1, d, generator=g).to(dtype)
+    k = (torch.randn(bh, s2, d, generator=g) * torch.logspace(-2, 1, d)).to(dtype)
+    v = torch.randn(bh, s2, d, generator=g).to(dtype)
+    if bh * s1 * s2 > 4e6:  # the BASELINE-size case: compare two heads' worth of rows with the oracle
+        sl = slice(0, 1)
+    else:
+        sl = slice(0, bh)
+    kt = k.to(DEV).transpose(1, 2)  # a view: dense along the contraction dim
+    out = lqer_amd.matmul_flexible(q.to(DEV), kt, qc)
+    assert out.shape == (bh, s1, s2) and out.dtype == dtype
+    ref = O.matmul_flexible(q[sl].float(), k[sl].float().transpose(1, 2), qc)
+    err = (out[sl].float().cpu() - ref).norm() / ref.norm()
+    assert err <= tol, float(err)
+    p = torch.softmax(out.float() / d ** 0.5, dim=-1).to(dtype)
+    o2 = lqer_amd.matmul_flexible(p, v.to(DEV), qc)
+    assert o2.shape == (bh, s1, d)
+    ref2 = O.matmul_flexible(p[sl].float().cpu(), v[sl].float(), qc)
+    err2 = (o2[sl].float().cpu() - ref2).norm() / ref2.norm()
+    assert err2 <= tol, float(err2)
+    # the same bits whatever the layout of y: a dense copy of the transposed view takes the j-contiguous image kernel
+    out_c = lqer_amd.matmul_flexible(q.to(DEV), kt.contiguous(), qc)
+    assert torch.equal(out_c, out)
+    # 2-D operands
+    assert torch.equal(lqer_amd.matmul_flexible(q[0].to(DEV), kt[0], qc), out[0])
 
 
 @pytest.mark.parametrize("M", [4, 300])
