@@ -196,9 +196,15 @@ def test_forward_stages_vs_reference_vectors(ops, golden_fwd):
         torch.cuda.synchronize()
         got = xaq[:M, : mod.rank].float().cpu()
         ref = t("xAq").reshape(M, -1)
-        # a re-quantizer amplifies fp32 summation-order noise into (rare) one-step differences
-        step = (got - ref).abs().max() / ref.abs().max()
-        assert (got != ref).float().mean() <= 0.02 and step <= 2.0 ** -6, name
+        # a re-quantizer turns fp32 summation-order noise into (rare) one-step differences.  The bound that follows from
+        # it (tests/_envelope.py): every product is exact, any summation order lands within D ulps of the exact sum, so each
+        # block of 16 must be the quantizer's image of SOME point of that interval - however few entries differ
+        from _envelope import envelope_check
+
+        s64 = t("xq").reshape(M, K).double().numpy() @ t("A").double().numpy()
+        bad = envelope_check(s64, got.numpy(), 16, 7, max(16.0, K ** 0.5))
+        assert bad == 0, (name, bad)
+        assert (got != ref).float().mean() <= 0.02, name  # and stays close to torch's own order
 
 
 def test_forward_no_side_path(ops, golden_fwd):
