@@ -68,8 +68,46 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
         if (t * 16 + row < g.M) sp_x[t] = *(const bf16x8*)(g.xaq + (int64_t)(t * 16 + row) * g.xaq_ld + 8 * q);
     }
   }
+  auto load_panel = [&](int kt, SmPanel& p, bf16x8 (&x)[MT][2]) {
+    const uint8_t* pp = prow + (int64_t)kt * LQER_PANEL_BYTES;
+    p.cw = *(const u32x4*)(pp + codes_off);
+    p.ex = *(const uint32_t*)(pp + exps_off);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      // token rows beyond M load nothing: the activation image (M x K x 2 B, read by every workgroup from L2) is
+      // the larger stream of this kernel; their output columns are never stored
+      x[t][0] = x[t][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (t * 16 + row < g.M) {
+        const bf16_t* xr = g.xq + (int64_t)(t * 16 + row) * g.Kp + kt * 64 + 8 * q;
+        x[t][0] = *(const bf16x8*)xr;
+        x[t][1] = *(const bf16x8*)(xr + 32);
+      }
+    }
+  };
+  auto compute_panel = [&](const SmPanel& p, const bf16x8 (&x)[MT][2]) {
+    const uint32_t w0 = hi ? p.cw[1] : p.cw[0], w1 = hi ? p.cw[3] : p.cw[2];
+    const bf16x8 wb0 = expand_frag_t<XF16>(w0, ((p.ex >> sh0) & 0xffu) << 23);
+    const bf16x8 wb1 = expand_frag_t<XF16>(w1, ((p.ex >> sh1) & 0xffu) << 23);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      acc[t] = mfma_16x16x32<XF16>(wb0, x[t][0], acc[t]);
+      acc[t] = mfma_16x16x32<XF16>(wb1, x[t][1], acc[t]);
+    }
+  };
+
+  // wave w takes panels w, w + SM_NW, ...; two register buffers of SM_UNR panels keep 2 x SM_UNR panels of loads in flight
+  constexpr int SM_UNR = SmUnr<MT>::v;
+  SmPanel pa[SM_UNR], pb[SM_UNR];
+  bf16x8 xa[SM_UNR][MT][2], xb[SM_UNR][MT][2];
+  const int per_wave = (nk - wave + SM_NW - 1) / SM_NW;  // panels of this wave
+  auto kt_of = [&](int i) { return wave + SM_NW * i; };
+  int i = 0;
+#pragma unroll
+  for (int u = 0; u < SM_UNR; ++u)
+    if (u < per_wave) load_panel(kt_of(u), pa[u], xa[u]);
   if constexpr (LOWRANK) {
     if (from_partials) {
+      // (after the first weight panels have been requested: the partial tiles' round trip passes under the weight stream's)
       // x A = sum over the split-K chunks, ascending (the order of k_xa_reduce4: same bits as the three-launch route),
       // then A_out in blocks of 16 = 4 consecutive lanes; the bf16 image goes to LDS for wave 0's epilogue (it is read
       // after the combine barrier below).  One lane per 4 rank entries; M * rp / 4 <= 1024 items on 512 lanes.
@@ -113,43 +151,6 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
     }
   }
 
-  auto load_panel = [&](int kt, SmPanel& p, bf16x8 (&x)[MT][2]) {
-    const uint8_t* pp = prow + (int64_t)kt * LQER_PANEL_BYTES;
-    p.cw = *(const u32x4*)(pp + codes_off);
-    p.ex = *(const uint32_t*)(pp + exps_off);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      // token rows beyond M load nothing: the activation image (M x K x 2 B, read by every workgroup from L2) is
-      // the larger stream of this kernel; their output columns are never stored
-      x[t][0] = x[t][1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (t * 16 + row < g.M) {
-        const bf16_t* xr = g.xq + (int64_t)(t * 16 + row) * g.Kp + kt * 64 + 8 * q;
-        x[t][0] = *(const bf16x8*)xr;
-        x[t][1] = *(const bf16x8*)(xr + 32);
-      }
-    }
-  };
-  auto compute_panel = [&](const SmPanel& p, const bf16x8 (&x)[MT][2]) {
-    const uint32_t w0 = hi ? p.cw[1] : p.cw[0], w1 = hi ? p.cw[3] : p.cw[2];
-    const bf16x8 wb0 = expand_frag_t<XF16>(w0, ((p.ex >> sh0) & 0xffu) << 23);
-    const bf16x8 wb1 = expand_frag_t<XF16>(w1, ((p.ex >> sh1) & 0xffu) << 23);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      acc[t] = mfma_16x16x32<XF16>(wb0, x[t][0], acc[t]);
-      acc[t] = mfma_16x16x32<XF16>(wb1, x[t][1], acc[t]);
-    }
-  };
-
-  // wave w takes panels w, w + SM_NW, ...; two register buffers of SM_UNR panels keep 2 x SM_UNR panels of loads in flight
-  constexpr int SM_UNR = SmUnr<MT>::v;
-  SmPanel pa[SM_UNR], pb[SM_UNR];
-  bf16x8 xa[SM_UNR][MT][2], xb[SM_UNR][MT][2];
-  const int per_wave = (nk - wave + SM_NW - 1) / SM_NW;  // panels of this wave
-  auto kt_of = [&](int i) { return wave + SM_NW * i; };
-  int i = 0;
-#pragma unroll
-  for (int u = 0; u < SM_UNR; ++u)
-    if (u < per_wave) load_panel(kt_of(u), pa[u], xa[u]);
   for (; i < per_wave; i += 2 * SM_UNR) {
 #pragma unroll
     for (int u = 0; u < SM_UNR; ++u)
