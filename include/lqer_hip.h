@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 5
+#define LQER_ABI_VERSION 6
 
 /* error codes */
 #define LQER_OK 0
@@ -55,6 +55,13 @@ extern "C" {
 
 #define LQER_Q_MXINT_I8 3 /* x_fmt only: block_fp activations with ONE block per row (width <= 8) carried as int8 mantissas and
                             multiplied on the int8 MFMA - needs lqer_i8_prepare to report the weight eligible, see "int8 route" */
+
+#define LQER_Q_INT 4 /* "integer" (reference quantizers/integer.py:10-43): fixed point, clamp(rne(x 2^frac), lo, hi) / 2^frac with
+                        lo, hi = -2^(width-1), 2^(width-1)-1 (signed) or 0, 2^width-1.  Fields: width; exp_bias = frac_width;
+                        exp_width = is_signed (1 / 0); block is ignored.  Implemented for the x, b and A_out quantizers (width
+                        <= 9 signed / 8 unsigned, so that every value is a bf16 number) and in lqer_quantize_mxint; a 4-bit
+                        integer weight (codes -8..7) does not fit the sign-magnitude weight image and B_out needs the
+                        quantizer inside the fused kernels: both return LQER_E_UNSUPPORTED */
 
 /* Geometry of the packed operands (fixed by the kernels; exported so callers can size buffers). */
 #define LQER_K_ALIGN 64     /* K is zero-padded to a multiple of this                        */

@@ -39,6 +39,21 @@ static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
     set_error("%s: LQER_Q_MXINT_I8 is an x_quantizer kind", name);
     return false;
   }
+  if (f->kind == LQER_Q_INT) {  // fixed point: exp_bias = frac_width, exp_width = is_signed
+    const bool role_ok = !strcmp(name, "x_quantizer") || !strcmp(name, "b_quantizer") || !strcmp(name, "A_out_quantizer") ||
+                         !strcmp(name, "quantize_mxint");
+    if (!role_ok) {
+      set_error("%s: the integer quantizer is implemented for x, b and A_out (a 4-bit integer weight has the code -8, which the "
+                "sign-magnitude weight image cannot hold; B_out is quantized inside the fused kernels, block_fp / passthrough only)", name);
+      return false;
+    }
+    const int maxw = f->exp_width ? max_width : max_width - 1;  // unsigned: one magnitude bit more per width
+    if (f->width < 1 || f->width > maxw || f->exp_bias < -100 || f->exp_bias > 100) {
+      set_error("%s: integer width %d outside [1,%d] or frac_width %d outside [-100,100]", name, f->width, maxw, f->exp_bias);
+      return false;
+    }
+    return true;
+  }
   if (f->kind != LQER_Q_MXINT && f->kind != LQER_Q_MXINT_I8) {
     set_error("%s: quantizer kind %d is not implemented on the HIP path", name, f->kind);
     return false;
@@ -148,8 +163,8 @@ int lqer_quantize_mxint(const void* x, int dtype, int64_t rows, int64_t cols, in
     return LQER_E_INVALID;
   }
   if (!fmt_ok(fmt, "quantize_mxint", 24)) return LQER_E_UNSUPPORTED;
-  if (fmt->kind != LQER_Q_MXINT) {
-    set_error("quantize_mxint: format is not MXINT");
+  if (fmt->kind != LQER_Q_MXINT && fmt->kind != LQER_Q_INT) {
+    set_error("quantize_mxint: format is neither block_fp nor integer");
     return LQER_E_INVALID;
   }
   if (codes && fmt->width > 8) {
@@ -174,8 +189,8 @@ int lqer_quantize_act_mxint(const void* x, int dtype, int64_t M, int64_t K, int6
     return LQER_E_INVALID;
   }
   if (!fmt_ok(fmt, "x_quantizer", 9)) return LQER_E_UNSUPPORTED;
-  if (fmt->kind != LQER_Q_MXINT) {
-    set_error("x_quantizer: only block_fp activations are implemented on the HIP path");
+  if (fmt->kind != LQER_Q_MXINT && fmt->kind != LQER_Q_INT) {
+    set_error("x_quantizer: only block_fp and integer activations have a bf16 image on the HIP path");
     return LQER_E_UNSUPPORTED;
   }
   QP q = make_qp(*fmt);

@@ -20,7 +20,13 @@ struct QP {
   int mbits;  // width - 1
   int block;  // elements per shared exponent; <=0 = whole row
   int emin, emax;
-  float mmax;  // 2^mbits - 1
+  float mmax;  // 2^mbits - 1 (integer kind: the upper clamp)
+  // what distinguishes "integer" (fixed point, LQER_Q_INT) from block_fp in the shared element routine: no +1e-9, no
+  // pass-through of |x| <= 1e-8, a two's-complement range (the negative clamp is one step larger), a fixed exponent
+  float mneg;  // magnitude of the negative clamp (block_fp: = mmax)
+  float eps;   // added to |x| before scaling (block_fp.py:57: 1e-9; integer: 0)
+  float tiny;  // |x| <= tiny is not quantized (block_fp.py:79-80: 1e-8; integer: -1 = never)
+  int width;   // bits per element incl. sign
 };
 
 __host__ inline QP make_qp(const lqer_qfmt_t& f) {
@@ -31,6 +37,16 @@ __host__ inline QP make_qp(const lqer_qfmt_t& f) {
   q.emin = -f.exp_bias;
   q.emax = (1 << f.exp_width) - 1 - f.exp_bias;
   q.mmax = (float)((1 << (f.width - 1)) - 1);
+  q.mneg = q.mmax, q.eps = 1e-9f, q.tiny = 1e-8f, q.width = f.width;
+  if (f.kind == LQER_Q_INT) {  // value = m 2^-frac: "exponent" pinned to 0, mbits = frac_width
+    const bool is_signed = f.exp_width != 0;
+    q.mbits = f.exp_bias;
+    q.block = -1;
+    q.emin = q.emax = 0;
+    q.mmax = is_signed ? (float)((1 << (f.width - 1)) - 1) : (float)((1u << f.width) - 1);
+    q.mneg = is_signed ? (float)(1 << (f.width - 1)) : 0.0f;
+    q.eps = 0.0f, q.tiny = -1.0f;
+  }
   return q;
 }
 
@@ -106,11 +122,13 @@ __device__ __forceinline__ int block_exponent(float amax, const QP& q) {
 // Signed mantissa of one element given its block exponent (block_fp.py:55-65):
 //   m = min(rne((|x| + 1e-9) / 2^e * 2^mbits), 2^mbits - 1), sign from x.
 // |x| <= 1e-8 is the reference's pass-through (block_fp.py:79-80); packed images flush it to 0.
+// (integer kind, quantizers/integer.py:37-40: clamp(rne(x 2^frac), lo, hi) - the same routine with eps = 0, tiny = -1 and
+// the two's-complement negative clamp)
 __device__ __forceinline__ float mxint_mantissa(float x, int e, const QP& q) {
-  const float v = fabsf(x) + 1e-9f;
+  const float v = fabsf(x) + q.eps;
   const float t = ldexpf(v, q.mbits - e);
-  const float m = fminf(rintf(t), q.mmax);
-  return fabsf(x) <= 1e-8f ? 0.0f : copysignf(m, x);
+  const float m = fminf(rintf(t), x < 0.0f ? q.mneg : q.mmax);
+  return fabsf(x) <= q.tiny ? 0.0f : copysignf(m, x);
 }
 
 // The bf16 image of 16 values that share the block exponent e, in packed-fp32 arithmetic (v_pk_add/fma/mul_f32: two

@@ -555,9 +555,10 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
   const float* rowscale = x_i8 ? i8_row_scales(xq, M, K) : nullptr;
   const int rp = (int)lqer_padded_r(r);
   const bool pass = q.kind == LQER_Q_PASSTHROUGH;
-  if (pass ? (xa_limbs != 2 && xa_limbs != 3) : (q.kind != LQER_Q_MXINT || q.mbits > 8)) {
-    set_error("A_out_quantizer must be block_fp with width <= 9, or passthrough with 2 or 3 limbs, on the HIP path (got "
-              "kind %d width %d)", q.kind, q.mbits + 1);
+  const bool fixed = q.kind == LQER_Q_INT;  // (integer: the reduce pass quantizes with the pinned exponent, common.h)
+  if (pass ? (xa_limbs != 2 && xa_limbs != 3) : !((q.kind == LQER_Q_MXINT && q.mbits <= 8) || (fixed && q.mmax <= 256.f && q.mneg <= 256.f))) {
+    set_error("A_out_quantizer must be block_fp or integer with codes up to 256 (a bf16 image), or passthrough with 2 or 3 limbs, on "
+              "the HIP path (got kind %d width %d)", q.kind, q.width);
     return LQER_E_UNSUPPORTED;
   }
   const int L = pass ? 4 : ((q.block <= 0 || q.block >= rp) ? rp : q.block);

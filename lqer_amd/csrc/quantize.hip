@@ -204,11 +204,51 @@ __global__ __launch_bounds__(256) void k_quant_blk(const void* __restrict__ x, i
   }
 }
 
+// "integer" (fixed point, reference quantizers/integer.py:10-43): elementwise, one lane per 16 elements - no shared
+// exponent, so no reduction.  Every image of the block_fp kernels: fp32 values, int8 codes (width <= 8), the bf16 image
+// (|code| <= 256) - and the "exponent" output holds -frac_width, one entry per row (value = code 2^exponent).
+template <int DT>
+__global__ __launch_bounds__(256) void k_quant_int(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t ld, QP q,
+                                                   QuantOut o) {
+  const int64_t segs = o.xq ? o.cols_p / 16 : (cols + 15) / 16;
+  const int64_t total = rows * segs;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / segs;
+    const int64_t k0 = (idx - row * segs) * 16;
+    float v[16], m[16];
+    load16<DT, false>(x, row * ld, k0, cols, v);  // (elements past `cols` read as 0 -> code 0)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = mxint_mantissa(v[i], 0, q);
+    if (o.xq) {
+      uint32_t w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        w[i] = exact_bf16_bits(ldexpf(m[2 * i], -q.mbits)) | (exact_bf16_bits(ldexpf(m[2 * i + 1], -q.mbits)) << 16);
+      uint4* dst = (uint4*)(o.xq + row * o.cols_p + k0);
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (k0 + i < cols) {
+        if (o.deq) o.deq[row * cols + k0 + i] = ldexpf(m[i], -q.mbits);
+        if (o.codes) o.codes[row * cols + k0 + i] = (int8_t)(int)m[i];
+      }
+    if (o.exps && k0 == 0) o.exps[row * o.nblk] = (int8_t)(-q.mbits < -128 ? -128 : -q.mbits);  // (one "block" per row)
+  }
+}
+
 template <int DT>
 static int launch_quant(const void* x, int64_t rows, int64_t cols, int64_t ld, const QP& q, const QuantOut& o,
                         hipStream_t st) {
   if (rows == 0 || cols == 0) return LQER_OK;
   const int64_t width = o.xq ? o.cols_p : cols;
+  if (q.kind == LQER_Q_INT) {
+    const int64_t total = rows * ((width + 15) / 16);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 1 << 20 ? (total + 255) / 256 : 1 << 20);
+    k_quant_int<DT><<<grid, 256, 0, st>>>(x, rows, cols, ld, q, o);
+    return check_launch("quantize (integer)");
+  }
   const bool whole = q.block <= 0 || q.block >= cols;
   if (whole) {
     const int esz0 = DT == LQER_F32 ? 4 : 2;

@@ -1,0 +1,100 @@
+"""The reference's `integer` quantizer (quantizers/integer.py:10-43, fixed point) on the HIP path: the standalone quantizer
+against the vectors generated from the reference, the bf16 activation image, and a Linear forward whose x / bias / A_out
+quantizers are integer against the oracle.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lqer_oracle as O  # the checker
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from lqer_amd import ops as _ops
+
+    return _ops
+
+
+def _tags(golden_q):
+    return sorted({k.split("/")[1] for k in golden_q.files if k.startswith("int/")})
+
+
+def test_integer_quantizer_bit_exact_vs_reference_vectors(ops, golden_q):
+    tags = _tags(golden_q)
+    assert tags, "no integer vectors in tests/golden/quantizers.npz"
+    for tag in tags:
+        width, frac = int(tag[1:].split("f")[0]), int(tag.split("f")[1])
+        x = torch.from_numpy(golden_q[f"int/{tag}/x"])
+        ref = torch.from_numpy(golden_q[f"int/{tag}/y"])
+        fmt = ops.make_qfmt(dict(name="integer", width=width, frac_width=frac), "x")
+        want = ("deq", "codes", "exps") if width <= 8 else ("deq",)
+        out = ops.quantize_mxint(x.to(DEV), fmt, want=want)
+        assert torch.equal(out["deq"].cpu().reshape(ref.shape), ref), tag
+        if width <= 8:
+            codes = out["codes"].cpu().reshape(ref.shape).float()
+            assert torch.equal(codes * 2.0 ** -frac, ref), tag
+            assert codes.min() >= -(2 ** (width - 1)) and codes.max() <= 2 ** (width - 1) - 1
+            assert (out["exps"].cpu() == -frac).all()
+        for dt in (torch.float16, torch.bfloat16):  # 16-bit inputs: the same arithmetic on the upcast values
+            xh = x.to(dt)
+            got = ops.quantize_mxint(xh.to(DEV), fmt, want=("deq",))["deq"].cpu().reshape(ref.shape)
+            assert torch.equal(got, O.integer_quantize(xh.float(), width, frac)), (tag, dt)
+
+
+def test_integer_edge_cases(ops):
+    """Clamp at both ends of the two's-complement range, round-half-to-even, unsigned range, negative frac_width."""
+    x = torch.tensor([[-200.0, -8.03125, -8.0, -7.96875, -0.09375, -0.03125, 0.0, 0.03125, 0.09375, 0.15625, 7.9, 7.96875, 8.0, 500.0,
+                       1e-9, -1e-9, 3.0]])
+    for cfg in (dict(width=8, frac_width=4), dict(width=8, frac_width=4, is_signed=False), dict(width=4, frac_width=-2),
+                dict(width=9, frac_width=0)):
+        fmt = ops.make_qfmt(dict(name="integer", **cfg), "x")
+        xs = x * (64.0 if cfg["frac_width"] < 0 else 1.0)
+        got = ops.quantize_mxint(xs.to(DEV), fmt, want=("deq",))["deq"].cpu()
+        assert torch.equal(got, O.integer_quantize(xs, **cfg)), cfg
+
+
+def test_integer_activation_image(ops, golden_q):
+    x = torch.from_numpy(golden_q["int/w8f4/x"])
+    ref = torch.from_numpy(golden_q["int/w8f4/y"])
+    x2, r2 = x.reshape(-1, x.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    fmt = ops.make_qfmt(dict(name="integer", width=8, frac_width=4), "x")
+    img = ops.quantize_act(x2.to(DEV), fmt)
+    M, K = x2.shape
+    assert torch.equal(img[:M, :K].float().cpu(), r2)
+    assert not img[:M, K:].float().any()  # K padding zeroed
+
+
+@pytest.mark.parametrize("M,K,N,r,bias", [(7, 96, 80, 16, True), (300, 512, 384, 32, True), (2048, 1024, 512, 32, False)])
+def test_forward_with_integer_quantizers_vs_oracle(ops, M, K, N, r, bias):
+    """x, bias and A_out through the integer quantizer (B_out given explicitly: block_fp), every kernel size class."""
+    import lqer_amd
+    from bench import _bfp, make_case
+
+    iq = dict(name="integer", width=8, frac_width=4)
+    qc = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=iq, w_quantizer=_bfp(4, [1, 16], False),
+              b_quantizer=dict(name="integer", width=8, frac_width=6), A_out_quantizer=dict(name="integer", width=9, frac_width=3),
+              B_out_quantizer=_bfp(8, [1, 16], True))
+    case = make_case(M, K, N, r, seed=11, bias=bias)
+    x, W, A, B = case[:4]
+    b = case[4] if bias else None
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = b
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV)
+    y = mod(x.to(DEV)).cpu()
+    ref = O.lqer_linear_forward(x, W, b, A, B, qc)
+    err = float((y - ref).norm() / ref.norm())
+    assert err <= 1e-5, err
+    if bias:  # like the reference, the bias parameter now holds the quantized values
+        assert torch.equal(mod.bias.detach().cpu(), O.integer_quantize(b, 8, 6))
+    # the default B_out (= the x quantizer, linear.py:115-119) would be integer: refused at construction, never approximated
+    with pytest.raises(NotImplementedError):
+        lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config={k: v for k, v in qc.items() if k != "B_out_quantizer"}, l_config={"rank": r})

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""A/B timing of the whole step (lqer_quantize_act_xa + lqer_linear_gemm: activation quantizer, side GEMM, reduce pass, fused
+GEMM - what bench.py times) across several builds of the library in ONE process, interleaved rounds.
+    python tools/ab_step.py [--M 2048 --K 4096 --N 4096 --r 32] lib_a.so lib_b.so ...
+Operands as in tools/ab_gemm.py (random 4-bit codes, gaussian fp16 activations); results are not checked here."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lqer_amd import _lib  # noqa: E402
+from tools.ab_gemm import load  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="+")
+    ap.add_argument("--M", type=int, default=2048)
+    ap.add_argument("--K", type=int, default=4096)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--r", type=int, default=32)
+    ap.add_argument("--rounds", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=40)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    M, K, N, r = a.M, a.K, a.N, a.r
+    Kp, Np, Mp, rp = (K + 63) // 64 * 64, (N + 255) // 256 * 256, (M + 255) // 256 * 256, (r + 15) // 16 * 16
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(M, K, generator=g).half().to(dev)
+    xq = torch.empty(Mp, Kp, dtype=torch.bfloat16, device=dev)
+    wp = torch.randint(0, 256, ((Np // 16) * (Kp // 64) * 576,), generator=g, dtype=torch.uint8)
+    wv = wp.view(-1, 576)
+    wv[:, 512:] = torch.randint(0, 3, (wv.shape[0], 64), generator=g, dtype=torch.uint8) + 250
+    wp = wp.to(dev)
+    xaq = torch.empty(Mp, rp, dtype=torch.bfloat16, device=dev)
+    at = (0.01 * torch.randn(3 * rp * Kp, generator=g)).to(torch.bfloat16).to(dev)
+    bt = (0.1 * torch.randn(3 * Np * rp, generator=g)).to(torch.bfloat16).to(dev)
+    y = torch.empty(M, N, dtype=torch.float16, device=dev)
+    f8 = _lib.QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
+    f4 = _lib.QFmt(_lib.Q_MXINT, 4, 16, 8, 127)
+    desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
+    libs = [(p, load(p)) for p in a.libs]
+    st = torch.cuda.current_stream().cuda_stream
+    nscr = libs[0][1].lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
+    scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
+
+    def run(L):
+        rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xaq.data_ptr(),
+                                    scr.data_ptr(), nscr, st)
+        assert rc == 0, L.lqer_last_error()
+        rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(),
+                                _lib.F16, N, scr.data_ptr(), nscr, st)
+        assert rc == 0, L.lqer_last_error()
+
+    times = {p: [] for p, _ in libs}
+    for p, L in libs:
+        for _ in range(10):
+            run(L)
+    torch.cuda.synchronize()
+    for _ in range(a.rounds):
+        for p, L in libs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run(L)
+            e1.record()
+            torch.cuda.synchronize()
+            times[p].append(e0.elapsed_time(e1) / a.iters * 1e3)
+    fl = 2.0 * M * K * N + 2.0 * M * K * r + 2.0 * M * r * N
+    for p, _ in libs:
+        t = sorted(times[p])
+        med, mn = t[len(t) // 2], t[0]
+        print(f"{os.path.basename(p):28s} median {med:8.2f} us  min {mn:8.2f} us per step  {fl / med / 1e6:8.1f} TFLOP/s-equiv (median)")
+
+
+if __name__ == "__main__":
+    main()
