@@ -188,8 +188,9 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
                                                  int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs, int64_t S2p, int64_t Kp,
                                                  QP q, bool vec) {
-  __shared__ __attribute__((aligned(16))) unsigned char sa[BM * BK * 2];  // x tile, quantized: 128 rows x 128 B
-  __shared__ __attribute__((aligned(16))) unsigned char sb[BN * BK * 2];  // image tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BM * BK * 2 + BN * BK * 2];
+  unsigned char* const sa = smem;                // x tile, quantized: 128 rows x 128 B
+  unsigned char* const sb = smem + BM * BK * 2;  // image tile (after the loop the 32 KiB hold the 16-bit output tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
   const int64_t b = blockIdx.z, i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
@@ -259,14 +260,16 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
   // ---- store: lane = output row, register r of tile (a, c): column (r & 3) + 8 (r >> 2) + 4 lh
   const int esz = DT == LQER_F32 ? 4 : 2;
   const bool aligned = (((uintptr_t)out) & 15) == 0 && (S2 * esz) % 16 == 0;
+  const bool staged = DT != LQER_F32 && aligned && j0 + BN <= S2;  // workgroup-uniform
+  if (staged) __syncthreads();  // the last chunk's fragment reads are done: the tiles' LDS is free
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int64_t i = i0 + wm * 64 + c * 32 + l31;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int64_t jb = j0 + wn * 64 + a * 32;
-      if (i >= S1) continue;
       if constexpr (DT == LQER_F32) {
+        if (i >= S1) continue;
         float* dst = (float*)out + (b * S1 + i) * S2;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
@@ -280,32 +283,64 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
           }
         }
       } else {
-        bf16_t* dst = (bf16_t*)out + (b * S1 + i) * S2;
+        // 16-bit outputs: pack 4 columns into 8 B, then merge quads (2p, 2p+1) of lanes l / l^32 into one 16-byte store
+        // (gemm_w4a8.hip's store): lanes 0-31 write columns 16p .. 16p+7, lanes 32-63 columns 16p+8 .. 16p+15 - the output
+        // is the large stream of Q K^T (S1 x S2 per head)
+        uint32_t pk[4][2];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int64_t j = jb + 8 * qd + 4 * lh;
-          uint32_t pk[2];
+        for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const float v0 = acc[a][c][4 * qd + 2 * h], v1 = acc[a][c][4 * qd + 2 * h + 1];
             if constexpr (DT == LQER_F16) {
               typedef __attribute__((ext_vector_type(2))) _Float16 h2;
               const h2 hv = {(_Float16)v0, (_Float16)v1};
-              pk[h] = __builtin_bit_cast(uint32_t, hv);
+              pk[qd][h] = __builtin_bit_cast(uint32_t, hv);
             } else {
-              pk[h] = (uint32_t)f32_to_bf16_rne(v0) | ((uint32_t)f32_to_bf16_rne(v1) << 16);
+              pk[qd][h] = (uint32_t)f32_to_bf16_rne(v0) | ((uint32_t)f32_to_bf16_rne(v1) << 16);
             }
           }
-          if (aligned && j + 3 < S2) {
-            *(uint2*)(dst + j) = make_uint2(pk[0], pk[1]);
-          } else {
-            if (j < S2) dst[j] = (bf16_t)(pk[0] & 0xffff);
-            if (j + 1 < S2) dst[j + 1] = (bf16_t)(pk[0] >> 16);
-            if (j + 2 < S2) dst[j + 2] = (bf16_t)(pk[1] & 0xffff);
-            if (j + 3 < S2) dst[j + 3] = (bf16_t)(pk[1] >> 16);
+        bf16_t* dst = (bf16_t*)out + (b * S1 + i) * S2;
+        const bool wide = aligned && jb + 32 <= S2;  // wave-uniform
+        if (staged) {
+          // whole tile inside the output: the 16-byte pieces go to LDS (row-major 256 B per row, chunks XOR-ed with the row
+          // so that the 32 rows of a wave's store spread over the banks) and leave as full 256-byte row segments below
+          const int row_l = wm * 64 + c * 32 + l31;
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+            const int chunk = (wn * 64 + a * 32 + 16 * p2 + 8 * lh) >> 3;
+            *(uint4*)(smem + row_l * 256 + ((chunk ^ (row_l & 15)) << 4)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          }
+        } else if (wide) {
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+            if (i < S1) *(uint4*)(dst + jb + 16 * p2 + 8 * lh) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          }
+        } else if (i < S1) {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int64_t j = jb + 8 * qd + 4 * lh;
+            if (j < S2) dst[j] = (bf16_t)(pk[qd][0] & 0xffff);
+            if (j + 1 < S2) dst[j + 1] = (bf16_t)(pk[qd][0] >> 16);
+            if (j + 2 < S2) dst[j + 2] = (bf16_t)(pk[qd][1] & 0xffff);
+            if (j + 3 < S2) dst[j + 3] = (bf16_t)(pk[qd][1] >> 16);
           }
         }
       }
+    }
+  }
+  if (staged) {
+    __syncthreads();
+    bf16_t* const ob = (bf16_t*)out + (b * S1) * S2 + j0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // 16 consecutive lanes = one row of the tile: 256 contiguous bytes
+      const int idx = tid + 256 * u, row_l = idx >> 4, chunk = idx & 15;
+      const uint4 v = *(const uint4*)(smem + row_l * 256 + ((chunk ^ (row_l & 15)) << 4));
+      if (i0 + row_l < S1) *(uint4*)(ob + (i0 + row_l) * S2 + chunk * 8) = v;
     }
   }
 }
