@@ -11,6 +11,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:  # another build of the library (e.g. -DLQER_I8_T16=0), bound before anything loads it
+    from lqer_amd import _lib as _l
+
+    _l.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 import lqer_amd  # noqa: E402
 from bench import INT_Q, _bfp, make_case  # noqa: E402
 from lqer_amd import _lib, ops  # noqa: E402
@@ -25,6 +29,7 @@ def main():
     ap.add_argument("--wblock", type=int, default=128)
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--lib", default=None, help="path of another build of liblqer_hip.so")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, K, N, r = a.M, a.K, a.N, a.r
