@@ -287,20 +287,38 @@ def main():
         if L.lqer_decode_partials(C.byref(desc), M):
             xaq, gscr = None, nscr  # decode route: the GEMM reduces the partial tiles of x A left in the scratch itself
         plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=p["a_t"].data_ptr(), a_limbs=p["a_limbs"], xq=xq, xaq=xaq,
+                          ws=ws.data_ptr(), ws_bytes=ws.numel(),
                           xscr=xscr, nscr=nscr, w=p["w"].data_ptr(),
                           b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),
                           gscr=gscr, K=K, N=N, reps=reps, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16)))
+
+    # M <= 8 with block_fp activations in blocks of 16: lqer_linear_forward issues ONE launch (not inside a captured graph)
+    one_launch = (M <= 8 and not args.graph and r > 0 and
+                  all(L.lqer_decode_partials(pl["dref"], M) and pl["a_limbs"] == 1 for pl in plans))
 
     def step(timed: bool, stream=stream):
         for pl in plans:
             K, N = pl["K"], pl["N"]
             for _ in range(pl["reps"]):
+                ev = timed and launch_no[0] % EV_EVERY == 0  # counts timed launches only: the first one is always sampled
+                launch_no[0] += int(timed)
+                if one_launch:
+                    # up to 8 tokens the whole forward is ONE launch (csrc/decode1.hip) behind lqer_linear_forward - the entry
+                    # point of INTEGRATION.md; the events bracket that launch
+                    if ev:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    _lib.check(L.lqer_linear_forward(pl["dref"], pl["x"], _lib.F16, M, K, pl["w"], pl["a_t"], pl["b_t"], pl["a_limbs"],
+                                                     pl["b_limbs"], pl["bias"], pl["y"], N, pl["ws"], pl["ws_bytes"], stream),
+                               "linear_forward")
+                    if ev:
+                        e1.record()
+                        gemm_events.append((e0, e1, K, N))
+                    continue
                 # the two calls of lqer_linear_forward, issued separately so that the dominant kernel can be
                 # bracketed with HIP events on the launch stream
                 _lib.check(L.lqer_quantize_act_xa(pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"],
                                                   pl["xq"], pl["xaq"], pl["xscr"], pl["nscr"], stream), "quantize_act_xa")
-                ev = timed and launch_no[0] % EV_EVERY == 0  # counts timed launches only: the first one is always sampled
-                launch_no[0] += int(timed)
                 if ev:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -423,7 +441,7 @@ def main():
             n_launch += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         routes = sorted({pl["route"] for pl in plans})
-        kname = {_lib.ROUTE_SMALLM: "k_lqer_gemm_smallm", _lib.ROUTE_TILE128: "k_lqer_gemm", _lib.ROUTE_TILE256: "k_lqer_gemm_m256",
+        kname = {_lib.ROUTE_SMALLM: "k_decode1 (whole forward)" if one_launch else "k_lqer_gemm_smallm", _lib.ROUTE_TILE128: "k_lqer_gemm", _lib.ROUTE_TILE256: "k_lqer_gemm_m256",
                  _lib.ROUTE_TILE256_I8: "k_lqer_gemm_i8"}
         int8 = routes == [_lib.ROUTE_TILE256_I8]  # every GEMM of the step ran the int8 MFMA main loop
         peak = INT8_MFMA_PEAK_TOPS if int8 else BF16_MFMA_PEAK_TFLOPS
@@ -449,6 +467,8 @@ def main():
             for _, _, K, N in gemm_events:
                 Kp, Np, rp = -(-K // 64) * 64, -(-N // 256) * 256, -(-r // 16) * 16
                 tot_by += Np * Kp * 0.5625 + Np * rp * 2 + M * Kp * 2 + M * rp * 2 + M * N * 2 + (Np * 4 if has_bias else 0)  # (one copy of every image: algorithmic)
+                if one_launch:
+                    tot_by += rp * Kp * 2  # the whole forward: A^T as well (x in place of its image: the same bytes)
             gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
@@ -472,7 +492,9 @@ def main():
                            "MXINT8/%s" % qc["x_quantizer"]["block_size"][-1] if qc["x_quantizer"]["name"] == "block_fp"
                            else ("fp16 pass-through (fp16 MFMA main loop)" if mods[0][0]._x_f16 else "fp16 pass-through (2 bf16 limbs)"),
                            qc["w_quantizer"]["block_size"][-1]),
-                       "boundary": "C ABI (lqer_quantize_act_xa + lqer_linear_gemm per Linear, pre-built plans); the nn.Module figure is in `module`",
+                       "boundary": ("C ABI (lqer_linear_forward per Linear: one launch)" if one_launch else
+                                    "C ABI (lqer_quantize_act_xa + lqer_linear_gemm per Linear, pre-built plans)") +
+                                   "; the nn.Module figure is in `module`",
                        "sharding": ("decoder layers split over the ranks, ceil(L/G) consecutive layers each (infer_device_map.py:29-37)"
                                     if strong else "every rank runs its own Linear unit(s) of the workload") +
                                    "; x broadcast from rank 0 and per-rank results gathered outside the timed region, no data-path collective",

@@ -14,7 +14,8 @@
  *    current (hipSetDevice) before the call - the Python mirror does (lqer_amd/linear.py, ops.py);
  *  - the caller owns every buffer (incl. workspace); the library never allocates, frees or
  *    retains pointers, and is re-entrant (its only process-wide state are std::once_flag-guarded, idempotent kernel
- *    attribute settings and the thread-local error text);
+ *    attribute settings, one atomic call counter - the tag of the one-launch decode route, see lqer_linear_forward - and
+ *    the thread-local error text);
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  *    stream) and performs no host synchronisation, so calls may be captured in a hipGraph;
  *  - return value 0 = success, <0 = error (LQER_E_*); lqer_last_error() gives the text of the
@@ -173,6 +174,17 @@ int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype
                         int64_t ldx, const void* w_packed, const void* a_t, const void* b_t,
                         int a_limbs, int b_limbs, const float* bias_q, void* y, int64_t ldy,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Up to 8 tokens (block_fp activations in blocks of 16, A_out in blocks of 16, padded rank <= 64, one limb of A, B_out
+ * pass-through or in blocks of 16 - lqer_decode_partials - and 16-byte aligned rows of x) lqer_linear_forward issues ONE
+ * launch (csrc/decode1.hip): producer workgroups publish the split-K partial tiles of x A as {value, tag} granules in the
+ * workspace, the weight-streaming workgroups quantize x themselves and read the tiles at their very end.  The tag is a
+ * per-call value from a process-wide atomic counter - the library's only mutable state besides the thread-local error
+ * text -, which is why a call under stream capture keeps the two-launch route (a replayed graph would carry the captured
+ * tag).  The wait for the tiles is bounded; a workgroup that does not see them computes them itself (same bits). */
+
+/* test hook: poll sweeps of that wait before the fall-back (0 = every workgroup computes the tiles itself; < 0 = default) */
+int lqer_debug_set_decode_spin(int sweeps);
 
 /* The same, split for callers that share one quantized activation between several Linears
  * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */

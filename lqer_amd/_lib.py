@@ -68,6 +68,7 @@ SIGNATURES = {
     "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "lqer_decode_partials": (_i, [_dp, _i64]),
+    "lqer_debug_set_decode_spin": (_i, [_i]),
     "lqer_gemm_route": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),

@@ -533,8 +533,36 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   if (dtype == LQER_F16 && f16_image_is_input(d, x, M, ldx)) xq = const_cast<void*>(x);  // no copy (never written)
   void* xaq = ws + align_up(Mp * Kp * 2 * xl, 256);
   void* xa_scratch = ws + align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256);
-  if (decode_partials_ok(d, M) && a_t && b_t) {  // two launches: the GEMM sums the partial tiles of x A itself
+  if (decode_partials_ok(d, M) && a_t && b_t) {
     const size_t nscr = lqer_lowrank_xa_scratch_bytes(d, M);
+#ifndef LQER_NO_DECODE1
+    // up to 8 tokens: ONE launch (decode1.hip) - producer workgroups publish the partial tiles of x A, the weight-streaming
+    // workgroups quantize x themselves and pick the tiles up at their very end
+    const int esz = dtype == LQER_F32 ? 4 : 2;
+    // (not under stream capture: the granule tag is a per-call nonce, and a replayed graph would carry the captured one -
+    // a replay could then accept the previous replay's tiles; captured forwards keep the two-launch route)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
+    if (cap == hipStreamCaptureStatusNone && M <= 8 && a_limbs == 1 && !x_is_f16(d) && ((uintptr_t)x & 15) == 0 &&
+        (ldx * esz) % 16 == 0 && b_limbs >= 1 && b_limbs <= 3) {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      rc = gemm_shape_args(d, M, dtype, g);
+      if (rc) return rc;
+      g.wp = (const uint8_t*)w_packed;
+      g.bt = (const bf16_t*)b_t;
+      g.bias = d->has_bias ? bias_q : nullptr;
+      g.y = y;
+      g.ldy = ldy;
+      g.b_limbs = b_limbs;
+      g.aout = make_qp(d->a_out_fmt);
+      const int bout = d->b_out_fmt.kind == LQER_Q_PASSTHROUGH ? 0 : 1;  // (decode_partials_ok: pass-through or blocks of 16)
+      rc = decode1_dispatch(g, dtype, x, ldx, d->in_features, make_qp(d->x_fmt), (const bf16_t*)a_t, bout, xa_scratch, nscr,
+                            (hipStream_t)stream);
+      if (rc != LQER_E_UNSUPPORTED) return rc;
+    }
+#endif
+    // two launches: the GEMM sums the partial tiles of x A itself
     rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, nullptr, xa_scratch, nscr, stream);
     if (rc) return rc;
     return lqer_linear_gemm(d, xq, M, w_packed, nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch, nscr, stream);

@@ -368,6 +368,11 @@ int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipSt
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 
+// decode1.hip: the whole forward of M <= 8 tokens in one launch (LQER_E_UNSUPPORTED without launching when outside its shapes)
+size_t decode1_scratch_bytes(int64_t Kp, int rp);
+int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, const QP& qx, const bf16_t* a_t, int bout, void* scratch,
+                     size_t scratch_bytes, hipStream_t st);
+
 size_t qmatmul_workspace_bytes(int64_t batch, int64_t K, int64_t S2);  // matmul_q.hip
 int qmatmul_dispatch(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs,
                      int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const QP& qx, const QP& qy, void* workspace, hipStream_t st);

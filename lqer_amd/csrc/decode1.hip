@@ -1,0 +1,497 @@
+// The whole forward of a decode-size Linear (M <= 8 tokens) in ONE launch:
+//
+//   y = Q_x(x) Wq^T + bq + Q_Bout( Q_Aout( Q_x(x) A ) B )        (reference quantized_layers/linear.py:145-157)
+//
+// The two-launch decode route (k_quant_xa16 -> k_lqer_gemm_smallm) is bound by two kernel latencies and the boundary
+// between them (11 us at M = 1 for 9.4 MB of weights).  Here one grid holds two kinds of workgroups:
+//   * producers (blocks 0 .. np-1, one per 256 k of K): quantize their slab of x, multiply it with the slab of A
+//     (v_mfma_f32_16x16x32_bf16, the 8 waves' tiles summed in a fixed order) and publish the partial tile of x A as 8-byte
+//     {value, tag} granules - one write-through (sc1) store each, the tag is this call's nonce: no flag, no counter, nothing
+//     to reset (MI355X_MICROARCH.md, hand-off price list: data-tagged granules);
+//   * consumers (one per 16 output columns, as in gemm_smallm.hip): request their first weight panels, quantize ALL of x
+//     into an LDS image themselves (M x K <= 8 x 4096 elements: cheaper than waiting for another kernel), stream their
+//     packed weight rows through the MFMA, and only at the very end read the producers' granules (sc1 loads, polled until
+//     the tags match), sum them in ascending slab order, apply A_out and run the side path epilogue of gemm_smallm.hip.
+// No workgroup ever waits for a consumer, producers wait for nobody, and the poll is bounded: if a granule has not arrived
+// after QD1_SPIN sweeps (it has, in practice, long before a consumer asks - producers are the first blocks of the grid and
+// finish in ~2 us) the consumer workgroup computes every partial tile itself with the producers' own routine (same bits)
+// and goes on: every wave reaches the end of the kernel whatever the dispatch order.
+#include <atomic>
+#include <type_traits>
+
+#include "common.h"
+
+namespace lqer {
+namespace d1 {
+
+constexpr int NW = 8;          // waves per workgroup
+constexpr int MAXM = 8;        // token rows
+constexpr int SLAB_K = 256;    // k per producer
+constexpr int MAXNT = 4;       // rank tiles of 16 (padded rank <= 64)
+#ifndef LQER_QD1_SPIN
+#define LQER_QD1_SPIN 4096
+#endif
+// LDS (dynamic): [xs image: M x Kp bf16][red 7 KiB][xaq 1 KiB][pslab 4 KiB][pred 28 KiB]
+constexpr int RED_BYTES = (NW - 1) * 4 * 64 * 4;
+constexpr int XAQ_BYTES = MAXM * 64 * 2;
+constexpr int PSLAB_BYTES = MAXM * SLAB_K * 2;
+constexpr int PRED_BYTES = (NW - 1) * MAXNT * 4 * 64 * 4;
+
+#ifdef LQER_D1_STAMPS
+__device__ unsigned long long* g_d1_stamps = nullptr;  // diagnostic build: s_memrealtime (100 MHz) at the phases of every workgroup
+#define D1_STAMP(i)                                                                                            \
+  do {                                                                                                         \
+    unsigned long long t_;                                                                                     \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+    if (g_d1_stamps && tid == 0) g_d1_stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                \
+  } while (0)
+#else
+#define D1_STAMP(i)
+#endif
+
+struct Args {
+  GemmArgs g;          // the consumer side: wp, bt, bias, y, ldy, M, N, Np, Kp, rp, b_limbs, aout, bout
+  const void* x;       // [M, K] tokens, row stride ldx
+  int64_t ldx;
+  int K;
+  QP qx;
+  const bf16_t* a_t;   // A^T bf16 image [rp][Kp] (one limb)
+  uint32_t* gran;      // granules [np][MAXM][rp] x {value, tag}
+  uint32_t nonce;
+  int np;              // producers = ceil(Kp / 256)
+  int spin;            // poll sweeps before a consumer computes the tiles itself
+};
+
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+
+struct SmPanel {
+  u32x4 cw;
+  uint32_t ex;
+};
+
+template <int DT>
+__device__ __forceinline__ void load_block16(const void* x, int64_t off, float (&v)[16]) {
+  if constexpr (DT == LQER_F32) {
+    const float4* p = (const float4*)((const float*)x + off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = p[i];
+      v[4 * i] = t.x, v[4 * i + 1] = t.y, v[4 * i + 2] = t.z, v[4 * i + 3] = t.w;
+    }
+  } else {
+    const uint4* p = (const uint4*)((const bf16_t*)x + off);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint4 t = p[i];
+      const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (DT == LQER_F16) {
+          typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+          const h2 h = __builtin_bit_cast(h2, w[j]);
+          v[8 * i + 2 * j] = (float)h[0], v[8 * i + 2 * j + 1] = (float)h[1];
+        } else {
+          v[8 * i + 2 * j] = __uint_as_float(w[j] << 16), v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+    }
+  }
+}
+
+// one block of 16 -> its exact bf16 image (the arithmetic of k_quant_seg16 / k_quant_xa16: bit-identical images)
+template <int DT>
+__device__ __forceinline__ void quant_block16(const float (&v)[16], const QP& q, uint32_t (&w)[8]) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = 0;
+  if (amax > 0.f) {
+    const int e = block_exponent(amax, q);
+    if (mxint16_fast_ok(e, q)) {
+      mxint16_bf16_fast<DT != LQER_F16>(v, e, q, w);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t lo = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i], e, q), e - q.mbits));
+        const uint32_t hi = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * i + 1], e, q), e - q.mbits));
+        w[i] = lo | (hi << 16);
+      }
+    }
+  }
+}
+
+// 16-byte chunk c of image row r (row pitch `pitch` bytes): chunks XOR-ed with 2 (r & 7), so that the rows one ds_read_b128
+// lane group touches (8 rows x two neighbouring chunks) spread over the 16 chunk slots of a 256-byte bank row
+__device__ __forceinline__ int img_off(int r, int c, int pitch) { return r * pitch + ((c ^ (2 * (r & 7))) << 4); }
+
+template <int DT, int BOUT>
+// (two workgroups per CU: the grid is the N/16 consumers PLUS the producers - 272 for N = 4096 -, with one workgroup per CU the
+// last 16 would wait for a whole round; 4 waves per SIMD caps the kernel at 128 registers)
+__global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const GemmArgs& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int M = g.M, Kp = g.Kp, rp = g.rp;
+  const int xpitch = (Kp * 2 + 255) / 256 * 256;  // (the chunk XOR stays inside a 256-byte group)
+  const int xs_bytes = M * xpitch;
+  unsigned char* const xs = smem;
+  float* const red = (float*)(smem + xs_bytes);
+  bf16_t* const xaq_l = (bf16_t*)(smem + xs_bytes + RED_BYTES);
+  unsigned char* const pslab = smem + xs_bytes + RED_BYTES + XAQ_BYTES;
+  float* const pred = (float*)(pslab + PSLAB_BYTES);
+  const auto gran_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, a.np * MAXM * rp * 8, 0x00020000);
+  const int nt16 = rp / 16;
+
+  // ---- the partial tile of x A of slab p, published as granules (the producers' whole job; a consumer's fall-back)
+  auto produce = [&](int p) {
+    // this wave's A^T fragments first: they do not depend on x, and their L2 / HBM latency then passes under the quantizer
+    const int64_t k = (int64_t)p * SLAB_K + 32 * wave;
+    bf16x8 af[MAXNT];
+#pragma unroll
+    for (int t = 0; t < MAXNT; ++t) {
+      af[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (t < nt16 && k < Kp) af[t] = *(const bf16x8*)(a.a_t + (int64_t)(16 * t + l15) * Kp + k + 8 * lq);
+    }
+    // quantize the slab: threads 0..127 take block (row t >> 4, segment t & 15); rows >= M and k >= K are zeros
+    if (tid < MAXM * 16) {
+      const int row = tid >> 4, seg = tid & 15;
+      const int64_t k0 = (int64_t)p * SLAB_K + seg * 16;
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (row < M && k0 < a.K) {
+        float v[16];
+        load_block16<DT>(a.x, row * a.ldx + k0, v);
+        quant_block16<DT>(v, a.qx, w);
+      }
+      *(uint4*)(pslab + img_off(row, 2 * seg, SLAB_K * 2)) = make_uint4(w[0], w[1], w[2], w[3]);
+      *(uint4*)(pslab + img_off(row, 2 * seg + 1, SLAB_K * 2)) = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+    __syncthreads();
+    // wave w multiplies the slab's k [32 w, 32 w + 32): A operand = tokens (row l15 & 7: rows 8..15 duplicate 0..7 and
+    // are never published), B operand = A^T (lane: rank entry 16 t + l15, k + 8 lq)
+    f32x4 acc[MAXNT];
+#pragma unroll
+    for (int t = 0; t < MAXNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k < Kp) {
+      const bf16x8 xf = *(const bf16x8*)(pslab + img_off(l15 & 7, 4 * wave + lq, SLAB_K * 2));
+#pragma unroll
+      for (int t = 0; t < MAXNT; ++t)
+        if (t < nt16) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, af[t], acc[t], 0, 0, 0);
+    }
+    // fixed-order combine ((w0 + w1) + ... + w7)
+    if (wave > 0) {
+#pragma unroll
+      for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pred[(((wave - 1) * MAXNT + t) * 4 + j) * 64 + lane] = acc[t][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float sum = acc[t][j];
+#pragma unroll
+          for (int w2 = 0; w2 < NW - 1; ++w2) sum += pred[((w2 * MAXNT + t) * 4 + j) * 64 + lane];
+          const int row = 4 * lq + j;  // lane holds token rows 4 lq + j, rank entry 16 t + l15
+          if (t < nt16 && row < M) {
+            const u32x2_t gv = {__float_as_uint(sum), a.nonce};
+            __builtin_amdgcn_raw_buffer_store_b64(gv, gran_rsrc, (((p * MAXM + row) * rp) + 16 * t + l15) * 8, 0, 16);  // sc1
+          }
+        }
+    }
+    __syncthreads();  // pslab / pred may be reused (fall-back loop)
+  };
+
+  D1_STAMP(0);
+  if ((int)blockIdx.x < a.np) {
+    produce((int)blockIdx.x);
+    D1_STAMP(5);
+    return;
+  }
+
+  // ================================================== consumer =========================================================
+  const int cb = (int)blockIdx.x - a.np;
+  const int row = l15, q = lq;  // weight row / token within the tile; k group (gemm_smallm.hip's names)
+  const int n0 = cb * 16;
+  const int nk = Kp / 64;
+  const uint8_t* prow = g.wp + (int64_t)cb * nk * LQER_PANEL_BYTES;
+  const int codes_off = row * 32 + (q & 1) * 16;
+  const int exps_off = 512 + row * 4;
+  const bool hi = (q >> 1) != 0;
+  const int sh0 = 8 * (q >> 1), sh1 = 16 + 8 * (q >> 1);
+  const bool lowrank = g.bt != nullptr && rp > 0;
+
+  // weight panels through a buffer descriptor: a request past the end is dropped by the range check,
+  // so no load sits under a branch and the compiler's vmcnt counts stay exact
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)prow, 0, nk * LQER_PANEL_BYTES, 0x00020000);
+  auto load_panel = [&](int kt, SmPanel& p) {  // kt >= nk: zeros
+    const uint32_t base = kt < nk ? (uint32_t)kt * LQER_PANEL_BYTES : 0x7ffffff0u;
+    p.cw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, base + codes_off, 0, 0));
+    p.ex = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, base + exps_off, 0, 0);
+  };
+  // wave w takes panels w, w + 8, ...; two register buffers of 4 panels
+  constexpr int UNR = 4;
+  SmPanel pa[UNR], pb[UNR];
+  const int per_wave = (nk - wave + NW - 1) / NW;
+  auto kt_of = [&](int i) { return wave + NW * i; };
+  // this thread's first block of x is requested BEFORE the weight panels (loads complete in order: the small L2-hot read
+  // must not queue behind the weight stream)
+  const int segs = Kp / 16;
+  float v0[16];
+  bool has_first;
+  {
+    const int r0 = tid / segs, seg0 = tid - r0 * segs;
+    const bool has0 = tid < M * segs && seg0 * 16 < a.K;
+    // (always loaded, from a clamped in-range offset: a load under a branch would make the compiler wait for everything in
+    // flight at its first use; threads without a block of their own ignore the values)
+    load_block16<DT>(a.x, has0 ? r0 * a.ldx + seg0 * 16 : 0, v0);
+    has_first = has0;
+  }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) load_panel(kt_of(u), pa[u]);
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- the activation image of ALL of x in LDS: block b = (row b / (Kp/16), segment b % (Kp/16))
+  for (int b = tid; b < M * segs; b += 64 * NW) {
+    const int r = b / segs, seg = b - r * segs;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (b == tid) {
+      if (has_first) quant_block16<DT>(v0, a.qx, w);
+    } else if (seg * 16 < a.K) {
+      float v[16];
+      load_block16<DT>(a.x, r * a.ldx + seg * 16, v);
+      quant_block16<DT>(v, a.qx, w);
+    }
+    *(uint4*)(xs + img_off(r, 2 * seg, xpitch)) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(uint4*)(xs + img_off(r, 2 * seg + 1, xpitch)) = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+  __syncthreads();
+  D1_STAMP(1);
+
+  // ---- main loop (gemm_smallm.hip with the activation fragments from LDS).  Token rows >= M read row 0: their output
+  // columns are never stored
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int xrow = row < M ? row : 0;
+  auto compute_panel = [&](int kt, const SmPanel& p) {
+    const uint32_t w0 = hi ? p.cw[1] : p.cw[0], w1 = hi ? p.cw[3] : p.cw[2];
+    const bf16x8 wb0 = expand_frag(w0, ((p.ex >> sh0) & 0xffu) << 23);
+    const bf16x8 wb1 = expand_frag(w1, ((p.ex >> sh1) & 0xffu) << 23);
+    const int kc = kt < nk ? kt : 0;  // (past the end: zero weights, any finite activation chunk)
+    const bf16x8 x0 = *(const bf16x8*)(xs + img_off(xrow, kc * 8 + q, xpitch));
+    const bf16x8 x1 = *(const bf16x8*)(xs + img_off(xrow, kc * 8 + 4 + q, xpitch));
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0, x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1, x1, acc, 0, 0, 0);
+  };
+  // (no tests around loads or MFMAs: a panel past the end is zeros times the image's first chunk)
+  for (int i = 0; i < per_wave; i += 2 * UNR) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) load_panel(kt_of(i + UNR + u), pb[u]);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + u), pa[u]);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) load_panel(kt_of(i + 2 * UNR + u), pa[u]);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + UNR + u), pb[u]);
+  }
+
+  D1_STAMP(2);
+  // fixed-order combine: (((w0 + w1) + w2) + ...) + w7
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[((wave - 1) * 4 + j) * 64 + lane] = acc[j];
+  }
+  __syncthreads();
+  D1_STAMP(3);
+
+  // wave 0 requests the first side-path fragment of B now: its latency passes under the granule round trip (requested at
+  // the top of the kernel it would sit under a branch in front of the weight stream and cost a register for the whole loop)
+  bf16x8 sp_b = zero8;
+  if (lowrank && wave == 0 && g.b_limbs > 0 && 8 * q < rp) sp_b = *(const bf16x8*)(g.bt + (int64_t)(n0 + row) * rp + 8 * q);
+  // ---- x A from the producers' granules: one thread per 4 rank entries of a token, slabs summed in ascending order
+  if (lowrank) {
+    const int items = M * rp / 4;  // <= 128
+    const int rq = rp / 4;
+    // the 512 threads read the granules as 4 groups x 128 items: group pg takes the slabs pg, pg + 4, pg + 8, ... (4 requested
+    // together: one memory round trip per batch), the groups' sums are added in the order 0..3 through LDS - a fixed order
+    auto gather = [&](int sweeps, bool& complete) -> float4 {
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      complete = true;
+      const int pg = tid >> 7, it = tid & 127;
+      if (it < items) {
+        const int r = it / rq, c4 = it - r * rq;
+        for (int p0 = pg; p0 < a.np; p0 += 16) {
+          u32x4_t v0[4], v1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int p = p0 + 4 * u;
+            const int off = p < a.np ? (((p * MAXM + r) * rp) + 4 * c4) * 8 : 0x7ffffff0;  // (past the range: zeros)
+            v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);       // sc1: past this CU's L1
+            v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int p = p0 + 4 * u;
+            if (p < a.np) {
+              const int off = (((p * MAXM + r) * rp) + 4 * c4) * 8;
+              u32x4_t x0 = v0[u], x1 = v1[u];
+              bool ok = x0[1] == a.nonce && x0[3] == a.nonce && x1[1] == a.nonce && x1[3] == a.nonce;
+              for (int tries = 0; tries < sweeps && !ok; ++tries) {  // not there yet: poll this slab
+                __builtin_amdgcn_s_sleep(8);
+                x0 = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);
+                x1 = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
+                ok = x0[1] == a.nonce && x0[3] == a.nonce && x1[1] == a.nonce && x1[3] == a.nonce;
+              }
+              if (!ok) complete = false;
+              sum.x += __uint_as_float(x0[0]), sum.y += __uint_as_float(x0[2]);
+              sum.z += __uint_as_float(x1[0]), sum.w += __uint_as_float(x1[2]);
+            }
+          }
+        }
+      }
+      float4* const gs = (float4*)pred;  // [4][128]
+      gs[tid] = sum;
+      __syncthreads();
+      if (tid < 128) {
+        const float4 s1 = gs[128 + tid], s2 = gs[256 + tid], s3 = gs[384 + tid];
+        sum.x = ((sum.x + s1.x) + s2.x) + s3.x, sum.y = ((sum.y + s1.y) + s2.y) + s3.y;
+        sum.z = ((sum.z + s1.z) + s2.z) + s3.z, sum.w = ((sum.w + s1.w) + s2.w) + s3.w;
+      }
+      return sum;  // (threads 0 .. items-1 hold the totals)
+    };
+    bool complete;
+    float4 s = gather(a.spin, complete);
+    D1_STAMP(4);
+    if (__syncthreads_or(complete ? 0 : 1)) {
+      // a producer has not been seen: compute every partial tile here (same routine, same bits), then read them back
+      for (int p = 0; p < a.np; ++p) produce(p);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      s = gather(64, complete);  // (written by this very workgroup: there after its own drain + barrier)
+    }
+    // A_out in blocks of 16 = 4 consecutive threads
+    float amax = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    if (tid < items) {
+      const bool any = amax > 0.f;
+      const int e = any ? block_exponent(amax, g.aout) : 0;
+      const float v[4] = {s.x, s.y, s.z, s.w};
+      uint32_t w[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float m0v = any ? mxint_mantissa(v[2 * i], e, g.aout) : 0.f;
+        const float m1v = any ? mxint_mantissa(v[2 * i + 1], e, g.aout) : 0.f;
+        w[i] = exact_bf16_bits(ldexpf(m0v, e - g.aout.mbits)) | (exact_bf16_bits(ldexpf(m1v, e - g.aout.mbits)) << 16);
+      }
+      *(uint2*)(xaq_l + tid * 4) = make_uint2(w[0], w[1]);
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int w2 = 0; w2 < NW - 1; ++w2) acc[j] += red[(w2 * 4 + j) * 64 + lane];
+
+  // ---- side path + bias + store (wave 0, gemm_smallm.hip's epilogue): lane = token `row`, output columns n0 + 4 q + j
+  const int nq = n0 + 4 * q;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (lowrank) {
+    bf16x8 sp_x = zero8;
+    if (8 * q < rp && row < M) sp_x = *(const bf16x8*)(xaq_l + row * rp + 8 * q);
+    if (g.b_limbs > 0) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_b, sp_x, s, 0, 0, 0);  // prefetched
+    for (int l = 0; l < g.b_limbs; ++l)
+      for (int ks = (l == 0 ? 1 : 0); ks * 32 < rp; ++ks) {
+        const int j0 = ks * 32 + 8 * q;
+        bf16x8 bb = zero8, xv = zero8;
+        if (j0 < rp) {
+          bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + row) * rp + j0);
+          if (row < M) xv = *(const bf16x8*)(xaq_l + row * rp + j0);
+        }
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, xv, s, 0, 0, 0);
+      }
+    if constexpr (BOUT == 1) {
+      float amax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3])));
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const int e = block_exponent(amax, g.bout);
+      const int mb = g.bout.mbits;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = s[j];
+        const float m = fminf(rintf(ldexpf(fabsf(v) + 1e-9f, mb - e)), g.bout.mmax);
+        const float qv = copysignf(ldexpf(m, e - mb), v);
+        s[j] = fabsf(v) <= 1e-8f ? v : qv;
+      }
+    }
+  }
+  if (row < M) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float out = (s[j] + (g.bias ? g.bias[nq + j] : 0.f)) + acc[j];
+      if (nq + j < g.N) store_elem<DT>(g.y, (int64_t)row * g.ldy + nq + j, out);
+    }
+  }
+  D1_STAMP(5);
+}
+
+static std::atomic<uint32_t> g_nonce{1};  // the call's granule tag: any value the granule area does not hold yet
+static std::atomic<int> g_spin{LQER_QD1_SPIN};
+
+}  // namespace d1
+
+#ifdef LQER_D1_STAMPS
+extern "C" int lqer_debug_set_d1_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(d1::g_d1_stamps), &p, sizeof(p)); }
+#endif
+
+// test hook: poll sweeps before the fall-back (0: every consumer workgroup computes the partial tiles itself)
+extern "C" int lqer_debug_set_decode_spin(int sweeps) {
+  d1::g_spin.store(sweeps < 0 ? LQER_QD1_SPIN : sweeps, std::memory_order_relaxed);
+  return 0;
+}
+
+size_t decode1_lds_bytes(int M, int64_t Kp) {
+  return (size_t)M * ((Kp * 2 + 255) / 256 * 256) + d1::RED_BYTES + d1::XAQ_BYTES + d1::PSLAB_BYTES + d1::PRED_BYTES;
+}
+
+size_t decode1_scratch_bytes(int64_t Kp, int rp) { return (size_t)((Kp + d1::SLAB_K - 1) / d1::SLAB_K) * d1::MAXM * rp * 8; }
+
+// g: filled like for the small-M kernel (xq / xaq / xa_part unused).  Returns LQER_E_UNSUPPORTED when the shape is outside.
+int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, const QP& qx, const bf16_t* a_t, int bout,
+                     void* scratch, size_t scratch_bytes, hipStream_t st) {
+  if (g.M < 1 || g.M > d1::MAXM || g.rp > 16 * d1::MAXNT || bout > 1 || K % 16 != 0) return LQER_E_UNSUPPORTED;
+  const size_t lds = decode1_lds_bytes(g.M, g.Kp);
+  if (lds > 150 * 1024 || scratch_bytes < decode1_scratch_bytes(g.Kp, g.rp) || ((uintptr_t)scratch & 15)) return LQER_E_UNSUPPORTED;
+  d1::Args a;
+  a.g = g;
+  a.x = x, a.ldx = ldx, a.K = K, a.qx = qx, a.a_t = a_t;
+  a.gran = (uint32_t*)scratch;
+  // the call's tag: a counter spread over all 32 bits (odd multiplier: a bijection, so two calls never share a tag before
+  // 2^32 calls) - small integers, zeros and the bit patterns of ordinary floats are what stale workspace bytes look like
+  const uint32_t n = d1::g_nonce.fetch_add(1, std::memory_order_relaxed);
+  a.nonce = n * 0x9E3779B1u ^ 0xA5C35A3Cu;
+  a.np = (int)((g.Kp + d1::SLAB_K - 1) / d1::SLAB_K);
+  a.spin = d1::g_spin.load(std::memory_order_relaxed);
+  const unsigned grid = (unsigned)(a.np + g.Np / 16);
+#define D1_LAUNCH(DT, BO)                                                                     \
+  do {                                                                                        \
+    static LdsLimitOnce lds_once;                                                             \
+    lds_once.set((const void*)d1::k_decode1<DT, BO>, 150 * 1024);                             \
+    d1::k_decode1<DT, BO><<<grid, 64 * d1::NW, lds, st>>>(a);                                 \
+  } while (0)
+  switch (dtype) {
+    case LQER_F32: if (bout == 1) D1_LAUNCH(LQER_F32, 1); else D1_LAUNCH(LQER_F32, 0); break;
+    case LQER_F16: if (bout == 1) D1_LAUNCH(LQER_F16, 1); else D1_LAUNCH(LQER_F16, 0); break;
+    case LQER_BF16: if (bout == 1) D1_LAUNCH(LQER_BF16, 1); else D1_LAUNCH(LQER_BF16, 0); break;
+    default: set_error("unknown dtype %d", dtype); return LQER_E_INVALID;
+  }
+#undef D1_LAUNCH
+  return check_launch("lqer_decode1");
+}
+
+}  // namespace lqer
