@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
     // flight at its first use; threads without a block of their own ignore the values)
     load_block16<DT>(a.x, has0 ? r0 * a.ldx + seg0 * 16 : 0, v0);
     has_first = has0;
+    asm volatile("" ::: "memory");  // (keeps the request HERE: the compiler otherwise sinks it to its use, behind the panels)
   }
 #pragma unroll
   for (int u = 0; u < UNR; ++u) load_panel(kt_of(u), pa[u]);
