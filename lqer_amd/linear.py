@@ -373,6 +373,8 @@ class SharedActivation:
     Requirements checked at construction: same in_features, same block_fp x / A_out quantizers, A_out blocks of 16 or
     one block per row with equal power-of-two ranks (a multiple of 16), rank > 0 for every member."""
 
+    _pool = {}  # device -> {"xq", "xaq", "scr": uint8 tensors, "owner": (id(group), round)} - see forward_member
+
     def __init__(self, members):
         self.members = list(members)
         m0 = self.members[0]
@@ -396,7 +398,7 @@ class SharedActivation:
         self._cat = None      # concatenated A^T limb image + member offsets
         self._x = None        # the tensor the images below were made from (strong reference: its address stays taken)
         self._ver = -1
-        self._buf = {}        # per (M, device): xq, xaq buffers
+        self._round = 0       # rounds started by this group (pool ownership)
         self._cur = None
         self._served = set()  # members served from the current images
         if self.enabled:
@@ -443,7 +445,9 @@ class SharedActivation:
         # member: a member that comes back with the same tensor starts a new round
         ver = None if x.is_inference() else x._version
         idx = self.members.index(mod)
-        fresh = not (x is self._x and ver == self._ver and self._cur is not None and self._cur["M"] == M and idx not in self._served)
+        pool = SharedActivation._pool.get(dev)
+        fresh = not (x is self._x and ver == self._ver and self._cur is not None and self._cur["M"] == M and idx not in self._served
+                     and pool is not None and pool["owner"] == (id(self), self._round))  # (another group has used the pool since)
         # members on the int8 route (per-token activations): the shared image is int8 only if every member's GEMM takes the
         # int8 kernel at this token count, else everybody uses the bf16 image
         i8 = all(m._x_i8 for m in self.members)
@@ -455,13 +459,19 @@ class SharedActivation:
             gdesc.rank = self._cat["rp_total"]
             gdesc.a_out_fmt.block = self._aout_block  # (one block per member row -> blocks of a member's rank)
             Mp, Kp = L.lqer_padded_m(M), L.lqer_padded_k(K)
-            key = (M, dev)
-            if key not in self._buf:
-                nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(gdesc), M)
-                self._buf = {key: {"xq": torch.empty(Mp * Kp, dtype=torch.bfloat16, device=dev),
-                                   "xaq": torch.empty(Mp * self._cat["rp_total"], dtype=torch.bfloat16, device=dev),
-                                   "scr": torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev), "nscr": nscr}}
-            b = self._buf[key]
+            # the images live in ONE grow-only pool per device, shared by every group (the groups of a model run one after
+            # the other; 64 private copies would pin ~1 GiB at M = 2048): a group owns the pool from its first member's call
+            # of a round to its last; a member that finds another owner re-makes the images (always correct, only slower)
+            nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(gdesc), M)
+            need = {"xq": Mp * Kp * 2, "xaq": Mp * self._cat["rp_total"] * 2, "scr": max(nscr, 16)}
+            if pool is None:
+                pool = SharedActivation._pool[dev] = {"owner": None}
+            for name, nbytes in need.items():
+                if name not in pool or pool[name].numel() < nbytes:
+                    pool[name] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._round += 1
+            pool["owner"] = (id(self), self._round)
+            b = {"xq": pool["xq"], "xaq": pool["xaq"], "scr": pool["scr"], "nscr": nscr}
             check(L.lqer_quantize_act_xa(C.byref(gdesc), x2.data_ptr(), ops.dtype_code(x2), M, x2.stride(0) if M > 1 else K,
                                          self._cat["a_t"].data_ptr(), self._cat["a_limbs"], b["xq"].data_ptr(),
                                          b["xaq"].data_ptr(), b["scr"].data_ptr(), b["nscr"], ops._stream(dev)),

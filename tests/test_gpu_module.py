@@ -127,6 +127,42 @@ def test_shared_activation_under_inference_mode(lq):
         assert (y1.float() - 2 * alone[1].float()).norm() / (2 * alone[1].float()).norm() <= 5e-3
 
 
+def test_shared_activation_groups_share_one_image_pool(lq):
+    """Every group takes its images from ONE per-device pool (64 private copies would pin ~1 GiB for a Llama-7B at M = 2048):
+    groups that run one after the other reuse the same bytes, and groups whose members are called INTERLEAVED (another
+    group has overwritten the pool between two members) re-make their images instead of reading the other group's."""
+    from bench import MXINT_Q, make_case
+    from lqer_amd.linear import SharedActivation
+
+    M, K, r = 200, 512, 32
+    groups, xs, alone = [], [], []
+    for gidx in range(2):
+        mods = []
+        for i, N in enumerate((256, 128)):
+            x, W, A, B = make_case(M, K, N, r, seed=50 + 10 * gidx + i)
+            m = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+            m.load_state_dict({"weight": W, "A": A, "B": B})
+            mods.append(m.to(DEV).half())
+        xd = (x * (1.0 + gidx)).half().to(DEV)
+        alone.append([m(xd).clone() for m in mods])
+        grp = SharedActivation(mods)
+        assert grp.enabled
+        groups.append(mods)
+        xs.append(xd)
+    close = lambda a, b: float((a.float() - b.float()).norm() / a.float().norm()) <= 2e-3
+    with torch.no_grad():
+        # one group after the other (the order of a decoder layer)
+        for mods, xd, ref in zip(groups, xs, alone):
+            for m, a in zip(mods, ref):
+                assert close(a, m(xd))
+        pool = SharedActivation._pool[xs[0].device]
+        ptr = pool["xq"].data_ptr()
+        # interleaved: g0.m0, g1.m0, g0.m1, g1.m1
+        y00 = groups[0][0](xs[0]); y10 = groups[1][0](xs[1]); y01 = groups[0][1](xs[0]); y11 = groups[1][1](xs[1])
+        assert close(alone[0][0], y00) and close(alone[1][0], y10) and close(alone[0][1], y01) and close(alone[1][1], y11)
+        assert SharedActivation._pool[xs[0].device]["xq"].data_ptr() == ptr  # still the one pool
+
+
 @pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
 def test_forward_on_a_non_current_device(lq):
     from bench import MXINT_Q, make_case
