@@ -345,6 +345,178 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
   }
 }
 
+
+// ---- the product for a short contraction dim (K <= 128: Q K^T, K = head_dim) ---------------------------------------------
+// There the OUTPUT is the stream (S1 x S2 per head) and the first operand is small: one workgroup quantizes its 128-row tile
+// of x for ALL of K once into LDS and walks XR_JT column tiles with it, so x is read and quantized once per 512 output
+// columns instead of once per 128.  Same tile arithmetic, fragment maps and LDS-staged 16-bit stores as k_qmatmul; the image
+// tile of the next column tile is requested before the current tile's MFMAs.
+constexpr int XR_JT = 4;      // column tiles per workgroup
+constexpr int XR_MAXK = 128;  // two 64-k chunks
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
+                                                    int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs, int64_t S2p, int64_t Kp,
+                                                    QP q, bool vec) {
+  // [x tile: 2 chunks x 128 rows x 128 B][image tile: 2 chunks x 128 rows x 128 B, reused for the 16-bit output tile]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * BK * 2 + 2 * BN * BK * 2];
+  unsigned char* const sa = smem;
+  unsigned char* const sb = smem + 2 * BM * BK * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int64_t b = blockIdx.z, i0 = (int64_t)blockIdx.y * BM;
+  const int nkc = (int)(Kp / BK);  // 1 or 2
+  // ---- the x tile, quantized once: thread -> rows tid / 4 and 64 + tid / 4, block tid % 4 of every chunk
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = (tid >> 2) + 64 * u;
+      const int64_t i = i0 + row, k = (int64_t)kc * BK + (tid & 3) * 16;
+      uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (kc < nkc && i < S1 && k < K) {
+        float v[16];
+        load16<DT>(x, b * x_bs + i * x_rs + k, K - k, vec, v);
+        quant16_bf16(v, q, w);
+      }
+      const int c = 2 * (tid & 3);
+      *(uint4*)(sa + kc * (BM * BK * 2) + swz(row, c)) = make_uint4(w[0], w[1], w[2], w[3]);
+      *(uint4*)(sa + kc * (BM * BK * 2) + swz(row, c + 1)) = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  const int esz = DT == LQER_F32 ? 4 : 2;
+  const bool aligned = (((uintptr_t)out) & 15) == 0 && (S2 * esz) % 16 == 0;
+  const int64_t jt0 = (int64_t)blockIdx.x * XR_JT, njt = S2p / BN;
+  uint4 bv[2][4];  // the image tile of one column tile: [chunk][piece]
+  auto fetch = [&](int64_t jt) {
+    const bf16_t* const ib = img + (b * S2p + jt * BN) * Kp;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = tid + 256 * u, row = p >> 3, ch = p & 7;
+        bv[kc][u] = kc < nkc ? *(const uint4*)(ib + (int64_t)row * Kp + (int64_t)kc * BK + ch * 8) : make_uint4(0, 0, 0, 0);
+      }
+  };
+  if (jt0 < njt) fetch(jt0);
+  for (int t = 0; t < XR_JT; ++t) {
+    const int64_t jt = jt0 + t, j0 = jt * BN;
+    if (jt >= njt) break;  // workgroup-uniform
+    __syncthreads();  // the x tile is written (t = 0); the previous tile's output has left LDS (t > 0)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = tid + 256 * u;
+        *(uint4*)(sb + kc * (BN * BK * 2) + swz(p >> 3, p & 7)) = bv[kc][u];
+      }
+    __syncthreads();
+    if (jt + 1 < njt && t + 1 < XR_JT) fetch(jt + 1);  // the next tile's loads travel under this tile's MFMAs and stores
+    f32x16 acc[2][2];  // [j tile][i tile]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      if (kc >= nkc) break;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 fj[2], fi[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          fj[u] = *(const bf16x8*)(sb + kc * (BN * BK * 2) + swz(wn * 64 + u * 32 + l31, 2 * ks + lh));
+          fi[u] = *(const bf16x8*)(sa + kc * (BM * BK * 2) + swz(wm * 64 + u * 32 + l31, 2 * ks + lh));
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fj[a], fi[c], acc[a][c], 0, 0, 0);
+      }
+    }
+    // ---- store (k_qmatmul's): fp32 directly; 16-bit through LDS as full 256-byte row segments when the tile is inside
+    const bool staged = DT != LQER_F32 && aligned && j0 + BN <= S2;  // workgroup-uniform
+    if (staged) __syncthreads();  // every wave has read its image fragments: sb is free
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int64_t i = i0 + wm * 64 + c * 32 + l31;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int64_t jb = j0 + wn * 64 + a * 32;
+        if constexpr (DT == LQER_F32) {
+          if (i >= S1) continue;
+          float* dst = (float*)out + (b * S1 + i) * S2;
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const int64_t j = jb + 8 * qd + 4 * lh;
+            if (aligned && j + 3 < S2) {
+              *(float4*)(dst + j) = make_float4(acc[a][c][4 * qd], acc[a][c][4 * qd + 1], acc[a][c][4 * qd + 2], acc[a][c][4 * qd + 3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (j + e < S2) dst[j + e] = acc[a][c][4 * qd + e];
+            }
+          }
+        } else {
+          uint32_t pk[4][2];
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float v0 = acc[a][c][4 * qd + 2 * h], v1 = acc[a][c][4 * qd + 2 * h + 1];
+              if constexpr (DT == LQER_F16) {
+                typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+                const h2 hv = {(_Float16)v0, (_Float16)v1};
+                pk[qd][h] = __builtin_bit_cast(uint32_t, hv);
+              } else {
+                pk[qd][h] = (uint32_t)f32_to_bf16_rne(v0) | ((uint32_t)f32_to_bf16_rne(v1) << 16);
+              }
+            }
+          bf16_t* dst = (bf16_t*)out + (b * S1 + i) * S2;
+          const bool wide = aligned && jb + 32 <= S2;  // wave-uniform
+          if (staged) {
+            const int row_l = wm * 64 + c * 32 + l31;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+              auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+              auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+              const int chunk = (wn * 64 + a * 32 + 16 * p2 + 8 * lh) >> 3;
+              *(uint4*)(sb + row_l * 256 + ((chunk ^ (row_l & 15)) << 4)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+          } else if (wide) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+              auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
+              auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
+              if (i < S1) *(uint4*)(dst + jb + 16 * p2 + 8 * lh) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+          } else if (i < S1) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const int64_t j = jb + 8 * qd + 4 * lh;
+              if (j < S2) dst[j] = (bf16_t)(pk[qd][0] & 0xffff);
+              if (j + 1 < S2) dst[j + 1] = (bf16_t)(pk[qd][0] >> 16);
+              if (j + 2 < S2) dst[j + 2] = (bf16_t)(pk[qd][1] & 0xffff);
+              if (j + 3 < S2) dst[j + 3] = (bf16_t)(pk[qd][1] >> 16);
+            }
+          }
+        }
+      }
+    }
+    if (staged) {
+      __syncthreads();
+      bf16_t* const ob = (bf16_t*)out + (b * S1) * S2 + j0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // 16 consecutive lanes = one row of the tile: 256 contiguous bytes
+        const int idx = tid + 256 * u, row_l = idx >> 4, chunk = idx & 15;
+        const uint4 v = *(const uint4*)(sb + row_l * 256 + ((chunk ^ (row_l & 15)) << 4));
+        if (i0 + row_l < S1) *(uint4*)(ob + (i0 + row_l) * S2 + chunk * 8) = v;
+      }
+    }
+  }
+}
+
 }  // namespace qmm
 
 size_t qmatmul_workspace_bytes(int64_t batch, int64_t K, int64_t S2) {
@@ -365,6 +537,11 @@ static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, in
     const int64_t items = (S2p / 16) * (Kp / 8);
     const dim3 grid((unsigned)((items + 255) / 256), 1, (unsigned)batch);
     qmm::k_qmm_bimage_k<DT><<<grid, 256, 0, st>>>(y, K, S2, y_bs, y_js, qy, img, S2p, Kp, al16(y, y_bs, y_js));
+  }
+  if (Kp <= qmm::XR_MAXK && S2p / qmm::BN >= 2 * qmm::XR_JT) {  // short contraction, many column tiles: x tile resident in LDS
+    const dim3 grid((unsigned)((S2p / qmm::BN + qmm::XR_JT - 1) / qmm::XR_JT), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
+    qmm::k_qmatmul_xr<DT><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, al16(x, x_bs, x_rs));
+    return check_launch("lqer_matmul_q");
   }
   const dim3 grid((unsigned)(S2p / qmm::BN), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
   qmm::k_qmatmul<DT><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, al16(x, x_bs, x_rs));

@@ -338,7 +338,8 @@ def test_quantized_attention_matmuls_vs_reference_vectors(ops):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 5e-3)])
-@pytest.mark.parametrize("bh,s1,s2,d", [(3, 300, 200, 128), (2, 129, 70, 64), (1, 16, 16, 40), (4, 2048, 2048, 128)])
+@pytest.mark.parametrize("bh,s1,s2,d", [(3, 300, 200, 128), (2, 129, 70, 64), (1, 16, 16, 40), (4, 2048, 2048, 128),
+                                        (2, 333, 1100, 72), (1, 130, 1537, 40)])  # (the last two: k_qmatmul_xr with ragged tiles / K)
 def test_fused_quantized_matmul_vs_oracle(ops, dtype, tol, bh, s1, s2, d):
     """lqer_matmul_q (x quantized in the GEMM's load path, y through a bf16 image) against the oracle's
     matmul(x_quantizer(x), w_quantizer(y)) for both attention products: Q K^T with y the transposed VIEW of K (blocks of 16
