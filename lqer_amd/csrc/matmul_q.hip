@@ -12,6 +12,8 @@
 //                    loads one block of 16 (32 B, four threads cover 128 B of a row), quantizes it in registers and writes
 //                    the bf16 image to an LDS slab - x (the attention probabilities in P V: the big operand) is read from HBM
 //                    exactly once and no quantized copy of it ever exists in HBM.  fp32 accumulation of exact products.
+#include <type_traits>
+
 #include "common.h"
 
 namespace lqer {
@@ -54,6 +56,38 @@ __device__ __forceinline__ void load16(const void* base, int64_t off, int64_t va
   } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = i < valid ? load_elem<DT>(base, off + i) : 0.0f;
+  }
+}
+
+// 16 consecutive elements as raw 16-byte loads (the aligned fast path: requested chunks ahead, converted at use)
+template <int DT>
+struct Raw16 {
+  static constexpr int N = DT == LQER_F32 ? 4 : 2;
+  uint4 r[N];
+};
+template <int DT>
+__device__ __forceinline__ void raw_to_f32(const Raw16<DT>& raw, float (&v)[16]) {
+  if constexpr (DT == LQER_F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[4 * i] = __uint_as_float(raw.r[i].x), v[4 * i + 1] = __uint_as_float(raw.r[i].y);
+      v[4 * i + 2] = __uint_as_float(raw.r[i].z), v[4 * i + 3] = __uint_as_float(raw.r[i].w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t w[4] = {raw.r[i].x, raw.r[i].y, raw.r[i].z, raw.r[i].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (DT == LQER_F16) {
+          typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+          const h2 h = __builtin_bit_cast(h2, w[j]);
+          v[8 * i + 2 * j] = (float)h[0], v[8 * i + 2 * j + 1] = (float)h[1];
+        } else {
+          v[8 * i + 2 * j] = __uint_as_float(w[j] << 16), v[8 * i + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+    }
   }
 }
 
@@ -184,7 +218,11 @@ __global__ __launch_bounds__(256) void k_qmm_bimage_k(const void* __restrict__ y
 // One workgroup = one 128 (i) x 128 (j) tile of out[b]; 4 waves as 2 x 2, each 64 x 64 = 2 x 2 tiles of 32 x 32.
 // The MFMA is issued with the image rows (j) as the A operand and the token rows (i) as the B operand, so a lane owns one
 // output row i and 4 consecutive columns j per accumulator quad (the store pattern of gemm_w4a8.hip).
-template <int DT>
+// PF (aligned rows, K a multiple of 16): the raw loads of x and of the image run THREE 64-k chunks ahead in a register ring
+// indexed statically (the loop is unrolled by its depth) - with one chunk ahead every chunk exposed a memory latency, and in
+// P V the attention probabilities are a 268 MB stream.  All loads are unconditional from clamped in-range addresses (a load
+// under a branch makes the compiler wait for everything in flight); what lies outside x is zeroed at the quantizer.
+template <int DT, bool PF>
 __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
                                                  int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs, int64_t S2p, int64_t Kp,
                                                  QP q, bool vec) {
@@ -203,6 +241,90 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
   const int nkc = (int)(Kp / BK);
+  auto mma_chunk = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fj[2], fi[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fj[t] = *(const bf16x8*)(sb + swz(wn * 64 + t * 32 + l31, 2 * ks + lh));
+        fi[t] = *(const bf16x8*)(sa + swz(wm * 64 + t * 32 + l31, 2 * ks + lh));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fj[a], fi[c], acc[a][c], 0, 0, 0);
+    }
+  };
+  if constexpr (PF) {
+    constexpr int DEPTH = 3;
+    constexpr int ESZ = DT == LQER_F32 ? 4 : 2;
+    constexpr int NR = Raw16<DT>::N;
+    struct Stage {  // one chunk's raw loads of this thread (three named stages: an indexed ring ended up in scratch memory)
+      uint4 x[2][NR];
+      uint4 b[4];
+    };
+    Stage s0, s1, s2;
+    const int xrow0 = tid >> 2;
+    auto fetch_raw = [&](int kc, Stage& st) {
+      const int kcc = kc < nkc ? kc : nkc - 1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t i = i0 + xrow0 + 64 * u, ic = i < S1 ? i : S1 - 1;
+        int64_t k = (int64_t)kcc * BK + (tid & 3) * 16;
+        k = k + 16 <= K ? k : K - 16;
+        const uint4* ptr = (const uint4*)((const char*)x + (b * x_bs + ic * x_rs + k) * ESZ);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) st.x[u][n] = ptr[n];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = tid + 256 * u;
+        st.b[u] = *(const uint4*)(ib + (int64_t)(p >> 3) * Kp + (int64_t)kcc * BK + (p & 7) * 8);
+      }
+    };
+    auto chunk = [&](int kc, Stage& st) {
+      uint32_t w[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool live = i0 + xrow0 + 64 * u < S1 && (int64_t)kc * BK + (tid & 3) * 16 < K;
+        float v[16];
+        Raw16<DT> raw;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) raw.r[n] = st.x[u][n];
+        raw_to_f32<DT>(raw, v);
+        quant16_bf16(v, q, w[u]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[u][e] = live ? w[u][e] : 0u;
+      }
+      __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = xrow0 + 64 * u, c = 2 * (tid & 3);
+        *(uint4*)(sa + swz(row, c)) = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
+        *(uint4*)(sa + swz(row, c + 1)) = make_uint4(w[u][4], w[u][5], w[u][6], w[u][7]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = tid + 256 * u;
+        *(uint4*)(sb + swz(p >> 3, p & 7)) = st.b[u];
+      }
+      __syncthreads();
+      fetch_raw(kc + DEPTH, st);  // (past the end: a clamped re-read, never used)
+      mma_chunk();
+    };
+    fetch_raw(0, s0);
+    fetch_raw(1, s1);
+    fetch_raw(2, s2);
+    for (int kc = 0;; kc += DEPTH) {
+      chunk(kc, s0);
+      if (kc + 1 >= nkc) break;
+      chunk(kc + 1, s1);
+      if (kc + 2 >= nkc) break;
+      chunk(kc + 2, s2);
+      if (kc + 3 >= nkc) break;
+    }
+  } else {
   // this thread's two blocks of the x tile (rows tid / 4 and 64 + tid / 4, block tid % 4) and four 16-byte pieces of the image tile
   float xv[2][16];
   uint4 bv[4];
@@ -243,19 +365,8 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
     }
     __syncthreads();
     if (kc + 1 < nkc) fetch(kc + 1);  // the next chunk's loads travel under this chunk's MFMAs
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fj[2], fi[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fj[t] = *(const bf16x8*)(sb + swz(wn * 64 + t * 32 + l31, 2 * ks + lh));
-        fi[t] = *(const bf16x8*)(sa + swz(wm * 64 + t * 32 + l31, 2 * ks + lh));
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fj[a], fi[c], acc[a][c], 0, 0, 0);
-    }
+    mma_chunk();
+  }
   }
   // ---- store: lane = output row, register r of tile (a, c): column (r & 3) + 8 (r >> 2) + 4 lh
   const int esz = DT == LQER_F32 ? 4 : 2;
@@ -544,7 +655,11 @@ static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, in
     return check_launch("lqer_matmul_q");
   }
   const dim3 grid((unsigned)(S2p / qmm::BN), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
-  qmm::k_qmatmul<DT><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, al16(x, x_bs, x_rs));
+  const bool vec = al16(x, x_bs, x_rs);
+  if (vec && K % 16 == 0 && K >= 16)
+    qmm::k_qmatmul<DT, true><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, vec);
+  else
+    qmm::k_qmatmul<DT, false><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, vec);
   return check_launch("lqer_matmul_q");
 }
 
