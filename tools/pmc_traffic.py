@@ -19,13 +19,13 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             grids[k][int(row["Grid_Size"]) if "Grid_Size" in row else 0] += 1
 out = {"workload": wl, "kernels": {}}
 for k in sorted(acc):
-    if not k.startswith("k_") and "k_lqer" not in k and "i8::" not in k:
+    if not k.startswith("k_") and "k_lqer" not in k and "i8::" not in k and "d1::" not in k:
         continue
     out["kernels"][k] = {c: round(v[0] / v[1], 1) for c, v in sorted(acc[k].items())}
     out["kernels"][k]["launches_per_pass"] = max(v[1] for v in acc[k].values())
 from bench import WORKLOADS
 desc, M, r, bias, qc, shapes, layers = WORKLOADS[wl]
-gemm = [k for k in out["kernels"] if "k_lqer_gemm" in k]
+gemm = [k for k in out["kernels"] if "k_lqer_gemm" in k or "k_decode1" in k]  # (k_decode1: the whole decode forward)
 if gemm:
     fetch = sum(out["kernels"][k].get("FETCH_SIZE", 0) * out["kernels"][k]["launches_per_pass"] for k in gemm)
     write = sum(out["kernels"][k].get("WRITE_SIZE", 0) * out["kernels"][k]["launches_per_pass"] for k in gemm)
@@ -38,6 +38,8 @@ if gemm:
         act = M * (-(-K // 128) * 128) * 1 if i8 else M * (-(-K // 64) * 64) * 2
         w = N * K * (0.5 + 1 / 128 if i8 else 0.5625)
         tot += c * (act + w + M * rp * 2 + N * rp * 2 * limbs + M * N * 2 + (N * 4 if bias else 0))
+        if any("k_decode1" in k for k in gemm):
+            tot += c * rp * K * 2  # the one-launch forward reads A^T as well
         cnt += c
     alg = tot / cnt
     traffic = (2 * fetch + write) * 1024 / n
