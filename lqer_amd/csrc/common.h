@@ -95,22 +95,43 @@ __device__ __forceinline__ void store_elem<LQER_BF16>(void* p, int64_t i, float 
   ((bf16_t*)p)[i] = f32_to_bf16_rne(v);
 }
 
+// four consecutive outputs of one row, elements [at, at + 4) of y with columns n .. n + 3 of N: one 8- / 16-byte store when the
+// four exist and are aligned, else element by element
+template <int DT>
+__device__ __forceinline__ void store_row4(void* y, int64_t at, int n, int N, const float (&out)[4]) {
+  if (n + 3 < N && (at & 3) == 0 && ((uintptr_t)y & 15) == 0) {
+    if constexpr (DT == LQER_F32) {
+      *(f32x4*)((float*)y + at) = (f32x4){out[0], out[1], out[2], out[3]};
+    } else if constexpr (DT == LQER_BF16) {
+      *(uint2*)((bf16_t*)y + at) = make_uint2((uint32_t)f32_to_bf16_rne(out[0]) | ((uint32_t)f32_to_bf16_rne(out[1]) << 16),
+                                              (uint32_t)f32_to_bf16_rne(out[2]) | ((uint32_t)f32_to_bf16_rne(out[3]) << 16));
+    } else {
+      typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+      *(h4*)((_Float16*)y + at) = (h4){(_Float16)out[0], (_Float16)out[1], (_Float16)out[2], (_Float16)out[3]};
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n + j < N) store_elem<DT>(y, at + j, out[j]);
+  }
+}
+
 // ---- the reference's exponent rule --------------------------------------------------------------
 // e = torch.ceil(torch.log2(amax)) evaluated in fp32 (reference block_fp.py:58).  torch's log2 is
 // correctly rounded, so for amax = 2^k (1 + j 2^-23) the sum k + log2(1 + j 2^-23) rounds back to k
 // while j <= J(k), J = floor(2^(p-1) ln 2) with p the binade of the reals just above k
 // (oracle/lqer_oracle.py::ceil_log2_f32; table pinned by tests/golden "log2_rule").
 __device__ __forceinline__ int ceil_log2_rule(float amax) {
+  // branch-free: slack(p) = {0, 0, 1, 2, 5, 11, 22, 22}[p], p = floor(log2 |k|) (one less for k = -2^j); |k| < 4 gives p <= 1
   const uint32_t bits = __float_as_uint(amax);
   const int k = (int)((bits >> 23) & 0xff) - 127;
   const int mant = (int)(bits & 0x7fffffu);
   const int ak = k < 0 ? -k : k;
-  int slack = 0;
-  if (ak >= 4) {
-    int p = 31 - __clz(ak);
-    if (k < 0 && (ak & (ak - 1)) == 0) p -= 1;
-    slack = p <= 1 ? 0 : p == 2 ? 1 : p == 3 ? 2 : p == 4 ? 5 : p == 5 ? 11 : 22;
-  }
+  int p = 31 - __clz(ak | 1);
+  p -= (k < 0 && (ak & (ak - 1)) == 0) ? 1 : 0;
+  p = p < 0 ? 0 : p;
+  const uint32_t tw = p < 4 ? 0x02010000u : 0x16160B05u;
+  const int slack = (int)((tw >> ((p & 3) * 8)) & 0xffu);
   return mant > slack ? k + 1 : k;
 }
 
@@ -127,7 +148,9 @@ __device__ __forceinline__ int block_exponent(float amax, const QP& q) {
 __device__ __forceinline__ float mxint_mantissa(float x, int e, const QP& q) {
   const float v = fabsf(x) + q.eps;
   const float t = ldexpf(v, q.mbits - e);
-  const float m = fminf(rintf(t), x < 0.0f ? q.mneg : q.mmax);
+  // (written as mmax + (x < 0 ? mneg - mmax : 0): a select between the two struct fields themselves becomes, when q lives in
+  // the kernel-argument segment, a per-lane LOAD from a selected address - a memory round trip per element)
+  const float m = fminf(rintf(t), q.mmax + (x < 0.0f ? q.mneg - q.mmax : 0.0f));
   return fabsf(x) <= q.tiny ? 0.0f : copysignf(m, x);
 }
 
@@ -136,7 +159,23 @@ __device__ __forceinline__ float mxint_mantissa(float x, int e, const QP& q) {
 //   t = |x| + 1e-9;  m = min(rne(t * 2^(mbits-e)), mmax);  value = sign(x) * m * 2^(e-mbits);  |x| <= 1e-8 -> 0.
 // rne(t s) = fma(t, s, 1.5 * 2^23) - 1.5 * 2^23: t s is exact (s is a power of two), the fma rounds once to an integer
 // (t s < 2^22 because t <= 2^e + 1e-9).  Needs s and 1/s to be normal floats: mxint16_fast_ok(e, q).
-__device__ __forceinline__ bool mxint16_fast_ok(int e, const QP& q) { return q.mbits - e <= 126 && e - q.mbits >= -126; }
+__device__ __forceinline__ bool mxint16_fast_ok(int e, const QP& q) {
+  const int d = q.mbits - e;  // both 2^d and 2^-d normal
+  return d <= 126 && d >= -126;
+}
+
+// One value: sign(x) min(rne((|x| + eps) 2^(mbits-e)), clamp) 2^(e-mbits) - mxint_mantissa + ldexpf without the two ldexpf
+// calls (power-of-two factors built from exponent bits, round-to-nearest-even by the 1.5 * 2^23 trick, as in
+// mxint16_bf16_fast below) when mxint16_fast_ok(e, q); the |x| <= tiny case is the caller's.
+__device__ __forceinline__ float mxint_value(float x, int e, const QP& q) {
+  if (mxint16_fast_ok(e, q)) {
+    const float s = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23), inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
+    const float r = __builtin_fmaf(fabsf(x) + q.eps, s, 12582912.0f) - 12582912.0f;
+    return copysignf(fminf(r, q.mmax + (x < 0.0f ? q.mneg - q.mmax : 0.0f)) * inv, x);
+  }
+  const float t = ldexpf(fabsf(x) + q.eps, q.mbits - e);
+  return copysignf(ldexpf(fminf(rintf(t), q.mmax + (x < 0.0f ? q.mneg - q.mmax : 0.0f)), e - q.mbits), x);
+}
 
 template <bool FLUSH_TINY>  // false when the input type cannot hold a non-zero |x| <= 1e-8 (fp16)
 __device__ __forceinline__ void mxint16_bf16_fast(const float (&v)[16], int e, const QP& q, uint32_t (&w)[8]) {

@@ -5,13 +5,19 @@
 // The two-launch decode route (k_quant_xa16 -> k_lqer_gemm_smallm) is bound by two kernel latencies and the boundary
 // between them (11 us at M = 1 for 9.4 MB of weights).  Here one grid holds two kinds of workgroups:
 //   * producers (blocks 0 .. np-1, one per 256 k of K): quantize their slab of x, multiply it with the slab of A
-//     (v_mfma_f32_16x16x32_bf16, the 8 waves' tiles summed in a fixed order) and publish the partial tile of x A as 8-byte
+//     (v_mfma_f32_16x16x32_bf16: 4 waves x 2 k-slices, the waves' tiles summed in a fixed order) and publish the partial tile of x A as 8-byte
 //     {value, tag} granules - one write-through (sc1) store each, the tag is this call's nonce: no flag, no counter, nothing
 //     to reset (MI355X_MICROARCH.md, hand-off price list: data-tagged granules);
 //   * consumers (one per 16 output columns, as in gemm_smallm.hip): request their first weight panels, quantize ALL of x
 //     into an LDS image themselves (M x K <= 8 x 4096 elements: cheaper than waiting for another kernel), stream their
-//     packed weight rows through the MFMA, and only at the very end read the producers' granules (sc1 loads, polled until
-//     the tags match), sum them in ascending slab order, apply A_out and run the side path epilogue of gemm_smallm.hip.
+//     packed weight rows through the MFMA, and only at the very end read the producers' granules (sc1 loads, requested as
+//     the weight stream ends so that their round trip passes under the cross-wave combine, polled until the tags match),
+//     sum them in a fixed slab order, apply A_out and run the side path epilogue of gemm_smallm.hip.
+// The kernel is a chain of latencies (measured with -DLQER_D1_STAMPS, tools/d1_stamps.py, M = 1, K = N = 4096: first data
+// 1.4 us after entry - every kernel starts behind cold caches -, producers acked at ~3 us, weight stream done at ~4-5,
+// granule round trip 1.2, tail 1.8), so the tail is written for instruction COUNT: branch-free exponent rule, power-of-two
+// scaling by exponent bits instead of ldexpf, DPP / v_permlane*_swap maxima instead of LDS shuffles, the workgroup's
+// "all granules seen" vote carried by a barrier that is there anyway, bias and B fragments requested before the wait.
 // No workgroup ever waits for a consumer, producers wait for nobody, and the poll is bounded: if a granule has not arrived
 // after QD1_SPIN sweeps (it has, in practice, long before a consumer asks - producers are the first blocks of the grid and
 // finish in ~2 us) the consumer workgroup computes every partial tile itself with the producers' own routine (same bits)
@@ -37,16 +43,27 @@ constexpr int XAQ_BYTES = MAXM * 64 * 2;
 constexpr int PSLAB_BYTES = MAXM * SLAB_K * 2;
 constexpr int PRED_BYTES = (NW - 1) * MAXNT * 4 * 64 * 4;
 
+#ifndef LQER_D1_PREFETCH
+#define LQER_D1_PREFETCH 1  // where the first granule batch is requested: 0 after the combine, 1 at the end of the weight stream, 2 inside its last iteration
+#endif
 #ifdef LQER_D1_STAMPS
 __device__ unsigned long long* g_d1_stamps = nullptr;  // diagnostic build: s_memrealtime (100 MHz) at the phases of every workgroup
 #define D1_STAMP(i)                                                                                            \
   do {                                                                                                         \
     unsigned long long t_;                                                                                     \
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
-    if (g_d1_stamps && tid == 0) g_d1_stamps[(size_t)blockIdx.x * 8 + (i)] = t_;                                \
+    if (g_d1_stamps && tid == 0) g_d1_stamps[(size_t)blockIdx.x * 16 + (i)] = t_;                                \
+  } while (0)
+// (after the instruction that produced `dep`: a stamp behind a load's first use)
+#define D1_STAMP_AFTER(i, dep)                                                                                 \
+  do {                                                                                                         \
+    unsigned long long t_;                                                                                     \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                 \
+    if (g_d1_stamps && tid == 0) g_d1_stamps[(size_t)blockIdx.x * 16 + (i)] = t_;                                \
   } while (0)
 #else
 #define D1_STAMP(i)
+#define D1_STAMP_AFTER(i, dep)
 #endif
 
 struct Args {
@@ -143,18 +160,28 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   bf16_t* const xaq_l = (bf16_t*)(smem + xs_bytes + RED_BYTES);
   unsigned char* const pslab = smem + xs_bytes + RED_BYTES + XAQ_BYTES;
   float* const pred = (float*)(pslab + PSLAB_BYTES);
+  volatile uint32_t* const miss_flag = (volatile uint32_t*)(pred + 4 * 128 * 4);  // behind the [4][128] float4 group sums
+  if (tid == 0) *miss_flag = 0u;  // (ordered before its use by the barriers below)
   const auto gran_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, a.np * MAXM * rp * 8, 0x00020000);
   const int nt16 = rp / 16;
 
   // ---- the partial tile of x A of slab p, published as granules (the producers' whole job; a consumer's fall-back)
   auto produce = [&](int p) {
-    // this wave's A^T fragments first: they do not depend on x, and their L2 / HBM latency then passes under the quantizer
-    const int64_t k = (int64_t)p * SLAB_K + 32 * wave;
-    bf16x8 af[MAXNT];
+    // Waves 0..3 multiply (2 k-slices of 32 each, accumulated in the MFMA in ascending k; total = ((w0 + w1) + w2) + w3): a
+    // partial tile is a dependent chain - loads, quantize, MFMA, combine, publish - whose length the consumers wait for at
+    // their very end, so it is kept short: three hand-overs through LDS instead of seven, only the live rank tiles.
+    // Their A^T fragments come first: they do not depend on x, and their L2 / HBM latency then passes under the quantizer.
+    constexpr int PW = 4, PS = SLAB_K / 32 / PW;  // multiplying waves, k-slices of 32 per wave
+    bf16x8 af[PS][MAXNT];
+    const int64_t kw = (int64_t)p * SLAB_K + 32 * PS * wave;
+    if (wave < PW) {
 #pragma unroll
-    for (int t = 0; t < MAXNT; ++t) {
-      af[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (t < nt16 && k < Kp) af[t] = *(const bf16x8*)(a.a_t + (int64_t)(16 * t + l15) * Kp + k + 8 * lq);
+      for (int sl = 0; sl < PS; ++sl)
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t) {
+          af[sl][t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (t < nt16 && kw + 32 * sl < Kp) af[sl][t] = *(const bf16x8*)(a.a_t + (int64_t)(16 * t + l15) * Kp + kw + 32 * sl + 8 * lq);
+        }
     }
     // quantize the slab: threads 0..127 take block (row t >> 4, segment t & 15); rows >= M and k >= K are zeros
     if (tid < MAXM * 16) {
@@ -166,27 +193,32 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
         load_block16<DT>(a.x, row * a.ldx + k0, v);
         quant_block16<DT>(v, a.qx, w);
       }
+      if (tid == 0) D1_STAMP_AFTER(6, w[0]);
       *(uint4*)(pslab + img_off(row, 2 * seg, SLAB_K * 2)) = make_uint4(w[0], w[1], w[2], w[3]);
       *(uint4*)(pslab + img_off(row, 2 * seg + 1, SLAB_K * 2)) = make_uint4(w[4], w[5], w[6], w[7]);
     }
     __syncthreads();
-    // wave w multiplies the slab's k [32 w, 32 w + 32): A operand = tokens (row l15 & 7: rows 8..15 duplicate 0..7 and
-    // are never published), B operand = A^T (lane: rank entry 16 t + l15, k + 8 lq)
+    // A operand = tokens (row l15 & 7: rows 8..15 duplicate 0..7 and are never published), B operand = A^T (lane: rank
+    // entry 16 t + l15, k + 8 lq)
     f32x4 acc[MAXNT];
 #pragma unroll
     for (int t = 0; t < MAXNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (k < Kp) {
-      const bf16x8 xf = *(const bf16x8*)(pslab + img_off(l15 & 7, 4 * wave + lq, SLAB_K * 2));
+    if (wave < PW) {
 #pragma unroll
-      for (int t = 0; t < MAXNT; ++t)
-        if (t < nt16) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, af[t], acc[t], 0, 0, 0);
+      for (int sl = 0; sl < PS; ++sl)
+        if (kw + 32 * sl < Kp) {
+          const bf16x8 xf = *(const bf16x8*)(pslab + img_off(l15 & 7, 4 * (PS * wave + sl) + lq, SLAB_K * 2));
+#pragma unroll
+          for (int t = 0; t < MAXNT; ++t)
+            if (t < nt16) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, af[sl][t], acc[t], 0, 0, 0);
+        }
     }
-    // fixed-order combine ((w0 + w1) + ... + w7)
-    if (wave > 0) {
+    if (wave > 0 && wave < PW) {
 #pragma unroll
       for (int t = 0; t < MAXNT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pred[(((wave - 1) * MAXNT + t) * 4 + j) * 64 + lane] = acc[t][j];
+        for (int j = 0; j < 4; ++j)
+          if (t < nt16) pred[(((wave - 1) * MAXNT + t) * 4 + j) * 64 + lane] = acc[t][j];
     }
     __syncthreads();
     if (wave == 0) {
@@ -194,11 +226,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
       for (int t = 0; t < MAXNT; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float sum = acc[t][j];
-#pragma unroll
-          for (int w2 = 0; w2 < NW - 1; ++w2) sum += pred[((w2 * MAXNT + t) * 4 + j) * 64 + lane];
           const int row = 4 * lq + j;  // lane holds token rows 4 lq + j, rank entry 16 t + l15
           if (t < nt16 && row < M) {
+            float sum = acc[t][j];
+#pragma unroll
+            for (int w2 = 0; w2 < PW - 1; ++w2) sum += pred[((w2 * MAXNT + t) * 4 + j) * 64 + lane];
             const u32x2_t gv = {__float_as_uint(sum), a.nonce};
             __builtin_amdgcn_raw_buffer_store_b64(gv, gran_rsrc, (((p * MAXM + row) * rp) + 16 * t + l15) * 8, 0, 16);  // sc1
           }
@@ -263,6 +295,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
     uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (b == tid) {
       if (has_first) quant_block16<DT>(v0, a.qx, w);
+      if (tid == 0) D1_STAMP_AFTER(6, w[0]);
     } else if (seg * 16 < a.K) {
       float v[16];
       load_block16<DT>(a.x, r * a.ldx + seg * 16, v);
@@ -288,75 +321,121 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0, x0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1, x1, acc, 0, 0, 0);
   };
+  // ---- x A from the producers' granules: one thread per 4 rank entries of a token, slabs summed in a fixed order.
+  // The 512 threads read the granules as 4 groups x 128 items: group pg takes the slabs pg, pg + 4, pg + 8, ... (4 requested
+  // together: one memory round trip per batch), the groups' sums are added in the order 0..3 through LDS.  The FIRST batch
+  // is requested inside the main loop's last iteration, behind the last weight panels: loads return in order, so the
+  // granules are there when the weight stream ends (their ~1.3 us round trip past this CU's caches is not paid after it).
+  const int items = lowrank ? M * rp / 4 : 0;  // <= 128
+  const int rq = lowrank ? rp / 4 : 1;
+  const int pg = tid >> 7, it = tid & 127;
+  const int g_r = it / rq, g_c4 = it - g_r * rq;
+  struct GBatch {
+    u32x4_t v0[4], v1[4];
+  };
+  auto gather_issue = [&](int p0, GBatch& b) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + 4 * u;
+      const int off = (it < items && p < a.np) ? (((p * MAXM + g_r) * rp) + 4 * g_c4) * 8 : 0x7ffffff0;  // (past the range: zeros)
+      b.v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);       // sc1: past this CU's L1
+      b.v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
+    }
+  };
+  GBatch gb;
   // (no tests around loads or MFMAs: a panel past the end is zeros times the image's first chunk)
   for (int i = 0; i < per_wave; i += 2 * UNR) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) load_panel(kt_of(i + UNR + u), pb[u]);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + u), pa[u]);
+    // (unconditional: every other iteration requests out-of-range offsets, which cost no memory access - a load under a
+    // branch would make the compiler wait for everything in flight at the next use)
+#if LQER_D1_PREFETCH == 2
+    gather_issue(lowrank && i + 2 * UNR >= per_wave ? pg : (1 << 20), gb);
+#endif
 #pragma unroll
     for (int u = 0; u < UNR; ++u) load_panel(kt_of(i + 2 * UNR + u), pa[u]);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + UNR + u), pb[u]);
   }
 
+#if LQER_D1_PREFETCH == 2
+  if (per_wave <= 0) gather_issue(lowrank ? pg : (1 << 20), gb);  // (a wave without panels: K < 64 x 8)
+#elif LQER_D1_PREFETCH == 1
+  gather_issue(lowrank ? pg : (1 << 20), gb);  // at the end of the weight stream: under the cross-wave combine
+#endif
   D1_STAMP(2);
-  // fixed-order combine: (((w0 + w1) + w2) + ...) + w7
+
+  // fixed-order combine of the main product: (((w0 + w1) + w2) + ...) + w7, summed by wave 0 while the granules travel
   if (wave > 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[((wave - 1) * 4 + j) * 64 + lane] = acc[j];
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (not __syncthreads(): that would wait for the granule loads)
   D1_STAMP(3);
-
   // wave 0 requests the first side-path fragment of B now: its latency passes under the granule round trip (requested at
   // the top of the kernel it would sit under a branch in front of the weight stream and cost a register for the whole loop)
   bf16x8 sp_b = zero8;
   if (lowrank && wave == 0 && g.b_limbs > 0 && 8 * q < rp) sp_b = *(const bf16x8*)(g.bt + (int64_t)(n0 + row) * rp + 8 * q);
-  // ---- x A from the producers' granules: one thread per 4 rank entries of a token, slabs summed in ascending order
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};  // (the bias image is padded to Np: columns n0 + 4 q .. + 3 exist)
+  if (wave == 0 && g.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = g.bias[n0 + 4 * q + j];
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int w2 = 0; w2 < NW - 1; ++w2) acc[j] += red[(w2 * 4 + j) * 64 + lane];
+  }
   if (lowrank) {
-    const int items = M * rp / 4;  // <= 128
-    const int rq = rp / 4;
-    // the 512 threads read the granules as 4 groups x 128 items: group pg takes the slabs pg, pg + 4, pg + 8, ... (4 requested
-    // together: one memory round trip per batch), the groups' sums are added in the order 0..3 through LDS - a fixed order
-    auto gather = [&](int sweeps, bool& complete) -> float4 {
+    // prefetched: the first batch is already in flight (gb)
+    auto gather = [&](int sweeps, bool& complete, bool prefetched) -> float4 {
       float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
       complete = true;
-      const int pg = tid >> 7, it = tid & 127;
       if (it < items) {
-        const int r = it / rq, c4 = it - r * rq;
         for (int p0 = pg; p0 < a.np; p0 += 16) {
-          u32x4_t v0[4], v1[4];
+          if (!(prefetched && p0 == pg)) gather_issue(p0, gb);
+          auto tagged = [&](const u32x4_t& x0, const u32x4_t& x1) {
+            return x0[1] == a.nonce && x0[3] == a.nonce && x1[1] == a.nonce && x1[3] == a.nonce;
+          };
+          bool ok[4], all_ok = true;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const int p = p0 + 4 * u;
-            const int off = p < a.np ? (((p * MAXM + r) * rp) + 4 * c4) * 8 : 0x7ffffff0;  // (past the range: zeros)
-            v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);       // sc1: past this CU's L1
-            v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
+            ok[u] = p0 + 4 * u >= a.np || tagged(gb.v0[u], gb.v1[u]);
+            all_ok = all_ok && ok[u];
           }
+          for (int tries = 0; tries < sweeps && !all_ok; ++tries) {  // not all there yet: poll the missing slabs TOGETHER
+            __builtin_amdgcn_s_sleep(8);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int p = p0 + 4 * u;
-            if (p < a.np) {
-              const int off = (((p * MAXM + r) * rp) + 4 * c4) * 8;
-              u32x4_t x0 = v0[u], x1 = v1[u];
-              bool ok = x0[1] == a.nonce && x0[3] == a.nonce && x1[1] == a.nonce && x1[3] == a.nonce;
-              for (int tries = 0; tries < sweeps && !ok; ++tries) {  // not there yet: poll this slab
-                __builtin_amdgcn_s_sleep(8);
-                x0 = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);
-                x1 = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
-                ok = x0[1] == a.nonce && x0[3] == a.nonce && x1[1] == a.nonce && x1[3] == a.nonce;
+            for (int u = 0; u < 4; ++u)
+              if (!ok[u]) {
+                const int off = ((((p0 + 4 * u) * MAXM + g_r) * rp) + 4 * g_c4) * 8;
+                gb.v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);
+                gb.v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
               }
-              if (!ok) complete = false;
-              sum.x += __uint_as_float(x0[0]), sum.y += __uint_as_float(x0[2]);
-              sum.z += __uint_as_float(x1[0]), sum.w += __uint_as_float(x1[2]);
+            all_ok = true;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (!ok[u]) ok[u] = tagged(gb.v0[u], gb.v1[u]);
+              all_ok = all_ok && ok[u];
             }
           }
+          if (!all_ok) complete = false;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (p0 + 4 * u < a.np) {  // ascending slabs within the group
+              sum.x += __uint_as_float(gb.v0[u][0]), sum.y += __uint_as_float(gb.v0[u][2]);
+              sum.z += __uint_as_float(gb.v1[u][0]), sum.w += __uint_as_float(gb.v1[u][2]);
+            }
         }
       }
       float4* const gs = (float4*)pred;  // [4][128]
       gs[tid] = sum;
+      if (!complete) *miss_flag = 1u;  // the workgroup's vote rides on the barrier of the group sums
       __syncthreads();
+      complete = *miss_flag == 0u;
       if (tid < 128) {
         const float4 s1 = gs[128 + tid], s2 = gs[256 + tid], s3 = gs[384 + tid];
         sum.x = ((sum.x + s1.x) + s2.x) + s3.x, sum.y = ((sum.y + s1.y) + s2.y) + s3.y;
@@ -365,19 +444,20 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
       return sum;  // (threads 0 .. items-1 hold the totals)
     };
     bool complete;
-    float4 s = gather(a.spin, complete);
+    float4 s = gather(a.spin, complete, LQER_D1_PREFETCH != 0);
     D1_STAMP(4);
-    if (__syncthreads_or(complete ? 0 : 1)) {
+    if (!complete) {  // (workgroup-uniform: read back from LDS behind the barrier)
       // a producer has not been seen: compute every partial tile here (same routine, same bits), then read them back
       for (int p = 0; p < a.np; ++p) produce(p);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      s = gather(64, complete);  // (written by this very workgroup: there after its own drain + barrier)
+      s = gather(64, complete, false);  // (written by this very workgroup: there after its own drain + barrier)
     }
+    D1_STAMP(7);
     // A_out in blocks of 16 = 4 consecutive threads
     float amax = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0xB1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0x4E, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
     if (tid < items) {
       const bool any = amax > 0.f;
       const int e = any ? block_exponent(amax, g.aout) : 0;
@@ -385,19 +465,16 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
       uint32_t w[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float m0v = any ? mxint_mantissa(v[2 * i], e, g.aout) : 0.f;
-        const float m1v = any ? mxint_mantissa(v[2 * i + 1], e, g.aout) : 0.f;
-        w[i] = exact_bf16_bits(ldexpf(m0v, e - g.aout.mbits)) | (exact_bf16_bits(ldexpf(m1v, e - g.aout.mbits)) << 16);
+        const float q0 = any && fabsf(v[2 * i]) > g.aout.tiny ? mxint_value(v[2 * i], e, g.aout) : 0.f;
+        const float q1 = any && fabsf(v[2 * i + 1]) > g.aout.tiny ? mxint_value(v[2 * i + 1], e, g.aout) : 0.f;
+        w[i] = exact_bf16_bits(q0) | (exact_bf16_bits(q1) << 16);
       }
       *(uint2*)(xaq_l + tid * 4) = make_uint2(w[0], w[1]);
     }
     __syncthreads();
   }
+  D1_STAMP(8);
   if (wave != 0) return;
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int w2 = 0; w2 < NW - 1; ++w2) acc[j] += red[(w2 * 4 + j) * 64 + lane];
 
   // ---- side path + bias + store (wave 0, gemm_smallm.hip's epilogue): lane = token `row`, output columns n0 + 4 q + j
   const int nq = n0 + 4 * q;
@@ -416,27 +493,26 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
         }
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, xv, s, 0, 0, 0);
       }
+    D1_STAMP_AFTER(9, s[0]);
     if constexpr (BOUT == 1) {
       float amax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3])));
-      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-      const int e = block_exponent(amax, g.bout);
-      const int mb = g.bout.mbits;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float v = s[j];
-        const float m = fminf(rintf(ldexpf(fabsf(v) + 1e-9f, mb - e)), g.bout.mmax);
-        const float qv = copysignf(ldexpf(m, e - mb), v);
-        s[j] = fabsf(v) <= 1e-8f ? v : qv;
+      {  // max over lanes l, l ^ 16, l ^ 32 without the LDS crossbar: v_permlane16_swap / v_permlane32_swap
+        auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+        amax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+        auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+        amax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
       }
+      const int e = block_exponent(amax, g.bout);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] = fabsf(s[j]) <= 1e-8f ? s[j] : mxint_value(s[j], e, g.bout);
     }
   }
+  D1_STAMP_AFTER(10, s[0]);
   if (row < M) {
+    float out[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float out = (s[j] + (g.bias ? g.bias[nq + j] : 0.f)) + acc[j];
-      if (nq + j < g.N) store_elem<DT>(g.y, (int64_t)row * g.ldy + nq + j, out);
-    }
+    for (int j = 0; j < 4; ++j) out[j] = (s[j] + bias4[j]) + acc[j];
+    store_row4<DT>(g.y, (int64_t)row * g.ldy + nq, nq, g.N, out);
   }
   D1_STAMP(5);
 }

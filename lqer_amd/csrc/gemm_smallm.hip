@@ -23,9 +23,11 @@ constexpr int SM_MAX_M = 64;   // tokens handled by this kernel (MT = ceil(M / 1
 constexpr int SM_NW = 8;       // waves per workgroup: wave w takes panels w, w + 8, ...
 template <int MT> struct SmUnr { static constexpr int v = MT <= 2 ? 4 : 2; };  // panels per register buffer (two buffers)
 
-__device__ __forceinline__ float quad16_max(float v) {  // max over lanes l, l^16, l^32, l^48
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+__device__ __forceinline__ float quad16_max(float v) {  // max over lanes l, l^16, l^32, l^48 (no LDS crossbar: the swaps)
+  auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+  auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
 }
 
 struct SmPanel {
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
           }
         }
         float amax = fmaxf(fmaxf(fabsf(sum.x), fabsf(sum.y)), fmaxf(fabsf(sum.z), fabsf(sum.w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0xB1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
+        amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(amax), 0x4E, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
         if (live) {
           const bool any = amax > 0.f;
           const int e = any ? block_exponent(amax, g.aout) : 0;
@@ -141,9 +143,9 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
           uint32_t w[2];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const float m0v = any ? mxint_mantissa(v[2 * i], e, g.aout) : 0.f;
-            const float m1v = any ? mxint_mantissa(v[2 * i + 1], e, g.aout) : 0.f;
-            w[i] = exact_bf16_bits(ldexpf(m0v, e - g.aout.mbits)) | (exact_bf16_bits(ldexpf(m1v, e - g.aout.mbits)) << 16);
+            const float q0 = any && fabsf(v[2 * i]) > g.aout.tiny ? mxint_value(v[2 * i], e, g.aout) : 0.f;
+            const float q1 = any && fabsf(v[2 * i + 1]) > g.aout.tiny ? mxint_value(v[2 * i + 1], e, g.aout) : 0.f;
+            w[i] = exact_bf16_bits(q0) | (exact_bf16_bits(q1) << 16);
           }
           *(uint2*)(xaq_l + item * 4) = make_uint2(w[0], w[1]);
         }
@@ -207,14 +209,8 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
         float amax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3])));
         amax = quad16_max(amax);
         const int e = block_exponent(amax, g.bout);  // amax = 0: every element takes the pass-through
-        const int mb = g.bout.mbits;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = s[j];
-          const float m = fminf(rintf(ldexpf(fabsf(v) + 1e-9f, mb - e)), g.bout.mmax);
-          const float qv = copysignf(ldexpf(m, e - mb), v);
-          s[j] = fabsf(v) <= 1e-8f ? v : qv;
-        }
+        for (int j = 0; j < 4; ++j) s[j] = fabsf(s[j]) <= 1e-8f ? s[j] : mxint_value(s[j], e, g.bout);
       }
     }
     // same association as the tile kernel: the side path and the bias form the initial accumulator
@@ -222,11 +218,7 @@ __global__ __launch_bounds__(64 * SM_NW) void k_lqer_gemm_smallm(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j] = (s[j] + (g.bias ? g.bias[nq + j] : 0.f)) + acc[t][j];
     const int m = t * 16 + row;
-    if (m < g.M) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (nq + j < g.N) store_elem<DT>(g.y, (int64_t)m * g.ldy + nq + j, out[j]);
-    }
+    if (m < g.M) store_row4<DT>(g.y, (int64_t)m * g.ldy + nq, nq, g.N, out);
   }
 }
 

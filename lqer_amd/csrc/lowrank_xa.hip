@@ -429,8 +429,16 @@ __global__ __launch_bounds__(QX_K) void k_quant_xa16(const void* __restrict__ x,
         }
       }
       uint4* dst = (uint4*)(xq + m * Kp + k0);   // rows up to the padded M are allocated
+#ifdef LQER_XQ_STORE_MODS  // cache-policy experiment (tools/ab_step.py): e.g. -DLQER_XQ_STORE_MODS='"nt"'
+      {
+        const u32x4 lo = {w[0], w[1], w[2], w[3]}, hi = {w[4], w[5], w[6], w[7]};
+        asm volatile("global_store_dwordx4 %0, %1, off " LQER_XQ_STORE_MODS "\n\tglobal_store_dwordx4 %0, %2, off offset:16 " LQER_XQ_STORE_MODS
+                     ::"v"(dst), "v"(lo), "v"(hi) : "memory");
+      }
+#else
       dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
       dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#endif
     }
     *(uint4*)(slab + qx_swz(row, 2 * seg)) = make_uint4(w[0], w[1], w[2], w[3]);
     *(uint4*)(slab + qx_swz(row, 2 * seg + 1)) = make_uint4(w[4], w[5], w[6], w[7]);

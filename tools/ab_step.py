@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--r", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--gap", type=int, default=0, help="tiny unrelated kernels launched between the quantizer and the GEMM (boundary-effect probe)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, K, N, r = a.M, a.K, a.N, a.r
@@ -47,11 +48,17 @@ def main():
     nscr = libs[0][1].lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
     scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
 
+    dummy = torch.zeros(64, device=dev)
+
     def run(L):
-        rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xaq.data_ptr(),
+        # (a build whose GEMM sums the partial tiles of x A itself - lqer_decode_partials - gets no xaq: two launches)
+        xa = None if L.lqer_decode_partials(C.byref(desc), M) else xaq.data_ptr()
+        rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xa,
                                     scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
-        rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(),
+        for _ in range(a.gap):
+            dummy.add_(1.0)
+        rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xa, bt.data_ptr(), 1, None, y.data_ptr(),
                                 _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
 

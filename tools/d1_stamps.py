@@ -16,16 +16,19 @@ mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={
 mod.load_state_dict({"weight": W, "A": A, "B": B}); mod = mod.to(dev).half()
 xd = x[:M].half().to(dev)
 npd = -(-K // 256); nb = npd + (-(-N // 256) * 256) // 16
-buf = torch.zeros(nb * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(nb * 16, dtype=torch.int64, device=dev)
 for _ in range(20): mod(xd)
 L.lqer_debug_set_d1_stamps(buf.data_ptr())
 for _ in range(5): mod(xd)
 torch.cuda.synchronize()
-b = buf.cpu().view(nb, 8).double()
+b = buf.cpu().view(nb, 16).double()
 t0 = b[:, 0].min()
 us = (b - t0) / 100.0
 prod, cons = us[:npd], us[npd:]
 print(f"K={K} N={N} M={M}: {npd} producers, {nb - npd} consumers; times in us after the first workgroup's entry (median / max)")
-print(f"  producers: entry {prod[:,0].median():.2f} / {prod[:,0].max():.2f}, published {prod[:,5].median():.2f} / {prod[:,5].max():.2f}")
-for i, name in enumerate(["entry", "activation image", "main loop done", "combined", "granules gathered", "end"]):
+print(f"  producers: entry {prod[:,0].median():.2f} / {prod[:,0].max():.2f}, x quantized {prod[:,6].median():.2f} / {prod[:,6].max():.2f}, "
+      f"published {prod[:,5].median():.2f} / {prod[:,5].max():.2f}")
+print(f"  consumers: first x block quantized {cons[:,6].median():6.2f} / {cons[:,6].max():6.2f}")
+for i, name in [(0, "entry"), (1, "activation image"), (2, "main loop done"), (3, "combined"), (4, "granules gathered"), (7, "all waves agree"),
+                (8, "A_out staged"), (9, "side MFMA"), (10, "B_out"), (5, "end")]:
     print(f"  consumers: {name:18s} {cons[:,i].median():6.2f} / {cons[:,i].max():6.2f}")
