@@ -116,6 +116,37 @@ __device__ __forceinline__ void load_block16(const void* x, int64_t off, float (
   }
 }
 
+// the same block as the bytes it is stored in (a request that costs 8 registers for the 16-bit types, converted at its use)
+template <int DT>
+struct RawBlk {
+  u32x4 r[DT == LQER_F32 ? 4 : 2];
+};
+template <int DT>
+__device__ __forceinline__ void load_raw16(const void* x, int64_t off, RawBlk<DT>& b) {
+  const u32x4* p = (const u32x4*)((const char*)x + off * (DT == LQER_F32 ? 4 : 2));
+#pragma unroll
+  for (int i = 0; i < (DT == LQER_F32 ? 4 : 2); ++i) b.r[i] = p[i];
+}
+template <int DT>
+__device__ __forceinline__ void raw16_to_f32(const RawBlk<DT>& b, float (&v)[16]) {
+  if constexpr (DT == LQER_F32) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = __uint_as_float(b.r[i >> 2][i & 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t w = b.r[i >> 2][i & 3];
+      if constexpr (DT == LQER_F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const h2 h = __builtin_bit_cast(h2, w);
+        v[2 * i] = (float)h[0], v[2 * i + 1] = (float)h[1];
+      } else {
+        v[2 * i] = __uint_as_float(w << 16), v[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+      }
+    }
+  }
+}
+
 // one block of 16 -> its exact bf16 image (the arithmetic of k_quant_seg16 / k_quant_xa16: bit-identical images)
 template <int DT>
 __device__ __forceinline__ void quant_block16(const float (&v)[16], const QP& q, uint32_t (&w)[8]) {
@@ -271,38 +302,46 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   SmPanel pa[UNR], pb[UNR];
   const int per_wave = (nk - wave + NW - 1) / NW;
   auto kt_of = [&](int i) { return wave + NW * i; };
-  // this thread's first block of x is requested BEFORE the weight panels (loads complete in order: the small L2-hot read
-  // must not queue behind the weight stream)
+  // this thread's first XB blocks of x are requested BEFORE the weight panels (loads complete in order: the small L2-hot
+  // reads must not queue behind the weight stream) and all together - one round trip for up to 4 x 512 blocks (M = 8, K = 4096)
+  // instead of one per block.  Always loaded, from a clamped in-range offset: a load under a branch would make the compiler
+  // wait for everything in flight at its first use; threads without such a block ignore the values.
   const int segs = Kp / 16;
-  float v0[16];
-  bool has_first;
-  {
-    const int r0 = tid / segs, seg0 = tid - r0 * segs;
-    const bool has0 = tid < M * segs && seg0 * 16 < a.K;
-    // (always loaded, from a clamped in-range offset: a load under a branch would make the compiler wait for everything in
-    // flight at its first use; threads without a block of their own ignore the values)
-    load_block16<DT>(a.x, has0 ? r0 * a.ldx + seg0 * 16 : 0, v0);
-    has_first = has0;
-    asm volatile("" ::: "memory");  // (keeps the request HERE: the compiler otherwise sinks it to its use, behind the panels)
-  }
+  constexpr int XB = DT == LQER_F32 ? 2 : 4;  // (8 registers per 16-bit block, 16 per fp32 block)
+  RawBlk<DT> rb[XB];
+  auto request_x = [&](int b0) {
+#pragma unroll
+    for (int u = 0; u < XB; ++u) {
+      const int b = b0 + 64 * NW * u;
+      const int r = b / segs, seg = b - r * segs;
+      load_raw16<DT>(a.x, b < M * segs && seg * 16 < a.K ? r * a.ldx + seg * 16 : 0, rb[u]);
+    }
+  };
+  request_x(tid);
+  asm volatile("" ::: "memory");  // (keeps the requests HERE: the compiler otherwise sinks them to their use, behind the panels)
 #pragma unroll
   for (int u = 0; u < UNR; ++u) load_panel(kt_of(u), pa[u]);
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // ---- the activation image of ALL of x in LDS: block b = (row b / (Kp/16), segment b % (Kp/16))
-  for (int b = tid; b < M * segs; b += 64 * NW) {
-    const int r = b / segs, seg = b - r * segs;
-    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (b == tid) {
-      if (has_first) quant_block16<DT>(v0, a.qx, w);
-      if (tid == 0) D1_STAMP_AFTER(6, w[0]);
-    } else if (seg * 16 < a.K) {
-      float v[16];
-      load_block16<DT>(a.x, r * a.ldx + seg * 16, v);
-      quant_block16<DT>(v, a.qx, w);
+  for (int b0 = tid; b0 < M * segs; b0 += 64 * NW * XB) {
+    if (b0 != tid) request_x(b0);
+#pragma unroll
+    for (int u = 0; u < XB; ++u) {
+      const int b = b0 + 64 * NW * u;
+      if (b < M * segs) {
+        const int r = b / segs, seg = b - r * segs;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (seg * 16 < a.K) {
+          float v[16];
+          raw16_to_f32<DT>(rb[u], v);
+          quant_block16<DT>(v, a.qx, w);
+        }
+        if (u == 0 && tid == 0) D1_STAMP_AFTER(6, w[0]);
+        *(uint4*)(xs + img_off(r, 2 * seg, xpitch)) = make_uint4(w[0], w[1], w[2], w[3]);
+        *(uint4*)(xs + img_off(r, 2 * seg + 1, xpitch)) = make_uint4(w[4], w[5], w[6], w[7]);
+      }
     }
-    *(uint4*)(xs + img_off(r, 2 * seg, xpitch)) = make_uint4(w[0], w[1], w[2], w[3]);
-    *(uint4*)(xs + img_off(r, 2 * seg + 1, xpitch)) = make_uint4(w[4], w[5], w[6], w[7]);
   }
   __syncthreads();
   D1_STAMP(1);
