@@ -395,6 +395,49 @@ def main():
         el_mod = sweep.max_over_ranks(timed_region(lambda n: [step_module() for _ in range(n)], args.steps), dev)
         module = {"ms_per_step": round(el_mod / args.steps * 1e3, 4), "vs_c_abi": round(el_mod / elapsed, 4)}
 
+    # third timed region (model workloads): the same Linears the way the model runs them - q/k/v and
+    # gate/up receive ONE tensor, so its activation image and one side GEMM over the members' concatenated A are made once
+    # per group (lqer_amd.linear.SharedActivation; same quantizers and GEMM kernels, results as member by member).  The
+    # headline `value` stays the conservative one: every Linear quantizes its own input, as the reference's modules do.
+    model_shared = None
+    if not args.no_module and layers > 1 and layers_here > 0:
+        import copy
+
+        from lqer_amd.linear import SharedActivation
+
+        try:
+            units = []  # per shape: (group members, solo module or None, solo calls per layer, x)
+            for mod, xd, K, N, reps, _, _ in mods:
+                cnt = reps // layers_here
+                gsz = 3 if (cnt >= 3 and K == N) else (2 if cnt == 2 else 0)
+                solo_n = cnt - gsz
+                copies = [copy.deepcopy(mod) for _ in range(max(gsz - 1, 0) + (1 if solo_n else 0))]
+                solo = copies.pop() if solo_n else None
+                members = []
+                if gsz:
+                    grp = SharedActivation([mod] + copies)
+                    members = grp.members if grp.enabled else []
+                    if not grp.enabled:
+                        solo, solo_n = mod, cnt
+                units.append((members, solo, solo_n, xd))
+            if any(members for members, _, _, _ in units):
+                def step_shared():
+                    for _ in range(layers_here):
+                        for members, solo, solo_n, xd in units:
+                            for m in members:
+                                m(xd)
+                            for _ in range(solo_n):
+                                solo(xd)
+
+                for _ in range(max(1, args.warmup // 2)):
+                    step_shared()
+                el_sh = sweep.max_over_ranks(timed_region(lambda n: [step_shared() for _ in range(n)], args.steps), dev)
+                model_shared = {"ms_per_step": round(el_sh / args.steps * 1e3, 4), "vs_c_abi": round(el_sh / elapsed, 4),
+                                "groups_per_layer": [len(members) for members, _, _, _ in units if members]}
+
+        except Exception as e:  # (a secondary figure must not cost the bench line)
+            model_shared = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     # ---- gather (outside the timed regions): per-rank elapsed time, a checksum of the first unit's output
     ysum = float(mods[0][5].float().sum().item()) if layers_here > 0 else 0.0
     gathered = sweep.gather_rows([elapsed_rank * 1e3 / args.steps, ysum, float(layers_here)], dev)
@@ -505,6 +548,9 @@ def main():
             "broadcast_ms": round(broadcast_ms, 3),
             "roofline": roofline,
             "module": module,
+            # (model workloads) q/k/v and gate/up sharing one quantized input, as the model runs them; `value` does not use it
+            "model_shared_inputs": model_shared if model_shared is None or "error" in model_shared else dict(
+                model_shared, value=round(flops_all / (model_shared["ms_per_step"] * 1e-3) / 1e12, 2)),
             "parity_rel_l2": None if parity is None else float(f"{parity:.3e}"),
             "parity_rows": None if parity is None else int(len(check_rows(M))),
             "rank_ms_per_step": [round(row[0], 4) for row in gathered],

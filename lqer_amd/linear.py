@@ -371,7 +371,8 @@ class SharedActivation:
     A member's forward uses the shared images only when it is handed the very tensor object the images were made
     from, unmodified (object identity + version counter) - an equal-looking tensor at a recycled address never hits.
     Requirements checked at construction: same in_features, same block_fp x / A_out quantizers, A_out blocks of 16 or
-    one block per row with equal power-of-two ranks (a multiple of 16), rank > 0 for every member."""
+    one block per row with equal power-of-two ranks (a multiple of 16), rank > 0 for every member, padded ranks summing
+    to at most 256 (else `enabled` is False and nothing changes for the members)."""
 
     _pool = {}  # device -> {"xq", "xaq", "scr": uint8 tensors, "owner": (id(group), round)} - see forward_member
 
@@ -393,6 +394,9 @@ class SharedActivation:
             ok = whole and len(rps) == 1 and all(m.rank == rp0 for m in self.members) and (rp0 & (rp0 - 1)) == 0
             self._aout_block = rp0
         ok = ok and ao.kind == _lib.Q_MXINT and len(self.members) > 1
+        # the side GEMM kernels take a padded rank of at most 256 (csrc/lowrank_xa.hip): three rank-128 members do not fit
+        # in one concatenation - such a group stays disabled and its members run one by one
+        ok = ok and sum((m.rank + 15) // 16 * 16 for m in self.members) <= 256
         ok = ok and m0._fmt["x"].kind == _lib.Q_MXINT  # (pass-through activations: every member splits x itself)
         self.enabled = bool(ok)
         self._cat = None      # concatenated A^T limb image + member offsets

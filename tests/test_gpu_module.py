@@ -163,6 +163,32 @@ def test_shared_activation_groups_share_one_image_pool(lq):
         assert SharedActivation._pool[xs[0].device]["xq"].data_ptr() == ptr  # still the one pool
 
 
+@pytest.mark.parametrize("r,members,enabled", [(128, 3, False), (128, 2, True), (80, 3, True)])
+def test_shared_activation_respects_the_side_gemm_rank_limit(lq, r, members, enabled):
+    """The concatenated side GEMM takes a padded rank of at most 256: q/k/v of OPT-6.7B at rank 128 (384) cannot share one
+    concatenation - the group is then disabled at construction and its members run one by one (it used to fail at the first
+    forward); two such members (256) and three rank-80 members (240) do share."""
+    from bench import MXINT_Q, make_case
+    from lqer_amd.linear import SharedActivation
+
+    M, K, N = 130, 512, 256
+    mods = []
+    for i in range(members):
+        x, W, A, B = make_case(M, K, N, r, seed=70 + i)
+        m = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+        m.load_state_dict({"weight": W, "A": A, "B": B})
+        mods.append(m.to(DEV).half())
+    xd = x.half().to(DEV)
+    alone = [m(xd).clone() for m in mods]
+    grp = SharedActivation(mods)
+    assert grp.enabled == enabled
+    assert all((getattr(m, "_group", None) is grp) == enabled for m in mods)
+    with torch.no_grad():
+        for m, a in zip(mods, alone):
+            y = m(xd)
+            assert float((y.float() - a.float()).norm() / a.float().norm()) <= 2e-3
+
+
 @pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs in one process")
 def test_forward_on_a_non_current_device(lq):
     from bench import MXINT_Q, make_case
