@@ -104,7 +104,8 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `bash {BUILD_SCRIPT}` (or __graft_entry__.build()). "
                 "lqer_amd has no CPU fallback."
             )
-        L = C.CDLL(LIB_PATH)
+        # RTLD_NOW: an unresolved symbol (a kernel stub the host pass did not emit) fails HERE, not at the first launch
+        L = C.CDLL(LIB_PATH, mode=os.RTLD_NOW)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args

@@ -32,6 +32,7 @@
 namespace lqer {
 
 constexpr int BM = 128, BN = 256, BK = 64;
+constexpr int LQER_STAGE_MIN_DEFAULT = 32;  // side products of at most two 16-deep slices are fetched directly (launch_gemm)
 #ifndef LQER_DEPTH
 #define LQER_DEPTH 3
 #endif
@@ -125,8 +126,13 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 
 // BOUT: 0 pass-through, 1 blocks of 16 (max in registers), 2 any block (max from the pre-pass).  STAGED: the side product's
 // operands go through LDS (below) - a separate instantiation, so that the direct route keeps its own register allocation.
-template <int DT, bool LOWRANK, int BOUT, bool STAGED = false>
+// MT: 32-row tiles per wave = tile height / 32.  4: the 128 x 256 tile.  2: a 64 x 256 tile for token counts whose 128-row
+// grid leaves most of the chip idle (half the MFMA work per expanded weight fragment, twice the workgroups).
+template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4>
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
+  static_assert(MT == 4 || (MT == 2 && !STAGED), "64-row tiles: direct side path only");
+  constexpr int BMk = 32 * MT;   // tile rows
+  constexpr int AP = MT / 2;     // 8-row LDS-DMA pieces of the activation tile per wave and k-step
   constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image, weights expanded to fp16, v_mfma_f32_32x32x16_f16
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -142,18 +148,18 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   }
   const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMk, n0 = tn * BN;
   const int nk = g.Kp / BK;
 
   // ---- staging ------------------------------------------------------------------------------
   // activation: wave w stages tile rows [16w, 16w+16): 2 x LDS-DMA of 8 rows x 128 B.  Buffer
   // addressing: wave-uniform descriptor + per-lane byte offset fixed for the whole kernel + the
   // k-step as scalar offset, so a prefetch costs no vector ALU work.
-  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xq + (int64_t)m0 * g.Kp), 0, BM * g.Kp * 2, 0x00020000);
-  int a_voff[2];
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xq + (int64_t)m0 * g.Kp), 0, BMk * g.Kp * 2, 0x00020000);
+  int a_voff[2] = {0, 0};  // (AP entries used; a dependent-size array here makes hipcc's HOST pass drop the kernel's stub silently)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wave * 16 + i * 8 + (lane >> 3);
+  for (int i = 0; i < AP; ++i) {
+    const int row = wave * (8 * AP) + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_voff[i] = (row * g.Kp + chunk * 8) * 2;
   }
@@ -168,12 +174,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     return pnl * nk * LQER_PANEL_BYTES + (byte - pnl * LQER_PANEL_BYTES);
   };
   const int w_voff = w_piece_voff(wave), w_voff8 = w_piece_voff(8);
-  unsigned char* const a_dst0 = smem + OFF_A + wave * 16 * 128;  // + slot * A_SLOT + piece * 1024
+  unsigned char* const a_dst0 = smem + OFF_A + wave * (8 * AP) * 128;  // + slot * A_SLOT + piece * 1024
   unsigned char* const w_dst0 = smem + OFF_R + wave * 1024;      // + slot * R_SLOT
   auto issue_loads = [&](int kt, int slot) {  // 3 LDS-DMA instructions per wave (wave 0: 4)
 #ifndef LQER_ABL_NO_A_LOAD
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < AP; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(a_dst0 + slot * A_SLOT + i * 1024), 16, a_voff[i],
                                                kt * (BK * 2), 0, 0);
 #endif
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // instead of one per 16-deep slice, no 8-fold refetch of xAq by the 8 waves.  The loads of pass 0 are issued BEFORE
   // the ring prefetch (loads return in order: their results can then be awaited while the prefetch is in flight), and
   // the staging writes / fragment reads are asm statements, invisible to the waitcnt pass (see above).
-  constexpr int STG = STAGED ? BM * 8 / 512 : 1;  // staged 16-byte chunks per thread and pass
+  constexpr int STG = STAGED ? BMk * 8 / 512 : 1;  // staged 16-byte chunks per thread and pass
   u32x4 stg[STG];
   bf16x8 sb[STAGED ? 2 : 1][STAGED ? 4 : 1];  // B^T fragments of one limb of the pass, double-buffered
   const uint32_t stage = lds0 + OFF_A + (NSLOT - 1) * A_SLOT;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < STG; ++j) {
       const int c = tid + 512 * j;
-      if (c < BM * cpr) {
+      if (c < BMk * cpr) {
         const int row = c / cpr, ch = c - row * cpr;
         stg[j] = *(const u32x4*)(g.xaq + (int64_t)(m0 + row) * g.xaq_ld + p0 + 8 * ch);
       }
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // direct route (at most two 16-deep slices: rank <= 32 with one limb, or rank 16 with two): both slices' operands
   // are requested here, ahead of the ring prefetch, instead of one slice at a time behind it
   constexpr bool side_direct = LOWRANK && !STAGED;
-  bf16x8 db[side_direct ? 2 : 1], dx[side_direct ? 2 : 1][side_direct ? 4 : 1];
+  bf16x8 db[side_direct ? 2 : 1], dx[side_direct ? 2 : 1][side_direct ? MT : 1];
   const bool two_limbs = g.b_limbs > 1;  // (then rank 16: slice s = limb s; else slice s = rank entries 16 s ..)
   if constexpr (side_direct) {
 #pragma unroll
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       if (l < g.b_limbs && ks * 16 < g.rp) {
         db[sl] = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + wn * 32 + l31) * g.rp + ks * 16 + 8 * lh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dx[sl][i] = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
+        for (int i = 0; i < MT; ++i) dx[sl][i] = *(const bf16x8*)(g.xaq + (int64_t)(m0 + i * 32 + l31) * g.xaq_ld + ks * 16 + 8 * lh);
       }
     }
   }
@@ -257,9 +263,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue_loads(d, d);  // (past the end of K: dropped by the buffer range check)
 
-  f32x16 acc[4];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
 
@@ -271,11 +277,11 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         const int l = two_limbs ? sl : 0, ks = two_limbs ? 0 : sl;
         if (l < g.b_limbs && ks * 16 < g.rp) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(db[sl], dx[sl][i], acc[i], 0, 0, 0);
+          for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(db[sl], dx[sl][i], acc[i], 0, 0, 0);
         }
       }
     }
-    if constexpr (side_staged)
+    if constexpr (side_staged && MT == 4)
     for (int p0 = 0; p0 < g.rp; p0 += 64) {
       const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;
       const int cpr = cols >> 3;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < STG; ++j) {
         const int c = tid + 512 * j;
-        if (c < BM * cpr) {
+        if (c < BMk * cpr) {
           const int row = c / cpr, ch = c - row * cpr;
           lds_write128(stage + swz(row, ch), stg[j]);
         }
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     if constexpr (BOUT != 0) {
       const int mb = g.bout.mbits;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           float amax;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     for (int k = 0; k < 16; ++k) {
       const float bv = g.bias[n0 + wn * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][k] += bv;
+      for (int i = 0; i < MT; ++i) acc[i][k] += bv;
     }
   }
 
@@ -363,7 +369,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // anyone starts LOAD(kt).  WAR: slot (kt+3) % 4 held step kt-1, last read in LOAD(kt-1) of waves 4-7,
   // which ends (lgkmcnt(0)) before barrier 2kt-1; the overwriting loads are issued after it.
   const bool late = wave >= 4;
-  asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");  // loads(0) landed; two batches of 3 may stay in flight
+  // loads(0) landed; two batches of AP + 1 (3, or 2 with 64-row tiles) may stay in flight
+  if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
   if (late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
   // diagnostic build: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) around the whole main loop
@@ -380,11 +388,11 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   const unsigned long long w_base64 = (unsigned long long)w_base;
   const u32x4 a_rs = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a_base64),
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a_base64 >> 32)) & 0xffffu,
-                      (uint32_t)(BM * g.Kp * 2), 0x00020000u};
+                      (uint32_t)(BMk * g.Kp * 2), 0x00020000u};
   const u32x4 w_rs = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w_base64),
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w_base64 >> 32)) & 0xffffu,
                       (uint32_t)(16 * nk * LQER_PANEL_BYTES), 0x00020000u};
-  const uint32_t m0_a = lds0 + OFF_A + wave * 16 * 128;  // + slot * A_SLOT (+ 1024: second piece)
+  const uint32_t m0_a = lds0 + OFF_A + wave * (8 * AP) * 128;  // + slot * A_SLOT (+ 1024: second piece)
   const uint32_t m0_w = lds0 + OFF_R + wave * 1024;      // + slot * R_SLOT
   const uint32_t m0_w8 = lds0 + OFF_R + 8192;            // + slot * R_SLOT (piece 8, wave 0)
   // One k-step.  The ring slot is a compile-time constant (the loop below is unrolled by the ring size), so every
@@ -403,35 +411,56 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     const int a_soff = ktn * (BK * 2), w_soff = ktn * LQER_PANEL_BYTES;
     const uint32_t m0a0 = m0_a + slot_new * A_SLOT, m0a1 = m0a0 + 1024;
     const uint32_t m0w = m0_w + slot_new * R_SLOT, m0w8 = m0_w8 + slot_new * R_SLOT;
-    bf16x8 xa[4][4];  // [ks][m tile]
+    bf16x8 xa[4][MT];  // [ks][m tile]
     u32x4 wr;
     uint32_t we;
-    asm volatile(
-        "ds_read_b128 %0, %18 offset:%c25\n\tds_read_b32 %1, %19 offset:%c25+512\n\t"
-        "ds_read_b128 %2, %20 offset:%c24\n\tds_read_b128 %3, %20 offset:%c24+4096\n\t"
-        "ds_read_b128 %4, %20 offset:%c24+8192\n\tds_read_b128 %5, %20 offset:%c24+12288\n\t"
-        "ds_read_b128 %6, %21 offset:%c24\n\tds_read_b128 %7, %21 offset:%c24+4096\n\t"
-        "ds_read_b128 %8, %21 offset:%c24+8192\n\tds_read_b128 %9, %21 offset:%c24+12288\n\t"
-        "ds_read_b128 %10, %22 offset:%c24\n\tds_read_b128 %11, %22 offset:%c24+4096\n\t"
-        "ds_read_b128 %12, %22 offset:%c24+8192\n\tds_read_b128 %13, %22 offset:%c24+12288\n\t"
-        "ds_read_b128 %14, %23 offset:%c24\n\tds_read_b128 %15, %23 offset:%c24+4096\n\t"
-        "ds_read_b128 %16, %23 offset:%c24+8192\n\tds_read_b128 %17, %23 offset:%c24+12288\n\t"
-        "s_mov_b32 m0, %32\n\ts_nop 0\n\tbuffer_load_dwordx4 %26, %30, %36 offen lds\n\t"
-        "s_mov_b32 m0, %33\n\ts_nop 0\n\tbuffer_load_dwordx4 %27, %30, %36 offen lds\n\t"
-        "s_mov_b32 m0, %34\n\ts_nop 0\n\tbuffer_load_dwordx4 %28, %31, %37 offen lds\n\t"
-        "s_cmp_lg_u32 %38, 0\n\ts_cbranch_scc1 1f\n\t"
-        "s_mov_b32 m0, %35\n\ts_nop 0\n\tbuffer_load_dwordx4 %29, %31, %37 offen lds\n\t"
-        // own loads of step kt+1 landed: the batches of kt+2 and kt+3 (3 loads each, wave 0: 4 - it waits a little
-        // more than it must) may stay in flight
-        "1:\n\ts_waitcnt vmcnt(6) lgkmcnt(0)"
-        : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]),
-          "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),
-          "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])
-        : "v"(fw_addr), "v"(fe_addr), "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3]),  // 18..23
-          "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT),                                                         // 24, 25
-          "v"(a_voff[0]), "v"(a_voff[1]), "v"(w_voff), "v"(w_voff8),                                       // 26..29
-          "s"(a_rs), "s"(w_rs), "s"(m0a0), "s"(m0a1), "s"(m0w), "s"(m0w8), "s"(a_soff), "s"(w_soff), "s"(wave)  // 30..38
-        : "memory", "scc");  // (s_cmp inside)
+    if constexpr (MT == 4) {
+      asm volatile(
+          "ds_read_b128 %0, %18 offset:%c25\n\tds_read_b32 %1, %19 offset:%c25+512\n\t"
+          "ds_read_b128 %2, %20 offset:%c24\n\tds_read_b128 %3, %20 offset:%c24+4096\n\t"
+          "ds_read_b128 %4, %20 offset:%c24+8192\n\tds_read_b128 %5, %20 offset:%c24+12288\n\t"
+          "ds_read_b128 %6, %21 offset:%c24\n\tds_read_b128 %7, %21 offset:%c24+4096\n\t"
+          "ds_read_b128 %8, %21 offset:%c24+8192\n\tds_read_b128 %9, %21 offset:%c24+12288\n\t"
+          "ds_read_b128 %10, %22 offset:%c24\n\tds_read_b128 %11, %22 offset:%c24+4096\n\t"
+          "ds_read_b128 %12, %22 offset:%c24+8192\n\tds_read_b128 %13, %22 offset:%c24+12288\n\t"
+          "ds_read_b128 %14, %23 offset:%c24\n\tds_read_b128 %15, %23 offset:%c24+4096\n\t"
+          "ds_read_b128 %16, %23 offset:%c24+8192\n\tds_read_b128 %17, %23 offset:%c24+12288\n\t"
+          "s_mov_b32 m0, %32\n\ts_nop 0\n\tbuffer_load_dwordx4 %26, %30, %36 offen lds\n\t"
+          "s_mov_b32 m0, %33\n\ts_nop 0\n\tbuffer_load_dwordx4 %27, %30, %36 offen lds\n\t"
+          "s_mov_b32 m0, %34\n\ts_nop 0\n\tbuffer_load_dwordx4 %28, %31, %37 offen lds\n\t"
+          "s_cmp_lg_u32 %38, 0\n\ts_cbranch_scc1 1f\n\t"
+          "s_mov_b32 m0, %35\n\ts_nop 0\n\tbuffer_load_dwordx4 %29, %31, %37 offen lds\n\t"
+          // own loads of step kt+1 landed: the batches of kt+2 and kt+3 (3 loads each, wave 0: 4 - it waits a little
+          // more than it must) may stay in flight
+          "1:\n\ts_waitcnt vmcnt(6) lgkmcnt(0)"
+          : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]),
+            "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),
+            "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])
+          : "v"(fw_addr), "v"(fe_addr), "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3]),  // 18..23
+            "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT),                                                         // 24, 25
+            "v"(a_voff[0]), "v"(a_voff[1]), "v"(w_voff), "v"(w_voff8),                                       // 26..29
+            "s"(a_rs), "s"(w_rs), "s"(m0a0), "s"(m0a1), "s"(m0w), "s"(m0w8), "s"(a_soff), "s"(w_soff), "s"(wave)  // 30..38
+          : "memory", "scc");  // (s_cmp inside)
+    } else {  // 64-row tile: two m tiles per k slice, one activation piece per wave
+      asm volatile(
+          "ds_read_b128 %0, %10 offset:%c17\n\tds_read_b32 %1, %11 offset:%c17+512\n\t"
+          "ds_read_b128 %2, %12 offset:%c16\n\tds_read_b128 %3, %12 offset:%c16+4096\n\t"
+          "ds_read_b128 %4, %13 offset:%c16\n\tds_read_b128 %5, %13 offset:%c16+4096\n\t"
+          "ds_read_b128 %6, %14 offset:%c16\n\tds_read_b128 %7, %14 offset:%c16+4096\n\t"
+          "ds_read_b128 %8, %15 offset:%c16\n\tds_read_b128 %9, %15 offset:%c16+4096\n\t"
+          "s_mov_b32 m0, %23\n\ts_nop 0\n\tbuffer_load_dwordx4 %18, %21, %26 offen lds\n\t"
+          "s_mov_b32 m0, %24\n\ts_nop 0\n\tbuffer_load_dwordx4 %19, %22, %27 offen lds\n\t"
+          "s_cmp_lg_u32 %28, 0\n\ts_cbranch_scc1 1f\n\t"
+          "s_mov_b32 m0, %25\n\ts_nop 0\n\tbuffer_load_dwordx4 %20, %22, %27 offen lds\n\t"
+          "1:\n\ts_waitcnt vmcnt(4) lgkmcnt(0)"
+          : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[1][0]), "=&v"(xa[1][1]), "=&v"(xa[2][0]),
+            "=&v"(xa[2][1]), "=&v"(xa[3][0]), "=&v"(xa[3][1])
+          : "v"(fw_addr), "v"(fe_addr), "v"(fa_addr[0]), "v"(fa_addr[1]), "v"(fa_addr[2]), "v"(fa_addr[3]),  // 10..15
+            "i"(SLOT * A_SLOT), "i"(SLOT * R_SLOT),                                                         // 16, 17
+            "v"(a_voff[0]), "v"(w_voff), "v"(w_voff8),                                                       // 18..20
+            "s"(a_rs), "s"(w_rs), "s"(m0a0), "s"(m0w), "s"(m0w8), "s"(a_soff), "s"(w_soff), "s"(wave)         // 21..28
+          : "memory", "scc");
+    }
     STAMP(1);  // LDS reads + DMA issue + waits
     bf16x8 wb_first = expand_frag_t<XF16>(wr[0], (we & 0xffu) << 23);
     asm volatile("s_barrier" : "+v"(wb_first)::"memory");
@@ -445,7 +474,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       const uint32_t sc = ((we >> (8 * ks)) & 0xffu) << 23;
       const bf16x8 wb = ks == 0 ? wb_first : expand_frag_t<XF16>(wr[ks], sc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = mfma_32x32x16<XF16>(wb, xa[ks][i], acc[i]);
+      for (int i = 0; i < MT; ++i) acc[i] = mfma_32x32x16<XF16>(wb, xa[ks][i], acc[i]);
     }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(5);  // COMPUTE section issue
@@ -485,14 +514,14 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // per 32x32 tile and quad q: regs 4q..4q+3 = columns n = nb + 8q + 4 lh + (0..3) of token row m
 #ifdef LQER_ABL_NO_STORE
   if (g.M > 0) {
-    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i]));
+    for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(acc[i]));
     return;
   }
 #endif
   const bool aligned16 = (((uintptr_t)g.y) & 15) == 0;
   const int nb = n0 + wn * 32;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < MT; ++i) {
     const int m = m0 + i * 32 + l31;
     if constexpr (DT == LQER_F32) {
 #pragma unroll
@@ -655,6 +684,19 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
 #define LQER_STAGE_MIN 32
 #endif
   const bool staged = lowrank && g.rp * g.b_limbs > LQER_STAGE_MIN;  // more than two 16-deep slices of side product
+#define LQER_GEMM_LAUNCH_H64(LR, BO)                                                                            \
+  do {                                                                                                          \
+    static LdsLimitOnce lds_once;                                                                               \
+    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO, false, 2>, GEMM_LDS);                                     \
+    k_lqer_gemm<DT, LR, BO, false, 2><<<grid, 512, GEMM_LDS, st>>>(g);                                          \
+  } while (0)
+  if (g.tiles_m_rows == 64) {  // (gemm_dispatch: the 128-row grid would fill at most half of the CUs)
+    if (!lowrank) LQER_GEMM_LAUNCH_H64(false, 0);
+    else if (bout == 1) LQER_GEMM_LAUNCH_H64(true, 1);
+    else LQER_GEMM_LAUNCH_H64(true, 0);
+    return check_launch("lqer_gemm");
+  }
+#undef LQER_GEMM_LAUNCH_H64
   if (!lowrank)
     LQER_GEMM_LAUNCH(false, 0);
   else if (bout == 1) {
@@ -761,6 +803,21 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   if (m256_eligible(g)) return m256_dispatch(g, dtype, lowrank, bout, st);            // large M: 256 x 256 tiles
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
+  g.tiles_m_rows = BM;
+#ifndef LQER_NO_H64
+  // Token counts whose 128-row grid covers at most half of the CUs: 64-row tiles (twice the workgroups, half the MFMA work
+  // per expanded weight fragment - the k-step is then paced by the weight expand, §4.1) as long as they still fit one round.
+  // Direct side path only (rank * limbs <= 32) and B_out pass-through or in blocks of 16.
+  {
+    constexpr int CUS = 256;
+    const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;
+    const bool direct = !lowrank || g.rp * g.b_limbs <= LQER_STAGE_MIN_DEFAULT;
+    if (2 * t128 <= CUS && t64 > t128 && direct && bout <= 1 && g.M > 64) {
+      g.tiles_m = (g.M + 63) / 64;
+      g.tiles_m_rows = 64;
+    }
+  }
+#endif
   switch (dtype) {
     case LQER_F32: return launch_gemm<LQER_F32>(g, lowrank, bout, st);
     case LQER_F16: return g.x_f16 ? launch_gemm<LQER_F16X>(g, lowrank, bout, st) : launch_gemm<LQER_F16>(g, lowrank, bout, st);
