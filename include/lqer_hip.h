@@ -208,7 +208,8 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
 
 /* Which GEMM kernel lqer_linear_gemm launches for `M` tokens of this descriptor and element type (the choice depends on
  * nothing else): LQER_ROUTE_SMALLM (M <= 64: one workgroup per 16 output columns streams its packed weight rows),
- * LQER_ROUTE_TILE128 (128 x 256 tiles), LQER_ROUTE_TILE256 (256 x 256 tiles, M >= 512 when that needs fewer rounds of one
+ * LQER_ROUTE_TILE128 (128 x 256 tiles; 64 x 256 tiles of the same kernel when the 128-row grid would cover at most half of
+ * the CUs and the side product is at most two 16-deep slices - M = 65..1024 at N = 4096), LQER_ROUTE_TILE256 (256 x 256 tiles, M >= 512 when that needs fewer rounds of one
  * tile per CU).  < 0: the error lqer_linear_gemm would return.  For benchmarks and tests that must know which kernel
  * they are looking at. */
 #define LQER_ROUTE_SMALLM 0
