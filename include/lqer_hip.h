@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 6
+#define LQER_ABI_VERSION 7
 
 /* error codes */
 #define LQER_OK 0
@@ -185,6 +185,10 @@ int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype
 
 /* test hook: poll sweeps of that wait before the fall-back (0 = every workgroup computes the tiles itself; < 0 = default) */
 int lqer_debug_set_decode_spin(int sweeps);
+
+/* test hook: tile height of the 128-row kernel family (LQER_ROUTE_TILE128): 0 = chosen per launch (64-row tiles when the
+ * 128-row grid covers at most half of the CUs), 128 = always 128 rows.  Both heights give the same bits. */
+int lqer_debug_set_tile_rows(int rows);
 
 /* The same, split for callers that share one quantized activation between several Linears
  * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
@@ -69,6 +69,7 @@ SIGNATURES = {
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "lqer_decode_partials": (_i, [_dp, _i64]),
     "lqer_debug_set_decode_spin": (_i, [_i]),
+    "lqer_debug_set_tile_rows": (_i, [_i]),
     "lqer_gemm_route": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),

@@ -25,6 +25,7 @@
 //  * the two waves of a SIMD run half a k-step apart (LOAD / COMPUTE ping-pong, see the main loop).
 //  * tiles are numbered so that each of the 8 XCDs works on a contiguous run of tiles (same token
 //    rows -> the activation slab stays in that XCD's L2).
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -717,6 +718,8 @@ extern "C" int lqer_debug_set_stamp_buffer(void* p) {
 }
 #endif
 
+static std::atomic<int> g_tile_rows{0};  // test hook (lqer_debug_set_tile_rows): 0 = per launch, 128 = never 64-row tiles
+
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
   if (bout.kind != LQER_Q_MXINT || bout.block == 16) return 0;
   const int64_t Np = lqer_padded_n(N);
@@ -812,7 +815,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
     constexpr int CUS = 256;
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;
     const bool direct = !lowrank || g.rp * g.b_limbs <= LQER_STAGE_MIN_DEFAULT;
-    if (2 * t128 <= CUS && t64 > t128 && direct && bout <= 1 && g.M > 64) {
+    if (g_tile_rows.load(std::memory_order_relaxed) != 128 && 2 * t128 <= CUS && t64 > t128 && direct && bout <= 1 && g.M > 64) {
       g.tiles_m = (g.M + 63) / 64;
       g.tiles_m_rows = 64;
     }
@@ -825,6 +828,11 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   }
   set_error("unknown dtype %d", dtype);
   return LQER_E_INVALID;
+}
+
+extern "C" int lqer_debug_set_tile_rows(int rows) {
+  g_tile_rows.store(rows == 128 ? 128 : 0, std::memory_order_relaxed);
+  return 0;
 }
 
 }  // namespace lqer

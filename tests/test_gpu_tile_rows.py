@@ -1,0 +1,69 @@
+"""64-row tiles of the fused GEMM (csrc/gemm_w4a8.hip, k_lqer_gemm<..., MT = 2>): taken when the 128-row grid would cover at
+most half of the CUs (token counts between the decode kernel and the full tile grid).  Same kernel, same per-element
+accumulation order: the outputs must equal the 128-row tiles' bit for bit, for every output type, ragged K / N, bias, both
+B_out modes and no side path at all; and they must be the oracle's (reference quantized_layers/linear.py:145-157).
+Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lqer_oracle as O  # the checker
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import lqer_amd
+
+    return lqer_amd
+
+
+CASES = [  # M, K, N, rank, bias, B_out, dtype
+    (65, 512, 384, 32, False, "mx", torch.float16),      # one live row in the second tile
+    (96, 4096, 768, 32, False, "mx", torch.float16),
+    (130, 1100, 520, 20, True, "mx", torch.bfloat16),    # ragged K and N (edge column tile), padded rank, bias
+    (300, 512, 256, 16, True, "pass", torch.float32),    # B_out pass-through, fp32 outputs
+    (1000, 2048, 1280, 32, False, "mx", torch.float16),
+    (1024, 1024, 4096, 32, False, "mx", torch.bfloat16),  # the largest token count the rule takes at N = 4096
+    (200, 768, 512, 0, True, "mx", torch.float16),       # LinearFlexible: no side path
+]
+
+
+@pytest.mark.parametrize("M,K,N,r,bias,bout,dtype", CASES)
+def test_64_row_tiles_equal_128_row_tiles_and_the_oracle(lq, M, K, N, r, bias, bout, dtype):
+    from bench import MXINT_Q, make_case
+    from lqer_amd import _lib
+
+    qc = MXINT_Q if bout == "mx" else dict(MXINT_Q, B_out_quantizer={"name": "passthrough"})
+    case = make_case(M, K, N, max(r, 16), seed=31, bias=bias)
+    x, W, A, B = case[:4]
+    bvec = case[4] if bias else None
+    if r > 0:
+        A, B = A[:, :r].contiguous(), B[:r].contiguous()
+        mod = lq.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+        sd = {"weight": W, "A": A, "B": B}
+    else:
+        mod = lq.LinearFlexible(K, N, bias=bias, q_config=dict(qc, name="flexible"))
+        sd = {"weight": W}
+    if bias:
+        sd["bias"] = bvec
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).to(dtype)
+    xd = x.to(dtype).to(DEV)
+    L = _lib.lib()
+    try:
+        assert L.lqer_debug_set_tile_rows(128) == 0
+        y128 = mod(xd).clone()
+        assert L.lqer_debug_set_tile_rows(0) == 0
+        y64 = mod(xd).clone()
+    finally:
+        L.lqer_debug_set_tile_rows(0)
+    assert torch.equal(y64, y128)
+    h = lambda t: None if t is None else t.to(dtype).float()
+    ref = O.lqer_linear_forward(h(x), h(W), h(bvec), h(A) if r > 0 else None, h(B) if r > 0 else None, qc)
+    err = float((y64.float().cpu() - ref).norm() / ref.norm())
+    assert err <= (4e-3 if dtype == torch.bfloat16 else 1e-3), err
