@@ -33,7 +33,6 @@
 namespace lqer {
 
 constexpr int BM = 128, BN = 256, BK = 64;
-constexpr int LQER_STAGE_MIN_DEFAULT = 32;  // side products of at most two 16-deep slices are fetched directly (launch_gemm)
 #ifndef LQER_DEPTH
 #define LQER_DEPTH 3
 #endif
@@ -97,6 +96,9 @@ __device__ __forceinline__ void lds_write128(uint32_t addr, u32x4 v) {
 __device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+__device__ __forceinline__ void lds_wait(bf16x8& a, bf16x8& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ void lds_wait(u32x2& a, int& b) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
 }
@@ -131,7 +133,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 // grid leaves most of the chip idle (half the MFMA work per expanded weight fragment, twice the workgroups).
 template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4>
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
-  static_assert(MT == 4 || (MT == 2 && !STAGED), "64-row tiles: direct side path only");
+  static_assert(MT == 4 || MT == 2, "128- or 64-row tiles");
   constexpr int BMk = 32 * MT;   // tile rows
   constexpr int AP = MT / 2;     // 8-row LDS-DMA pieces of the activation tile per wave and k-step
   constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image, weights expanded to fp16, v_mfma_f32_32x32x16_f16
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         }
       }
     }
-    if constexpr (side_staged && MT == 4)
+    if constexpr (side_staged)
     for (int p0 = 0; p0 < g.rp; p0 += 64) {
       const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;
       const int cpr = cols >> 3;
@@ -307,12 +309,19 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         for (int ks = 0; ks < 4; ++ks)
           if (ks * 16 < cols) {
             const uint32_t fa = stage + swz(l31, 2 * ks + lh);  // m tile i: + i * 4096 (row + 32 keeps the swizzle)
-            bf16x8 x0 = lds_read128<0>(fa), x1 = lds_read128<4096>(fa), x2 = lds_read128<8192>(fa), x3 = lds_read128<12288>(fa);
-            lds_wait(x0, x1, x2, x3);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x2, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x3, acc[3], 0, 0, 0);
+            if constexpr (MT == 4) {
+              bf16x8 x0 = lds_read128<0>(fa), x1 = lds_read128<4096>(fa), x2 = lds_read128<8192>(fa), x3 = lds_read128<12288>(fa);
+              lds_wait(x0, x1, x2, x3);
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x0, acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x1, acc[1], 0, 0, 0);
+              acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x2, acc[2], 0, 0, 0);
+              acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x3, acc[3], 0, 0, 0);
+            } else {
+              bf16x8 x0 = lds_read128<0>(fa), x1 = lds_read128<4096>(fa);
+              lds_wait(x0, x1);
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x0, acc[0], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x1, acc[1], 0, 0, 0);
+            }
           }
       };
       limb(0, std::integral_constant<int, 0>{});
@@ -685,16 +694,17 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
 #define LQER_STAGE_MIN 32
 #endif
   const bool staged = lowrank && g.rp * g.b_limbs > LQER_STAGE_MIN;  // more than two 16-deep slices of side product
-#define LQER_GEMM_LAUNCH_H64(LR, BO)                                                                            \
+#define LQER_GEMM_LAUNCH_H64(LR, BO, ST)                                                                        \
   do {                                                                                                          \
     static LdsLimitOnce lds_once;                                                                               \
-    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO, false, 2>, GEMM_LDS);                                     \
-    k_lqer_gemm<DT, LR, BO, false, 2><<<grid, 512, GEMM_LDS, st>>>(g);                                          \
+    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO, ST, 2>, GEMM_LDS);                                        \
+    k_lqer_gemm<DT, LR, BO, ST, 2><<<grid, 512, GEMM_LDS, st>>>(g);                                             \
   } while (0)
   if (g.tiles_m_rows == 64) {  // (gemm_dispatch: the 128-row grid would fill at most half of the CUs)
-    if (!lowrank) LQER_GEMM_LAUNCH_H64(false, 0);
-    else if (bout == 1) LQER_GEMM_LAUNCH_H64(true, 1);
-    else LQER_GEMM_LAUNCH_H64(true, 0);
+    if (!lowrank) LQER_GEMM_LAUNCH_H64(false, 0, false);
+    else if (bout == 1) { if (staged) LQER_GEMM_LAUNCH_H64(true, 1, true); else LQER_GEMM_LAUNCH_H64(true, 1, false); }
+    else if (bout == 2) { if (staged) LQER_GEMM_LAUNCH_H64(true, 2, true); else LQER_GEMM_LAUNCH_H64(true, 2, false); }
+    else { if (staged) LQER_GEMM_LAUNCH_H64(true, 0, true); else LQER_GEMM_LAUNCH_H64(true, 0, false); }
     return check_launch("lqer_gemm");
   }
 #undef LQER_GEMM_LAUNCH_H64
@@ -810,12 +820,10 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
 #ifndef LQER_NO_H64
   // Token counts whose 128-row grid covers at most half of the CUs: 64-row tiles (twice the workgroups, half the MFMA work
   // per expanded weight fragment - the k-step is then paced by the weight expand, §4.1) as long as they still fit one round.
-  // Direct side path only (rank * limbs <= 32) and B_out pass-through or in blocks of 16.
   {
     constexpr int CUS = 256;
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;
-    const bool direct = !lowrank || g.rp * g.b_limbs <= LQER_STAGE_MIN_DEFAULT;
-    if (g_tile_rows.load(std::memory_order_relaxed) != 128 && 2 * t128 <= CUS && t64 > t128 && direct && bout <= 1 && g.M > 64) {
+    if (g_tile_rows.load(std::memory_order_relaxed) != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) {
       g.tiles_m = (g.M + 63) / 64;
       g.tiles_m_rows = 64;
     }

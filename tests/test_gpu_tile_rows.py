@@ -30,16 +30,21 @@ CASES = [  # M, K, N, rank, bias, B_out, dtype
     (1000, 2048, 1280, 32, False, "mx", torch.float16),
     (1024, 1024, 4096, 32, False, "mx", torch.bfloat16),  # the largest token count the rule takes at N = 4096
     (200, 768, 512, 0, True, "mx", torch.float16),       # LinearFlexible: no side path
+    (200, 1024, 512, 48, False, "mx", torch.float16),    # padded rank 48: the staged side path
+    (330, 512, 768, 128, True, "mx", torch.bfloat16),    # rank 128: two staging passes
+    (260, 1024, 512, 32, False, "row", torch.float16),   # B_out with one block per token row: maxima from the pre-pass
+    (300, 640, 384, 64, False, "int", torch.float16),    # the INT template: per-token x, unquantized A / B (bf16 limbs), B_out per row
 ]
 
 
 @pytest.mark.parametrize("M,K,N,r,bias,bout,dtype", CASES)
 def test_64_row_tiles_equal_128_row_tiles_and_the_oracle(lq, M, K, N, r, bias, bout, dtype):
-    from bench import MXINT_Q, make_case
+    from bench import INT_Q, MXINT_Q, _bfp, make_case
     from lqer_amd import _lib
 
-    qc = MXINT_Q if bout == "mx" else dict(MXINT_Q, B_out_quantizer={"name": "passthrough"})
-    case = make_case(M, K, N, max(r, 16), seed=31, bias=bias)
+    qc = {"mx": MXINT_Q, "pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"}),
+          "row": dict(MXINT_Q, B_out_quantizer=_bfp(8, [1, -1], True)), "int": INT_Q}[bout]
+    case = make_case(M, K, N, max(r, 16), seed=31, bias=bias, quantize_ab=bout != "int")
     x, W, A, B = case[:4]
     bvec = case[4] if bias else None
     if r > 0:

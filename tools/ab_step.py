@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--r", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--also-128", action="store_true", help="time every build a second time with the 128-row tiles pinned (lqer_debug_set_tile_rows)")
     ap.add_argument("--gap", type=int, default=0, help="tiny unrelated kernels launched between the quantizer and the GEMM (boundary-effect probe)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -44,13 +45,17 @@ def main():
     f4 = _lib.QFmt(_lib.Q_MXINT, 4, 16, 8, 127)
     desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
     libs = [(p, load(p)) for p in a.libs]
+    if a.also_128:
+        libs += [(p + " [128-row tiles]", L) for p, L in list(libs)]
     st = torch.cuda.current_stream().cuda_stream
     nscr = libs[0][1].lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
     scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
 
     dummy = torch.zeros(64, device=dev)
 
-    def run(L):
+    def run(L, pin=False):
+        if hasattr(L, "lqer_debug_set_tile_rows"):
+            L.lqer_debug_set_tile_rows(128 if pin else 0)
         # (a build whose GEMM sums the partial tiles of x A itself - lqer_decode_partials - gets no xaq: two launches)
         xa = None if L.lqer_decode_partials(C.byref(desc), M) else xaq.data_ptr()
         rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xa,
@@ -65,14 +70,14 @@ def main():
     times = {p: [] for p, _ in libs}
     for p, L in libs:
         for _ in range(10):
-            run(L)
+            run(L, p.endswith("tiles]"))
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for p, L in libs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                run(L)
+                run(L, p.endswith("tiles]"))
             e1.record()
             torch.cuda.synchronize()
             times[p].append(e0.elapsed_time(e1) / a.iters * 1e3)
