@@ -296,34 +296,55 @@ def main():
     one_launch = (M <= 8 and not args.graph and r > 0 and
                   all(L.lqer_decode_partials(pl["dref"], M) and pl["a_limbs"] == 1 for pl in plans))
 
+    # the C-ABI calls of a step with their arguments bound once per stream (the launch stream, or the capture stream of
+    # --graph): at decode sizes the Python that assembles 16 arguments per call costs as much as the kernel it launches
+    fwd, qxa, gemm = L.lqer_linear_forward, L.lqer_quantize_act_xa, L.lqer_linear_gemm
+    bound = {}
+
+    def calls_for(st):
+        if st not in bound:
+            rows = []
+            for pl in plans:
+                K, N = pl["K"], pl["N"]
+                fa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["w"], pl["a_t"], pl["b_t"], pl["a_limbs"], pl["b_limbs"], pl["bias"],
+                      pl["y"], N, pl["ws"], pl["ws_bytes"], st)
+                qa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"], pl["xq"], pl["xaq"], pl["xscr"], pl["nscr"], st)
+                ga = (pl["dref"], pl["xq"], M, pl["w"], pl["xaq"], pl["b_t"], pl["b_limbs"], pl["bias"], pl["y"], _lib.F16, N,
+                      pl["xscr"], pl["gscr"], st)
+                rows.append((pl["reps"], K, N, fa, qa, ga))
+            bound[st] = rows
+        return bound[st]
+
     def step(timed: bool, stream=stream):
-        for pl in plans:
-            K, N = pl["K"], pl["N"]
-            for _ in range(pl["reps"]):
+        for reps, K, N, fa, qa, ga in calls_for(stream):
+            for _ in range(reps):
                 ev = timed and launch_no[0] % EV_EVERY == 0  # counts timed launches only: the first one is always sampled
-                launch_no[0] += int(timed)
+                if timed:
+                    launch_no[0] += 1
                 if one_launch:
                     # up to 8 tokens the whole forward is ONE launch (csrc/decode1.hip) behind lqer_linear_forward - the entry
                     # point of INTEGRATION.md; the events bracket that launch
                     if ev:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    _lib.check(L.lqer_linear_forward(pl["dref"], pl["x"], _lib.F16, M, K, pl["w"], pl["a_t"], pl["b_t"], pl["a_limbs"],
-                                                     pl["b_limbs"], pl["bias"], pl["y"], N, pl["ws"], pl["ws_bytes"], stream),
-                               "linear_forward")
+                    rc = fwd(*fa)
+                    if rc:
+                        _lib.check(rc, "linear_forward")
                     if ev:
                         e1.record()
                         gemm_events.append((e0, e1, K, N))
                     continue
                 # the two calls of lqer_linear_forward, issued separately so that the dominant kernel can be
                 # bracketed with HIP events on the launch stream
-                _lib.check(L.lqer_quantize_act_xa(pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"],
-                                                  pl["xq"], pl["xaq"], pl["xscr"], pl["nscr"], stream), "quantize_act_xa")
+                rc = qxa(*qa)
+                if rc:
+                    _lib.check(rc, "quantize_act_xa")
                 if ev:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                _lib.check(L.lqer_linear_gemm(pl["dref"], pl["xq"], M, pl["w"], pl["xaq"], pl["b_t"], pl["b_limbs"],
-                                              pl["bias"], pl["y"], _lib.F16, N, pl["xscr"], pl["gscr"], stream), "linear_gemm")
+                rc = gemm(*ga)
+                if rc:
+                    _lib.check(rc, "linear_gemm")
                 if ev:
                     e1.record()
                     gemm_events.append((e0, e1, K, N))
