@@ -218,7 +218,8 @@ def main():
         desc_txt += f" [--layers {layers}]"
     big = M >= 8192
     if args.steps is None:
-        args.steps = 4 if big else 50
+        # (decode sizes: a 50-step region is 0.4 ms, of which the first launch's latency and the closing synchronize are ~10 %)
+        args.steps = 4 if big else (400 if M <= 64 else 50)
     if args.warmup is None:
         args.warmup = 1 if big else 10
     strong = (args.sweep == "strong") or (args.sweep == "auto" and layers > 1)
@@ -300,6 +301,10 @@ def main():
     # --graph): at decode sizes the Python that assembles 16 arguments per call costs as much as the kernel it launches
     fwd, qxa, gemm = L.lqer_linear_forward, L.lqer_quantize_act_xa, L.lqer_linear_gemm
     bound = {}
+    # event pairs for the sampled launches, created ahead of the timed region (creating one costs more host time than a
+    # decode-size kernel runs)
+    new_pair = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev_pool = [new_pair() for _ in range(64)]
 
     def calls_for(st):
         if st not in bound:
@@ -325,7 +330,7 @@ def main():
                     # up to 8 tokens the whole forward is ONE launch (csrc/decode1.hip) behind lqer_linear_forward - the entry
                     # point of INTEGRATION.md; the events bracket that launch
                     if ev:
-                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0, e1 = ev_pool.pop() if ev_pool else new_pair()
                         e0.record()
                     rc = fwd(*fa)
                     if rc:
@@ -340,7 +345,7 @@ def main():
                 if rc:
                     _lib.check(rc, "quantize_act_xa")
                 if ev:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0, e1 = ev_pool.pop() if ev_pool else new_pair()
                     e0.record()
                 rc = gemm(*ga)
                 if rc:
