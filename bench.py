@@ -287,7 +287,10 @@ def main():
         gscr = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
         if L.lqer_decode_partials(C.byref(desc), M):
             xaq, gscr = None, nscr  # decode route: the GEMM reduces the partial tiles of x A left in the scratch itself
-        plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=p["a_t"].data_ptr(), a_limbs=p["a_limbs"], xq=xq, xaq=xaq,
+        a_t, a_limbs = p["a_t"].data_ptr(), p["a_limbs"]
+        if mod._x_i8 and "a_t_f16" in p and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) == _lib.ROUTE_TILE256_I8:
+            a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # the int8 route's side GEMM: A as one fp16 image (as the module passes it)
+        plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=a_t, a_limbs=a_limbs, xq=xq, xaq=xaq,
                           ws=ws.data_ptr(), ws_bytes=ws.numel(),
                           xscr=xscr, nscr=nscr, w=p["w"].data_ptr(),
                           b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),

@@ -169,7 +169,11 @@ int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fm
  * with the split-K partials of the rank-r side GEMM when x blocks are 16 and the padded rank <= 64; nothing at all for
  * a dense fp16 tensor on the LQER_Q_PASSTHROUGH_F16 route), a fixed-order reduce of the partials with the A_out
  * re-quantization (taken over by the GEMM at decode sizes, lqer_decode_partials), a pre-pass for B_out blocks other
- * than 16 columns, and the fused W4 GEMM with the B side GEMM, B_out re-quantization, bias and add in its prologue. */
+ * than 16 columns, and the fused W4 GEMM with the B side GEMM, B_out re-quantization, bias and add in its prologue.
+ * a_limbs = -1 (LQER_Q_MXINT_I8 descriptors at token counts of LQER_ROUTE_TILE256_I8 only; also lqer_quantize_act_xa and
+ * lqer_lowrank_xa): a_t is ONE fp16 image of A^T [padded rank][padded K] as lqer_f16_prepare writes it (its flag for A
+ * clear: every element exact in fp16) - the side GEMM then multiplies the int8 mantissas with it on the fp16 MFMA, half
+ * the A^T bytes and MFMAs of the two-limb image. */
 int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype, int64_t M,
                         int64_t ldx, const void* w_packed, const void* a_t, const void* b_t,
                         int a_limbs, int b_limbs, const float* bias_q, void* y, int64_t ldy,

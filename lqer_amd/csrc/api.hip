@@ -341,8 +341,8 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
   }
   if (!fmt_ok(&d->a_out_fmt, "A_out_quantizer", 9)) return LQER_E_UNSUPPORTED;
   if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")) return LQER_E_INVALID;
-  if (a_limbs < 0 || a_limbs > 3) {
-    set_error("lowrank_xa: a_limbs %d outside [0,3]", a_limbs);
+  if ((a_limbs < 0 || a_limbs > 3) && !(a_limbs == -1 && x_is_i8(d))) {
+    set_error("lowrank_xa: a_limbs %d outside [0,3] (-1 = one fp16 image of A^T: the int8 route only)", a_limbs);
     return LQER_E_INVALID;
   }
   return lowrank_xa_dispatch((const bf16_t*)xq, M, d->in_features, x_is_f16(d) ? 0 : (x_is_i8(d) ? -1 : act_limbs(d)), (const bf16_t*)a_t, a_limbs, d->rank,

@@ -77,6 +77,28 @@ __device__ __forceinline__ void i8x32_to_bf16(const u32x4& lo, const u32x4& hi, 
   }
 }
 
+// the same 32 mantissas as fp16 (XI8 with an fp16 A^T image: the mantissas times an fp16-exact A on v_mfma_*_f16, ONE limb of
+// A^T instead of two): byte b -> the half 0x6400 | (b ^ 0x80) = 1024 + (b + 128), minus 1152 - two bytes per v_perm_b32 and
+// v_pk_add_f16 instead of three conversions per byte
+__device__ __forceinline__ void i8x32_to_f16(const u32x4& lo, const u32x4& hi, bf16x8 (&f)[4]) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 bias = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // fragment i = bytes 8i .. 8i+7
+    const uint32_t w0 = i < 2 ? lo[2 * i] : hi[2 * i - 4], w1 = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+    u32x4 r;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t t = (j ? w1 : w0) ^ 0x80808080u;
+      const h2 a = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, t, 0x04010400u)) + bias;  // bytes 0, 1
+      const h2 b = __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, t, 0x04030402u)) + bias;  // bytes 2, 3
+      r[2 * j] = __builtin_bit_cast(uint32_t, a);
+      r[2 * j + 1] = __builtin_bit_cast(uint32_t, b);
+    }
+    f[i] = __builtin_bit_cast(bf16x8, r);
+  }
+}
+
 template <int NT, int RG, bool XF16 = false, bool AFPF = false, bool XI8 = false>
 __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t M, int64_t Kp, int64_t Kx,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
@@ -121,8 +143,9 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
     }
   };
   load_x(k_begin);
-  constexpr int PAIRS = AFPF ? 4 : 1;  // (limb, tile) fragment sets held one window ahead
-  constexpr int LMAX = AFPF ? 4 / NT : 1;
+  // (limb, tile) fragment sets held one window ahead; the fp16 image of the int8 route is ONE limb: half the registers
+  constexpr int LMAX = AFPF ? ((XF16 && XI8) ? 1 : 4 / NT) : 1;
+  constexpr int PAIRS = AFPF ? LMAX * NT : 1;
   bf16x8 afn[PAIRS][4];
   auto load_af = [&](int64_t k0) {
     if constexpr (AFPF) {
@@ -147,7 +170,9 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
     bf16x8 xf[RG][4];
 #pragma unroll
     for (int u = 0; u < RG; ++u) {
-      if constexpr (XI8) {
+      if constexpr (XI8 && XF16) {
+        i8x32_to_f16(__builtin_bit_cast(u32x4, xn[u][0]), __builtin_bit_cast(u32x4, xn[u][1]), xf[u]);
+      } else if constexpr (XI8) {
         i8x32_to_bf16(__builtin_bit_cast(u32x4, xn[u][0]), __builtin_bit_cast(u32x4, xn[u][1]), xf[u]);
       } else {
 #pragma unroll
@@ -556,7 +581,9 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
                         const QP& q, int xa_limbs, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st) {
   const bool x_f16 = x_limbs == 0;
   const bool x_i8 = x_limbs == -1;
-  if (x_f16) x_limbs = 1, a_limbs = 1;
+  const bool a_f16 = x_i8 && a_limbs == -1;  // int8 mantissas x ONE fp16 image of A^T (lqer_f16_prepare) on the fp16 MFMA
+  if (x_f16 || a_f16) a_limbs = 1;
+  if (x_f16) x_limbs = 1;
   if (x_i8) x_limbs = 1;
   const int64_t Kp = lqer_padded_k(K) * x_limbs;
   const int64_t Kx = x_i8 ? padded_k8(K) : Kp;  // row stride of the activation image (elements)
@@ -595,12 +622,16 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
     if (NT <= 2 && a_limbs * NT <= 4 && plan.kc > 64) { /* A^T fragments one window ahead */                 \
       if (x_f16)                                                                                             \
         k_xa_partial<NT, RG, true, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch);  \
+      else if (a_f16)                                                                                        \
+        k_xa_partial<NT, RG, true, (NT <= 2), true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
       else if (x_i8)                                                                                         \
         k_xa_partial<NT, RG, false, (NT <= 2), true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
       else                                                                                                   \
         k_xa_partial<NT, RG, false, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
     } else if (x_f16)                                                                                        \
       k_xa_partial<NT, RG, true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch);      \
+    else if (a_f16)                                                                                          \
+      k_xa_partial<NT, RG, true, false, true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
     else if (x_i8)                                                                                           \
       k_xa_partial<NT, RG, false, false, true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
     else                                                                                                     \

@@ -52,6 +52,7 @@ class _LinearBase(nn.Linear):
         self._x_f16 = False        # pass-through fp16 activations on the fp16 MFMA route (decided when the images are built)
         self.a16_native = True     # False: keep pass-through fp16 activations on the bf16-limb route
         self._x_i8 = False         # per-token 8-bit activations on the int8 MFMA route (decided when the images are built)
+        self.i8_a_f16 = True       # int8 route: fp16 A as one fp16 image for the side GEMM (False: the bf16 limb pair)
         self.a8_native = True      # False: keep them on the bf16 route
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
@@ -111,6 +112,12 @@ class _LinearBase(nn.Linear):
                 self._x_i8 = True
                 p = dict(p)
                 p["w"] = w2
+                # unquantized fp16 A (two bf16 limbs): the side GEMM of the int8 route takes it as ONE fp16 image on the fp16
+                # MFMA (int8 mantissas are exact in fp16) - half the A^T bytes and MFMAs of the limb pair
+                if self.rank > 0 and int(p.get("a_limbs", 0)) == 2 and self.i8_a_f16:
+                    ok16, a16 = ops.a_f16_image(w2, self.out_features, K, p["a_t"], 2, self.rank)
+                    if ok16:
+                        p["a_t_f16"] = a16
         if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native):
             ok, a16 = ops.f16_prepare(p["w"], self.out_features, self.in_features, p.get("a_t"), int(p.get("a_limbs", 0)), self.rank)
             if ok:
@@ -345,9 +352,13 @@ class _LinearBase(nn.Linear):
             if len(self._fw_cache) > 64:
                 self._fw_cache = {}
             # (plain data only: the module must stay deep-copyable and picklable)
+            a_t, a_limbs = ops._ptr(p.get("a_t")), p.get("a_limbs", 0)
+            if self._x_i8 and "a_t_f16" in p and \
+                    _lib.lib().lqer_gemm_route(C.byref(desc), M, ops.dtype_code(x2)) == _lib.ROUTE_TILE256_I8:
+                a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # (the int8 kernel's token counts only: elsewhere the bf16 kernels run)
             ent = self._fw_cache[key] = (desc, ops.linear_sizes(desc, M).workspace, ops.dtype_code(x2),
-                                         (p["w"].data_ptr(), ops._ptr(p.get("a_t")), ops._ptr(p.get("b_t")),
-                                          p.get("a_limbs", 0), p.get("b_limbs", 0), ops._ptr(p.get("bias"))))
+                                         (p["w"].data_ptr(), a_t, ops._ptr(p.get("b_t")),
+                                          a_limbs, p.get("b_limbs", 0), ops._ptr(p.get("bias"))))
         desc, ws_bytes, dt, consts = ent
         dref = C.byref(desc)
         ws = ops.workspace(x.device, ws_bytes)

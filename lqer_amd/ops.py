@@ -193,6 +193,20 @@ def f16_prepare(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: Optional[torc
 
 
 @_on_tensor_device
+def a_f16_image(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: torch.Tensor, a_limbs: int, r: int):
+    """A^T as ONE fp16 image [rp][Kp] for the int8 route's side GEMM (int8 mantissas x fp16 A on the fp16 MFMA, a_limbs = -1
+    in lqer_lowrank_xa / lqer_quantize_act_xa / lqer_linear_forward): (ok, image) - ok is False when an element of A is not
+    exact in fp16 (only that flag of lqer_f16_prepare matters here).  Synchronises."""
+    L = _lib.lib()
+    dev = w_packed.device
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    a16 = torch.empty(L.lqer_padded_r(r) * L.lqer_padded_k(K), dtype=torch.float16, device=dev)
+    check(L.lqer_f16_prepare(w_packed.data_ptr(), N, K, a_t_limbs.data_ptr(), a_limbs, r, a16.data_ptr(), flags.data_ptr(), _stream(dev)),
+          "lqer_f16_prepare")
+    return flags.tolist()[1] == 0, a16
+
+
+@_on_tensor_device
 def i8_prepare(w_packed: torch.Tensor, N: int, K: int, w_fmt: QFmt):
     """Eligibility of the int8 MFMA route (include/lqer_hip.h "int8 route") for one packed weight: returns (ok, buffer) -
     `buffer` holds the sign-magnitude image followed by the int8 main loop's image; ok is False when some row's integer
