@@ -192,3 +192,30 @@ def test_int8_route_shared_qkv_and_checkpoint(lq, tmp_path):
     m2.load_packed_state({k: v.cpu() for k, v in st.items()}, DEV)
     m2 = m2.to(DEV)
     assert torch.equal(m2(xd), alone[0]) and m2._x_i8
+
+
+def test_int8_route_side_gemm_on_one_fp16_limb(lq):
+    """The int8 route's side GEMM with the unquantized fp16 A as ONE fp16 image on the fp16 MFMA (a_limbs = -1, the
+    module's default) against the two-bf16-limb image: both are exact products summed in fp32 - the outputs agree to the
+    output type's rounding and both match the oracle."""
+    import ctypes as C
+
+    from bench import INT_Q, make_case
+    from lqer_amd import _lib
+
+    M, K, N, r = 2048, 640, 8192, 64
+    x, W, A, B = make_case(M, K, N, r, seed=13, quantize_ab=False)
+    outs = {}
+    for f16 in (True, False):
+        mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=INT_Q, l_config={"rank": r})
+        mod.i8_a_f16 = f16
+        mod.load_state_dict({"weight": W, "A": A, "B": B})
+        mod = mod.to(DEV).half()
+        outs[f16] = mod(x.half().to(DEV)).float().cpu()
+        assert mod._x_i8 and ("a_t_f16" in mod._packed) == f16
+        assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16) == _lib.ROUTE_TILE256_I8
+    h = lambda t: t.half().float()
+    ref = O.lqer_linear_forward(h(x), h(W), None, h(A), h(B), INT_Q)
+    for f16 in (True, False):
+        assert float((outs[f16] - ref).norm() / ref.norm()) <= 1e-3
+    assert float((outs[True] - outs[False]).norm() / ref.norm()) <= 5e-4
