@@ -224,20 +224,26 @@ __global__ __launch_bounds__(256) void k_qmm_bimage_k(const void* __restrict__ y
 // indexed statically (the loop is unrolled by its depth) - with one chunk ahead every chunk exposed a memory latency, and in
 // P V the attention probabilities are a 268 MB stream.  All loads are unconditional from clamped in-range addresses (a load
 // under a branch makes the compiler wait for everything in flight); what lies outside x is zeroed at the quantizer.
-template <int DT, bool PF>
-__global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
+// NW = 8 (with PF): the same tile on 512 threads, waves as 2 x 4, each 64 x 32 - one activation block and two image pieces
+// per thread and chunk, half the accumulators and prefetch registers per thread: twice the waves per CU hide the latencies
+// of a loop that alternates vector work (the quantizer), barriers and MFMAs (P V: 131 -> ? us).
+template <int DT, bool PF, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_qmatmul(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
                                                  int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs, int64_t S2p, int64_t Kp,
                                                  QP q, bool vec) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[BM * BK * 2 + BN * BK * 2];
   unsigned char* const sa = smem;                // x tile, quantized: 128 rows x 128 B
   unsigned char* const sb = smem + BM * BK * 2;  // image tile (after the loop the 32 KiB hold the 16-bit output tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  static_assert(NW == 4 || (NW == 8 && PF), "8 waves: the prefetching form only");
+  constexpr int T = 64 * NW, JT = 8 / NW;      // threads; 32-column tiles per wave (waves: 2 x NW/2, each 64 x 32 JT)
+  constexpr int XB = 512 / T, IB = 1024 / T;   // activation blocks / 16-byte image pieces per thread and chunk
+  const int wm = wave / (NW / 2), wn = wave % (NW / 2), l31 = lane & 31, lh = lane >> 5;
   const int64_t b = blockIdx.z, i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
   const bf16_t* const ib = img + (b * S2p + j0) * Kp;
-  f32x16 acc[2][2];  // [j tile][i tile]
+  f32x16 acc[JT][2];  // [j tile][i tile]
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < JT; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -246,33 +252,32 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
   auto mma_chunk = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fj[2], fi[2];
+      bf16x8 fj[JT], fi[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fj[t] = *(const bf16x8*)(sb + swz(wn * 64 + t * 32 + l31, 2 * ks + lh));
-        fi[t] = *(const bf16x8*)(sa + swz(wm * 64 + t * 32 + l31, 2 * ks + lh));
-      }
+      for (int t = 0; t < JT; ++t) fj[t] = *(const bf16x8*)(sb + swz(wn * (32 * JT) + t * 32 + l31, 2 * ks + lh));
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int t = 0; t < 2; ++t) fi[t] = *(const bf16x8*)(sa + swz(wm * 64 + t * 32 + l31, 2 * ks + lh));
+#pragma unroll
+      for (int a = 0; a < JT; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fj[a], fi[c], acc[a][c], 0, 0, 0);
     }
   };
   if constexpr (PF) {
-    constexpr int DEPTH = 3;
+    constexpr int DEPTH = NW == 8 ? 2 : 3;  // (8 waves: half the registers per thread for the ring, twice the waves to hide latency)
     constexpr int ESZ = DT == LQER_F32 ? 4 : 2;
     constexpr int NR = Raw16<DT>::N;
     struct Stage {  // one chunk's raw loads of this thread (three named stages: an indexed ring ended up in scratch memory)
-      uint4 x[2][NR];
-      uint4 b[4];
+      uint4 x[XB][NR];
+      uint4 b[IB];
     };
     Stage s0, s1, s2;
     const int xrow0 = tid >> 2;
     auto fetch_raw = [&](int kc, Stage& st) {
       const int kcc = kc < nkc ? kc : nkc - 1;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int64_t i = i0 + xrow0 + 64 * u, ic = i < S1 ? i : S1 - 1;
+      for (int u = 0; u < XB; ++u) {
+        const int64_t i = i0 + xrow0 + (T / 4) * u, ic = i < S1 ? i : S1 - 1;
         int64_t k = (int64_t)kcc * BK + (tid & 3) * 16;
         k = k + 16 <= K ? k : K - 16;
         const uint4* ptr = (const uint4*)((const char*)x + (b * x_bs + ic * x_rs + k) * ESZ);
@@ -280,16 +285,16 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
         for (int n = 0; n < NR; ++n) st.x[u][n] = ptr[n];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = tid + 256 * u;
+      for (int u = 0; u < IB; ++u) {
+        const int p = tid + T * u;
         st.b[u] = *(const uint4*)(ib + (int64_t)(p >> 3) * Kp + (int64_t)kcc * BK + (p & 7) * 8);
       }
     };
     auto chunk = [&](int kc, Stage& st) {
-      uint32_t w[2][8];
+      uint32_t w[XB][8];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bool live = i0 + xrow0 + 64 * u < S1 && (int64_t)kc * BK + (tid & 3) * 16 < K;
+      for (int u = 0; u < XB; ++u) {
+        const bool live = i0 + xrow0 + (T / 4) * u < S1 && (int64_t)kc * BK + (tid & 3) * 16 < K;
         float v[16];
         Raw16<DT> raw;
 #pragma unroll
@@ -301,14 +306,14 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
       }
       __syncthreads();  // the previous chunk's fragment reads are done
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int row = xrow0 + 64 * u, c = 2 * (tid & 3);
+      for (int u = 0; u < XB; ++u) {
+        const int row = xrow0 + (T / 4) * u, c = 2 * (tid & 3);
         *(uint4*)(sa + swz(row, c)) = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
         *(uint4*)(sa + swz(row, c + 1)) = make_uint4(w[u][4], w[u][5], w[u][6], w[u][7]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = tid + 256 * u;
+      for (int u = 0; u < IB; ++u) {
+        const int p = tid + T * u;
         *(uint4*)(sb + swz(p >> 3, p & 7)) = st.b[u];
       }
       __syncthreads();
@@ -317,14 +322,23 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
     };
     fetch_raw(0, s0);
     fetch_raw(1, s1);
-    fetch_raw(2, s2);
-    for (int kc = 0;; kc += DEPTH) {
-      chunk(kc, s0);
-      if (kc + 1 >= nkc) break;
-      chunk(kc + 1, s1);
-      if (kc + 2 >= nkc) break;
-      chunk(kc + 2, s2);
-      if (kc + 3 >= nkc) break;
+    if constexpr (DEPTH == 3) {
+      fetch_raw(2, s2);
+      for (int kc = 0;; kc += DEPTH) {
+        chunk(kc, s0);
+        if (kc + 1 >= nkc) break;
+        chunk(kc + 1, s1);
+        if (kc + 2 >= nkc) break;
+        chunk(kc + 2, s2);
+        if (kc + 3 >= nkc) break;
+      }
+    } else {
+      for (int kc = 0;; kc += DEPTH) {
+        chunk(kc, s0);
+        if (kc + 1 >= nkc) break;
+        chunk(kc + 1, s1);
+        if (kc + 2 >= nkc) break;
+      }
     }
   } else {
   // this thread's two blocks of the x tile (rows tid / 4 and 64 + tid / 4, block tid % 4) and four 16-byte pieces of the image tile
@@ -379,8 +393,8 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
   for (int c = 0; c < 2; ++c) {
     const int64_t i = i0 + wm * 64 + c * 32 + l31;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int64_t jb = j0 + wn * 64 + a * 32;
+    for (int a = 0; a < JT; ++a) {
+      const int64_t jb = j0 + wn * (32 * JT) + a * 32;
       if constexpr (DT == LQER_F32) {
         if (i >= S1) continue;
         float* dst = (float*)out + (b * S1 + i) * S2;
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
           for (int p2 = 0; p2 < 2; ++p2) {
             auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
             auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
-            const int chunk = (wn * 64 + a * 32 + 16 * p2 + 8 * lh) >> 3;
+            const int chunk = (wn * (32 * JT) + a * 32 + 16 * p2 + 8 * lh) >> 3;
             *(uint4*)(smem + row_l * 256 + ((chunk ^ (row_l & 15)) << 4)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
           }
         } else if (wide) {
@@ -450,8 +464,8 @@ __global__ __launch_bounds__(256) void k_qmatmul(const void* __restrict__ x, con
     __syncthreads();
     bf16_t* const ob = (bf16_t*)out + (b * S1) * S2 + j0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {  // 16 consecutive lanes = one row of the tile: 256 contiguous bytes
-      const int idx = tid + 256 * u, row_l = idx >> 4, chunk = idx & 15;
+    for (int u = 0; u < 2048 / T; ++u) {  // 16 consecutive lanes = one row of the tile: 256 contiguous bytes
+      const int idx = tid + T * u, row_l = idx >> 4, chunk = idx & 15;
       const uint4 v = *(const uint4*)(smem + row_l * 256 + ((chunk ^ (row_l & 15)) << 4));
       if (i0 + row_l < S1) *(uint4*)(ob + (i0 + row_l) * S2 + chunk * 8) = v;
     }
@@ -658,8 +672,11 @@ static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, in
   }
   const dim3 grid((unsigned)(S2p / qmm::BN), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
   const bool vec = al16(x, x_bs, x_rs);
+#ifndef LQER_QMM_NW
+#define LQER_QMM_NW 8
+#endif
   if (vec && K % 16 == 0 && K >= 16)
-    qmm::k_qmatmul<DT, true><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, vec);
+    qmm::k_qmatmul<DT, true, LQER_QMM_NW><<<grid, 64 * LQER_QMM_NW, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, vec);
   else
     qmm::k_qmatmul<DT, false><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, vec);
   return check_launch("lqer_matmul_q");
