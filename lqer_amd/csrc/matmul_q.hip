@@ -481,8 +481,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_qmatmul(const void
 constexpr int XR_JT = 4;      // column tiles per workgroup
 constexpr int XR_MAXK = 128;  // two 64-k chunks
 
-template <int DT>
-__global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
+template <int DT, int NW = 8>  // NW waves as 2 x NW/2, each 64 x (256 / NW) of the tile (k_qmatmul's two geometries)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_qmatmul_xr(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
                                                     int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs, int64_t S2p, int64_t Kp,
                                                     QP q, bool vec) {
   // [x tile: 2 chunks x 128 rows x 128 B][image tile: 2 chunks x 128 rows x 128 B, reused for the 16-bit output tile]
@@ -490,15 +490,16 @@ __global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, 
   unsigned char* const sa = smem;
   unsigned char* const sb = smem + 2 * BM * BK * 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  constexpr int T = 64 * NW, JT = 8 / NW, XB = 512 / T, IB = 1024 / T;
+  const int wm = wave / (NW / 2), wn = wave % (NW / 2), l31 = lane & 31, lh = lane >> 5;
   const int64_t b = blockIdx.z, i0 = (int64_t)blockIdx.y * BM;
   const int nkc = (int)(Kp / BK);  // 1 or 2
   // ---- the x tile, quantized once: thread -> rows tid / 4 and 64 + tid / 4, block tid % 4 of every chunk
 #pragma unroll
   for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int row = (tid >> 2) + 64 * u;
+    for (int u = 0; u < XB; ++u) {
+      const int row = (tid >> 2) + (T / 4) * u;
       const int64_t i = i0 + row, k = (int64_t)kc * BK + (tid & 3) * 16;
       uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (kc < nkc && i < S1 && k < K) {
@@ -513,14 +514,14 @@ __global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, 
   const int esz = DT == LQER_F32 ? 4 : 2;
   const bool aligned = (((uintptr_t)out) & 15) == 0 && (S2 * esz) % 16 == 0;
   const int64_t jt0 = (int64_t)blockIdx.x * XR_JT, njt = S2p / BN;
-  uint4 bv[2][4];  // the image tile of one column tile: [chunk][piece]
+  uint4 bv[2][IB];  // the image tile of one column tile: [chunk][piece]
   auto fetch = [&](int64_t jt) {
     const bf16_t* const ib = img + (b * S2p + jt * BN) * Kp;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = tid + 256 * u, row = p >> 3, ch = p & 7;
+      for (int u = 0; u < IB; ++u) {
+        const int p = tid + T * u, row = p >> 3, ch = p & 7;
         bv[kc][u] = kc < nkc ? *(const uint4*)(ib + (int64_t)row * Kp + (int64_t)kc * BK + ch * 8) : make_uint4(0, 0, 0, 0);
       }
   };
@@ -532,15 +533,15 @@ __global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, 
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = tid + 256 * u;
+      for (int u = 0; u < IB; ++u) {
+        const int p = tid + T * u;
         *(uint4*)(sb + kc * (BN * BK * 2) + swz(p >> 3, p & 7)) = bv[kc][u];
       }
     __syncthreads();
     if (jt + 1 < njt && t + 1 < XR_JT) fetch(jt + 1);  // the next tile's loads travel under this tile's MFMAs and stores
-    f32x16 acc[2][2];  // [j tile][i tile]
+    f32x16 acc[JT][2];  // [j tile][i tile]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < JT; ++a)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -550,14 +551,13 @@ __global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, 
       if (kc >= nkc) break;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 fj[2], fi[2];
+        bf16x8 fj[JT], fi[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          fj[u] = *(const bf16x8*)(sb + kc * (BN * BK * 2) + swz(wn * 64 + u * 32 + l31, 2 * ks + lh));
-          fi[u] = *(const bf16x8*)(sa + kc * (BM * BK * 2) + swz(wm * 64 + u * 32 + l31, 2 * ks + lh));
-        }
+        for (int u = 0; u < JT; ++u) fj[u] = *(const bf16x8*)(sb + kc * (BN * BK * 2) + swz(wn * (32 * JT) + u * 32 + l31, 2 * ks + lh));
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int u = 0; u < 2; ++u) fi[u] = *(const bf16x8*)(sa + kc * (BM * BK * 2) + swz(wm * 64 + u * 32 + l31, 2 * ks + lh));
+#pragma unroll
+        for (int a = 0; a < JT; ++a)
 #pragma unroll
           for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fj[a], fi[c], acc[a][c], 0, 0, 0);
       }
@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, 
     for (int c = 0; c < 2; ++c) {
       const int64_t i = i0 + wm * 64 + c * 32 + l31;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int64_t jb = j0 + wn * 64 + a * 32;
+      for (int a = 0; a < JT; ++a) {
+        const int64_t jb = j0 + wn * (32 * JT) + a * 32;
         if constexpr (DT == LQER_F32) {
           if (i >= S1) continue;
           float* dst = (float*)out + (b * S1 + i) * S2;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, 
             for (int p2 = 0; p2 < 2; ++p2) {
               auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][0], pk[2 * p2 + 1][0], false, false);
               auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * p2][1], pk[2 * p2 + 1][1], false, false);
-              const int chunk = (wn * 64 + a * 32 + 16 * p2 + 8 * lh) >> 3;
+              const int chunk = (wn * (32 * JT) + a * 32 + 16 * p2 + 8 * lh) >> 3;
               *(uint4*)(sb + row_l * 256 + ((chunk ^ (row_l & 15)) << 4)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
             }
           } else if (wide) {
@@ -635,8 +635,8 @@ __global__ __launch_bounds__(256) void k_qmatmul_xr(const void* __restrict__ x, 
       __syncthreads();
       bf16_t* const ob = (bf16_t*)out + (b * S1) * S2 + j0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {  // 16 consecutive lanes = one row of the tile: 256 contiguous bytes
-        const int idx = tid + 256 * u, row_l = idx >> 4, chunk = idx & 15;
+      for (int u = 0; u < 2048 / T; ++u) {  // 16 consecutive lanes = one row of the tile: 256 contiguous bytes
+        const int idx = tid + T * u, row_l = idx >> 4, chunk = idx & 15;
         const uint4 v = *(const uint4*)(sb + row_l * 256 + ((chunk ^ (row_l & 15)) << 4));
         if (i0 + row_l < S1) *(uint4*)(ob + (i0 + row_l) * S2 + chunk * 8) = v;
       }
@@ -667,7 +667,7 @@ static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, in
   }
   if (Kp <= qmm::XR_MAXK && S2p / qmm::BN >= 2 * qmm::XR_JT) {  // short contraction, many column tiles: x tile resident in LDS
     const dim3 grid((unsigned)((S2p / qmm::BN + qmm::XR_JT - 1) / qmm::XR_JT), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
-    qmm::k_qmatmul_xr<DT><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, al16(x, x_bs, x_rs));
+    qmm::k_qmatmul_xr<DT><<<grid, 512, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, al16(x, x_bs, x_rs));
     return check_launch("lqer_matmul_q");
   }
   const dim3 grid((unsigned)(S2p / qmm::BN), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
