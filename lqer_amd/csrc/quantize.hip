@@ -8,6 +8,8 @@
 // Replaces reference quantizers/block_fp.py:7-82 together with the pad/unfold/fold blocking of
 // quantizers/utils.py:127-158 and :211-258 (an activation's blocks are runs of L consecutive
 // elements of one row, for 2-D and 3-D inputs alike - SURVEY.md §4).
+#include <type_traits>
+
 #include "common.h"
 
 namespace lqer {
@@ -179,6 +181,97 @@ __global__ __launch_bounds__(256) void k_quant_row(const void* __restrict__ x, i
   if (o.xscale && threadIdx.x == 0) o.xscale[row] = any ? ldexpf(1.0f, e - q.mbits) : 1.0f;
 }
 
+// The int8 image of per-token activations (one exponent per row, the int8 route) from 16-bit tensors: ONE WAVE per row, the
+// whole row in registers as raw 16-byte chunks - lane l holds chunks l, l + 64, ... (a wave's request is a contiguous KiB),
+// MAXCH requests in flight -, the row maximum by packed 16-bit maxima and one wave reduction (no LDS, no barrier), then every
+// chunk's 8 elements to 8 int8 (one 8-byte store per lane, 512 contiguous bytes per wave) with the packed signed arithmetic of
+// mxint16_i8_fast.  With one exponent per row nothing needs the 16-element block structure.  Same codes and scales as
+// k_quant_row (which stays for fp32 inputs, unaligned rows and rows longer than 64 x 8 x MAXCH elements).
+template <int DT, int MAXCH>
+__global__ __launch_bounds__(256) void k_quant_row8(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t ld, QP q,
+                                                    int8_t* __restrict__ xq8, int64_t cols_p8, float* __restrict__ xscale) {
+  static_assert(DT != LQER_F32, "16-bit inputs");
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = (int)(cols / 8), nch_p = (int)(cols_p8 / 8);
+  const u32x4* p = (const u32x4*)((const bf16_t*)x + row * ld);
+  u32x4 raw[MAXCH];
+#pragma unroll
+  for (int u = 0; u < MAXCH; ++u) raw[u] = lane + 64 * u < nch ? p[lane + 64 * u] : (u32x4){0, 0, 0, 0};
+  float amax = 0.f;
+  if constexpr (DT == LQER_F16) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    h2 m = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m = __builtin_elementwise_max(m, __builtin_bit_cast(h2, raw[u][j] & 0x7fff7fffu));
+    amax = fmaxf((float)m[0], (float)m[1]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        amax = fmaxf(amax, fmaxf(__uint_as_float((raw[u][j] << 16) & 0x7fffffffu), __uint_as_float(raw[u][j] & 0x7fff0000u)));
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
+  const bool any = amax > 0.f;
+  const int e = any ? block_exponent(amax, q) : 0;
+  if (lane == 0 && xscale) xscale[row] = any ? ldexpf(1.0f, e - q.mbits) : 1.0f;
+  int8_t* const dst = xq8 + row * cols_p8;
+  const bool fast = mxint16_fast_ok(e, q);  // (wave-uniform)
+  const float s = __uint_as_float((uint32_t)(127 + (fast ? q.mbits - e : 0)) << 23);
+  const float es = 1e-9f * s, lo = -q.mneg, hi = q.mmax;
+  const f2 magic = {12582912.0f, 12582912.0f};
+  auto emit = [&](auto fast_c) {  // (two copies under ONE wave-uniform branch: as a select the slow arithmetic ran for every element)
+    constexpr bool FAST = decltype(fast_c)::value;
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u) {
+      const int c = lane + 64 * u;
+      if (c >= nch_p) continue;
+      uint32_t h[4] = {0, 0, 0, 0};  // pairs of int16 mantissas
+      if (c < nch && any) {
+        // (plain words first: indexing raw[u][j] with the unrolled j directly made hipcc reuse word 0 for all four pairs)
+        const uint32_t wd[4] = {raw[u][0], raw[u][1], raw[u][2], raw[u][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f2 xv;
+          if constexpr (DT == LQER_F16) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            const h2 hv = __builtin_bit_cast(h2, wd[j]);
+            xv = (f2){(float)hv[0], (float)hv[1]};
+          } else {
+            xv = (f2){__uint_as_float(wd[j] << 16), __uint_as_float(wd[j] & 0xffff0000u)};
+          }
+          f2 r;
+          if constexpr (FAST) {
+            const f2 cc = {copysignf(es, xv[0]), copysignf(es, xv[1])};
+            r = (__builtin_elementwise_fma(xv, (f2){s, s}, cc) + magic) - magic;
+            r[0] = __builtin_amdgcn_fmed3f(r[0], lo, hi);
+            r[1] = __builtin_amdgcn_fmed3f(r[1], lo, hi);
+            if constexpr (DT != LQER_F16) {  // (fp16 cannot hold a non-zero |x| <= 1e-8)
+              r[0] = fabsf(xv[0]) <= 1e-8f ? 0.0f : r[0];
+              r[1] = fabsf(xv[1]) <= 1e-8f ? 0.0f : r[1];
+            }
+          } else {
+            r = (f2){mxint_mantissa(xv[0], e, q), mxint_mantissa(xv[1], e, q)};
+          }
+          h[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)r[0], (int)r[1]));
+        }
+      }
+      const u32x2 w = {__builtin_amdgcn_perm(h[1], h[0], 0x06040200u), __builtin_amdgcn_perm(h[3], h[2], 0x06040200u)};
+      *(u32x2*)(dst + (int64_t)c * 8) = w;
+    }
+  };
+  if (fast)
+    emit(std::true_type{});
+  else
+    emit(std::false_type{});
+}
+
 // One lane per block of L elements (L a multiple of 16), serial.
 template <int DT>
 __global__ __launch_bounds__(256) void k_quant_blk(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
@@ -253,7 +346,24 @@ static int launch_quant(const void* x, int64_t rows, int64_t cols, int64_t ld, c
   if (whole) {
     const int esz0 = DT == LQER_F32 ? 4 : 2;
     const bool vec0 = ((uintptr_t)x % 16 == 0) && ((ld * esz0) % 16 == 0);
-    k_quant_row<DT><<<dim3((unsigned)rows), 256, 0, st>>>(x, rows, cols, ld, q, o, vec0);
+    // the int8 image alone, from an aligned 16-bit tensor: one wave per row, the row in registers (k_quant_row8)
+    bool done = false;
+    if constexpr (DT != LQER_F32) {
+#ifndef LQER_NO_QUANT_ROW8
+      if (o.xq8 && !o.xq && !o.deq && !o.codes && !o.exps && vec0 && cols % 8 == 0 && q.mbits <= 7) {
+        const unsigned grid = (unsigned)((rows + 3) / 4);
+        const int64_t nch_p = o.cols_p8 / 8;
+        if (nch_p <= 64 * 12) {
+          k_quant_row8<DT, 12><<<grid, 256, 0, st>>>(x, rows, cols, ld, q, o.xq8, o.cols_p8, o.xscale);
+          done = true;
+        } else if (nch_p <= 64 * 28) {
+          k_quant_row8<DT, 28><<<grid, 256, 0, st>>>(x, rows, cols, ld, q, o.xq8, o.cols_p8, o.xscale);
+          done = true;
+        }
+      }
+#endif
+    }
+    if (!done) k_quant_row<DT><<<dim3((unsigned)rows), 256, 0, st>>>(x, rows, cols, ld, q, o, vec0);
   } else if (q.block == 16) {
     const int64_t total = rows * ((width + 15) / 16);
     const unsigned grid = (unsigned)((total + 255) / 256 < 1 << 20 ? (total + 255) / 256 : 1 << 20);
