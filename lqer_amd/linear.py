@@ -440,6 +440,12 @@ class SharedActivation:
         dummy_b = torch.zeros(off, 16, dtype=a_cat.dtype, device=dev)
         a_t, _, a_limbs, _ = ops.pack_lowrank(a_cat, dummy_b)
         self._cat = {"a_t": a_t, "a_limbs": a_limbs, "offs": offs, "rp_total": off}
+        # members on the int8 route with an fp16 A: the group's side GEMM too takes A as ONE fp16 image (a_limbs = -1)
+        m0 = self.members[0]
+        if all(m._x_i8 and m.i8_a_f16 for m in self.members) and a_limbs == 2 and m0._packed is not None:
+            ok16, a16 = ops.a_f16_image(m0._packed["w"], m0.out_features, K, a_t, 2, off)
+            if ok16:
+                self._cat["a_t_f16"] = a16
 
     @torch.no_grad()
     def forward_member(self, mod, x, x2, y) -> bool:
@@ -488,7 +494,8 @@ class SharedActivation:
             pool["owner"] = (id(self), self._round)
             b = {"xq": pool["xq"], "xaq": pool["xaq"], "scr": pool["scr"], "nscr": nscr}
             check(L.lqer_quantize_act_xa(C.byref(gdesc), x2.data_ptr(), ops.dtype_code(x2), M, x2.stride(0) if M > 1 else K,
-                                         self._cat["a_t"].data_ptr(), self._cat["a_limbs"], b["xq"].data_ptr(),
+                                         *((self._cat["a_t_f16"].data_ptr(), -1) if i8 and "a_t_f16" in self._cat
+                                           else (self._cat["a_t"].data_ptr(), self._cat["a_limbs"])), b["xq"].data_ptr(),
                                          b["xaq"].data_ptr(), b["scr"].data_ptr(), b["nscr"], ops._stream(dev)),
                   "lqer_quantize_act_xa (shared input)")
             self._x, self._ver, self._cur, self._served = x, ver, dict(b, M=M), set()
