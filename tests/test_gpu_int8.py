@@ -81,9 +81,13 @@ def test_int8_activation_image_bit_exact(lq, dtype):
     from lqer_amd import ops
 
     torch.manual_seed(5)
-    for M, K in ((5, 200), (300, 4096), (1, 128)):
+    # (200, 128: one wave per row with 12 chunks per lane; 5120: the C4 shape; 13824: 28 chunks per lane; 20000: past that
+    # kernel's reach - the workgroup-per-row kernel; 100 and 1001: K not a multiple of 8 - the workgroup-per-row kernel)
+    for M, K in ((5, 200), (300, 4096), (1, 128), (7, 5120), (3, 13824), (2, 20000), (4, 100), (6, 1001)):
         x = (torch.randn(M, K) * 3).to(dtype)
         x[:, 3] *= 30
+        if M > 3:
+            x[3] *= 2.0 ** -6  # a row of smaller values (not so small that an fp32 element falls under the 1e-8 flush)
         if M > 2:
             x[2] = 0  # an all-zero row
         fmt = ops.make_qfmt(dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[1, -1], skip_first_dim=True), "x")
