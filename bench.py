@@ -3,12 +3,18 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|d1|d16|d1a16]
                     [--sweep auto|weak|strong] [--no-cpu-baseline] [--no-check] [--no-module] [--graph G] [--prewarm-ms T]
+                    [--dry-run-cpu]
 
 A step = one pass of the hot path (x fp16 in -> activation quantize -> rank-r side GEMM -> fused W4A8 GEMM -> y fp16
 out) over one batch of synthetic tokens for every Linear unit this rank owns, inputs resident in HBM.  Default
 workload = BASELINE.json configs[1]: one LqerLinear 4096 -> 4096, rank 32, W4A8 MXINT (block 16), M = 2048 tokens.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the path shards into independent Linear
+Multi-GPU (one rank per GPU).  Either the driver launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or a plain `python bench.py
+--gpus N` starts them itself: before anything touches the GPU it runs that very launcher as a CHILD process (never an
+exec), relays the child's output - rank 0's one JSON line - and exits with its return code.  `--dry-run-cpu` runs the
+same host logic (partition, broadcast, barrier-bracketed timed region, max over ranks, gather, one JSON line) on gloo
+without a GPU and without a kernel: the plumbing check of tests/test_multirank_cpu.py.  The path shards into independent Linear
 units.  Rank 0 generates the token batch x once per distinct K and BROADCASTS it (RCCL, outside the timed region, timed
 separately as `broadcast_ms`); every rank builds the weights of its own units from a seed; per-rank times and checksums
 are GATHERED after the timed region.  No collective on the data path.
@@ -170,6 +176,85 @@ def check_rows(M):
     return torch.tensor(sorted(set(range(n)) | set(range(M - n, M))))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --standalone --nproc-per-node N
+    bench.py <same arguments>` as a child process (this process has not touched the GPU and never will), pass its stdout
+    - rank 0's JSON line - and stderr through unchanged, return its exit code.  The rule the ranks then follow is the
+    reference's consecutive-layers-per-device split (experiments/infer_device_map.py:29-37)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port: two benches on one node must not meet
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print("# bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run_cpu(args, rank, world):
+    """--dry-run-cpu: everything of a multi-rank run that is not a kernel, on gloo / CPU tensors - layer partition,
+    broadcast of the token batch once per distinct K, barrier-bracketed timed region, max / sum over ranks, gather, ONE
+    JSON line on rank 0.  The step is a no-op (the hot path has no CPU form), so `value` is null and the line says so."""
+    from lqer_amd import sweep
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS[args.workload]
+    if args.layers > 0:
+        layers = args.layers
+    M = min(M, 64)  # the plumbing does not depend on the token count
+    steps = args.steps or 2
+    strong = (args.sweep == "strong") or (args.sweep == "auto" and layers > 1)
+    if strong and layers == 1 and world > 1:
+        sys.exit("--sweep strong needs a model workload (c3/c4/c5): a single Linear has no layers to split")
+    my_layers = sweep.layer_partition(layers, world)[rank] if strong else range(layers)
+    xs, broadcast_ms = {}, 0.0
+    for K in sorted({K for K, _, _ in shapes}):
+        xd = make_x(M, K, seed=0)[0].half() if rank == 0 else torch.full((M, K), float("nan"), dtype=torch.float16)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        sweep.broadcast_activation(xd, src=0)
+        broadcast_ms += (time.perf_counter() - t0) * 1e3
+        xs[K] = xd
+    units = sweep.projection_units(shapes, my_layers)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pass  # (no kernel without a GPU)
+    if dist is not None:
+        dist.barrier()
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = sweep.max_over_ranks(elapsed_rank, dev)
+    xsum = float(sum(v.float().sum().item() for v in xs.values()))
+    gathered = sweep.gather_rows([elapsed_rank * 1e3 / steps, xsum, float(len(my_layers))], dev)
+    flops_all = sweep.sum_over_ranks(float(sum(flops(M, K, N, r) for _, K, N, _ in units)), dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv", "value": None, "unit": "TFLOP/s-equiv", "n_gpus": world,
+            "steps": steps, "warmup": 0, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": None, "data": "synthetic",
+            "dry_run": "cpu/gloo: launcher, partition, broadcast, timed-region protocol and gather only - no kernel ran",
+            "config": {"workload": desc_txt + " [dry run, M=%d]" % M, "tokens_per_step": M, "rank": r,
+                       "layers_per_rank": [int(row[2]) for row in gathered]},
+            "broadcast_ms": round(broadcast_ms, 3), "flops_per_step_all_ranks": flops_all,
+            "rank_ms_per_step": [round(row[0], 4) for row in gathered],
+            "rank_checksums": [round(row[1], 3) for row in gathered]}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,15 +272,22 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="capture G consecutive steps in one hipGraph and replay it steps/G times (launch-bound decode sizes; "
                          "G ~ the number of Linears a model pushes a token through)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="no GPU, no kernel: the multi-rank host logic alone (launcher, partition, gloo broadcast / gather, "
+                         "timed-region protocol, the JSON line) - value is null")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves, as a child process, BEFORE any GPU call of this process
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)

@@ -173,3 +173,40 @@ def test_sharded_approximator_two_ranks_gloo():
     assert res[0][2] == res[1][2]  # every rank ends with the same full dictionary
     d = res[0][2]
     assert d["layers.0.q_proj.A"] == 1.0 and d["layers.1.o_proj.B"] == -1.0 and d["layers.2.q_proj.A"] == 2.0 and d["layers.2.o_proj.B"] == -2.0
+
+
+@pytest.mark.parametrize("workload,layers_per_rank,scaling", [("c3", [16, 16], "strong"), ("c2", [1, 1], "weak")])
+def test_bench_starts_its_own_ranks_dry_run(workload, layers_per_rank, scaling):
+    """`python bench.py --gpus 2` with no launcher around it (the form of the driver's 1-GPU command): the process
+    starts the two ranks itself as a child (torch.distributed.run), which partition the layers by the reference's rule
+    (experiments/infer_device_map.py:29-37), broadcast, time, gather - and stdout carries exactly ONE JSON line.
+    --dry-run-cpu keeps it on gloo with no kernel, so it runs in a container without a GPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--workload", workload],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] is None and "dry_run" in out
+    assert out["config"]["layers_per_rank"] == layers_per_rank
+    assert len(out["rank_ms_per_step"]) == 2
+    assert out["rank_checksums"][0] == out["rank_checksums"][1]  # rank 1 holds rank 0's broadcast batch
+
+
+def test_bench_launcher_relays_the_childs_exit_code():
+    """A failing rank must fail the bench: --sweep strong on a single-Linear workload is refused by every rank."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--workload", "c2",
+                          "--sweep", "strong"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
