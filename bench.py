@@ -144,7 +144,7 @@ def make_case(M, K, N, r, seed=0, bias=False, quantize_ab=True):
     return (x,) + make_weights(g, K, N, r, bias, quantize_ab)
 
 
-def cpu_baseline(M, K, N, r, q_config, reps=2):
+def cpu_baseline(M, K, N, r, q_config, reps=3):
     """The CPU oracle (a port of the reference's eager-torch emulation, routed through the same pad/unfold/fold blocking
     ops as the reference) timed on the host cores; steady state, i.e. the one-time weight quantization (reference
     linear.py:149-153) is done before the clock starts.  Bounded sample: at most 2048 tokens of the workload's first
@@ -159,13 +159,15 @@ def cpu_baseline(M, K, N, r, q_config, reps=2):
     x = x.half().float()
     wq = O.get_quantizer(q_config["w_quantizer"])(W)
     O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)  # warm-up
-    best = float("inf")
+    times = []
     for _ in range(reps):
         t0 = time.perf_counter()
         O.lqer_linear_forward(x, wq, None, A, B, q_config, weight_is_quantized=True, via_unfold=True)
-        best = min(best, time.perf_counter() - t0)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
     return {"value": round(flops(Ms, K, N, r) / best / 1e12, 4), "unit": "TFLOP/s-equiv", "cores": cores, "host_cores": host,
-            "kind": "port", "ms": round(best * 1e3, 2), "tokens_per_s": round(Ms / best, 1),
+            "kind": "port", "ms": round(best * 1e3, 2), "ms_all_reps": [round(t * 1e3, 2) for t in times],
+            "tokens_per_s": round(Ms / best, 1),
             "sample": f"M={Ms} of {M} tokens, K={K} N={N} r={r} (first projection shape), fp32 eager torch-CPU, "
                       f"min of {reps} after warm-up, weights pre-quantized"}
 
@@ -174,6 +176,40 @@ def check_rows(M):
     """Rows compared with the oracle after the timed region: the first and the last 96 (first / last row tile)."""
     n = min(96, M)
     return torch.tensor(sorted(set(range(n)) | set(range(M - n, M))))
+
+
+class HipEvent:
+    """A timing event recorded straight through the HIP runtime on the launch stream (the roofline sample brackets single
+    kernel launches inside the timed region; torch.cuda.Event is the same call with default flags).  LQER_BENCH_EVENT_FLAGS
+    selects the creation flags: default 0x20000000 = hipEventDisableSystemFence (the event's release stays at device scope -
+    nothing on the host reads what the bracketed kernel wrote; measured on the driver's 20-step C2 run with 10 sampled
+    launches: 982 TFLOP/s-equiv against 958-961 with hipEventDefault and 960 with hipEventReleaseToDevice, calibrated pair
+    overhead 3.4 vs 4.6-5.2 us, same kernel durations), 0 = hipEventDefault."""
+    _hip = None
+
+    def __init__(self, flags):
+        import ctypes as C
+
+        if HipEvent._hip is None:
+            h = C.CDLL("libamdhip64.so")
+            h.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+            h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+            h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+            HipEvent._hip = h
+        self.h = C.c_void_p()
+        rc = HipEvent._hip.hipEventCreateWithFlags(C.byref(self.h), flags)
+        assert rc == 0, f"hipEventCreateWithFlags: {rc}"
+
+    def record(self, stream):
+        HipEvent._hip.hipEventRecord(self.h, stream)
+
+    def elapsed_time(self, other):
+        import ctypes as C
+
+        ms = C.c_float()
+        rc = HipEvent._hip.hipEventElapsedTime(C.byref(ms), self.h, other.h)
+        assert rc == 0, f"hipEventElapsedTime: {rc}"
+        return ms.value
 
 
 def launch_ranks(n, argv):
@@ -357,7 +393,9 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     gemm_events = []
     launch_no = [0]
-    EV_EVERY = 10  # bracket every 10th launch of the dominant kernel with HIP events (each pair costs ~12 us of gaps)
+    # bracket every n-th launch of the dominant kernel with HIP events: at least 8 samples inside the timed region
+    # whatever --steps is (the driver's 20-step C2 run: every 2nd launch), at most every 10th (a pair costs ~12 us of gaps)
+    EV_EVERY = max(1, min(10, args.steps * sum(m[4] for m in mods) // 8))
 
     # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
     plans = []
@@ -398,7 +436,8 @@ def main():
     bound = {}
     # event pairs for the sampled launches, created ahead of the timed region (creating one costs more host time than a
     # decode-size kernel runs)
-    new_pair = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev_flags = int(os.environ.get("LQER_BENCH_EVENT_FLAGS", "0x20000000"), 0)
+    new_pair = lambda: (HipEvent(ev_flags), HipEvent(ev_flags))
     ev_pool = [new_pair() for _ in range(64)]
 
     def calls_for(st):
@@ -426,12 +465,12 @@ def main():
                     # point of INTEGRATION.md; the events bracket that launch
                     if ev:
                         e0, e1 = ev_pool.pop() if ev_pool else new_pair()
-                        e0.record()
+                        e0.record(stream)
                     rc = fwd(*fa)
                     if rc:
                         _lib.check(rc, "linear_forward")
                     if ev:
-                        e1.record()
+                        e1.record(stream)
                         gemm_events.append((e0, e1, K, N))
                     continue
                 # the two calls of lqer_linear_forward, issued separately so that the dominant kernel can be
@@ -441,12 +480,12 @@ def main():
                     _lib.check(rc, "quantize_act_xa")
                 if ev:
                     e0, e1 = ev_pool.pop() if ev_pool else new_pair()
-                    e0.record()
+                    e0.record(stream)
                 rc = gemm(*ga)
                 if rc:
                     _lib.check(rc, "linear_gemm")
                 if ev:
-                    e1.record()
+                    e1.record(stream)
                     gemm_events.append((e0, e1, K, N))
 
     def step_module():
@@ -592,9 +631,9 @@ def main():
         for _ in range(32):
             _lib.check(L.lqer_quantize_act_mxint(mods[0][1].data_ptr(), _lib.F16, min(32, M), mods[0][2], mods[0][2],
                                                  C.byref(ops.make_qfmt(MXINT_Q["x_quantizer"], "x")), ops.workspace(dev, 1 << 20).data_ptr(), stream), "cal")
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            c1.record()
+            c0, c1 = new_pair()
+            c0.record(stream)
+            c1.record(stream)
             cal.append((c0, c1))
         torch.cuda.synchronize()
         ev_overhead_ms = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2]
@@ -613,16 +652,20 @@ def main():
         # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes over this very
         # command (tools/pmc_bench.sh; a profiler cannot run inside this process); the committed summary of the
         # workload is quoted, with its ratio to the algorithmic bytes
-        traffic, traffic_ratio = None, None
-        tfile = os.path.join(ROOT, "profiles", f"r02_traffic_{args.workload}.json")
-        if os.path.exists(tfile):
-            with open(tfile) as fh:
-                tj = json.load(fh)
-            traffic, traffic_ratio = tj.get("traffic_bytes_per_launch"), tj.get("ratio_to_algorithmic")
+        traffic, traffic_ratio, traffic_source = None, None, None
+        for rnd in ("r03", "r02"):
+            tfile = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{args.workload}.json")
+            if os.path.exists(tfile):
+                with open(tfile) as fh:
+                    tj = json.load(fh)
+                traffic, traffic_ratio = tj.get("traffic_bytes_per_launch"), tj.get("ratio_to_algorithmic")
+                traffic_source = (f"profiles/{rnd}_traffic_{args.workload}.json - separate rocprofv3 --pmc passes over this command "
+                                  "(tools/pmc_bench.sh), committed; NOT measured in this run")
+                break
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TOP/s" if int8 else "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
-                    "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
-                    "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
+                    "traffic_source": traffic_source, "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
+                    "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2), "event_flags": hex(ev_flags),
                     "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4)}
         if M <= 64:
             # small-M kernel: HBM-bound.  Algorithmic bytes per launch: packed W (0.5625 B per weight)
@@ -636,7 +679,7 @@ def main():
             gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
-                        "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch}
+                        "traffic_source": traffic_source, "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch}
         out = {
             "metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv",
             "value": round(value, 2),

@@ -38,11 +38,11 @@ constexpr int BM = 128, BN = 256, BK = 64;
 #endif
 constexpr int DEPTH = LQER_DEPTH;                     // k-steps of prefetch in flight
 constexpr int NSLOT = DEPTH + 1;                      // LDS ring slots
-constexpr int A_SLOT = BM * BK * 2;                   // 16 KiB  activation tile, bf16
 constexpr int R_SLOT = (BN / 16) * LQER_PANEL_BYTES;  // 9216 B  packed weight panels (4-bit codes + exponents)
 constexpr int OFF_A = 0;
-constexpr int OFF_R = NSLOT * A_SLOT;
-constexpr int GEMM_LDS = OFF_R + NSLOT * R_SLOT;  // 102400 B
+// per tile height (MT 32-row tiles): activation slot 16 KiB (128 rows) or 8 KiB (64 rows), bf16; the panels behind the ring
+constexpr int a_slot_bytes(int mt) { return 32 * mt * BK * 2; }
+constexpr int gemm_lds_bytes(int mt) { return NSLOT * a_slot_bytes(mt) + NSLOT * R_SLOT; }  // 102400 B / 69632 B (two workgroups per CU)
 
 // byte offset of 16-byte chunk `c` (8 bf16 along k) of tile row `r`; rows are 128 B.
 // chunk ^ ((row >> 1) & 7): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots.
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   constexpr int BMk = 32 * MT;   // tile rows
   constexpr int AP = MT / 2;     // 8-row LDS-DMA pieces of the activation tile per wave and k-step
   constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image, weights expanded to fp16, v_mfma_f32_32x32x16_f16
+  constexpr int A_SLOT = a_slot_bytes(MT), OFF_R = NSLOT * A_SLOT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -681,14 +682,14 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
 #define LQER_GEMM_LAUNCH(LR, BO)                                                                                \
   do {                                                                                                          \
     static LdsLimitOnce lds_once;                                                                               \
-    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO>, GEMM_LDS);                                               \
-    k_lqer_gemm<DT, LR, BO><<<grid, 512, GEMM_LDS, st>>>(g);                                                    \
+    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO>, gemm_lds_bytes(4));                                      \
+    k_lqer_gemm<DT, LR, BO><<<grid, 512, gemm_lds_bytes(4), st>>>(g);                                           \
   } while (0)
 #define LQER_GEMM_LAUNCH_STAGED(BO)                                                                             \
   do {                                                                                                          \
     static LdsLimitOnce lds_once;                                                                               \
-    lds_once.set((const void*)k_lqer_gemm<DT, true, BO, true>, GEMM_LDS);                                       \
-    k_lqer_gemm<DT, true, BO, true><<<grid, 512, GEMM_LDS, st>>>(g);                                            \
+    lds_once.set((const void*)k_lqer_gemm<DT, true, BO, true>, gemm_lds_bytes(4));                              \
+    k_lqer_gemm<DT, true, BO, true><<<grid, 512, gemm_lds_bytes(4), st>>>(g);                                   \
   } while (0)
 #ifndef LQER_STAGE_MIN
 #define LQER_STAGE_MIN 32
@@ -697,8 +698,8 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
 #define LQER_GEMM_LAUNCH_H64(LR, BO, ST)                                                                        \
   do {                                                                                                          \
     static LdsLimitOnce lds_once;                                                                               \
-    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO, ST, 2>, GEMM_LDS);                                        \
-    k_lqer_gemm<DT, LR, BO, ST, 2><<<grid, 512, GEMM_LDS, st>>>(g);                                             \
+    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO, ST, 2>, gemm_lds_bytes(2));                               \
+    k_lqer_gemm<DT, LR, BO, ST, 2><<<grid, 512, gemm_lds_bytes(2), st>>>(g);                                    \
   } while (0)
   if (g.tiles_m_rows == 64) {  // (gemm_dispatch: the 128-row grid would fill at most half of the CUs)
     if (!lowrank) LQER_GEMM_LAUNCH_H64(false, 0, false);
@@ -728,7 +729,7 @@ extern "C" int lqer_debug_set_stamp_buffer(void* p) {
 }
 #endif
 
-static std::atomic<int> g_tile_rows{0};  // test hook (lqer_debug_set_tile_rows): 0 = per launch, 128 = never 64-row tiles
+static std::atomic<int> g_tile_rows{0};  // test hook (lqer_debug_set_tile_rows): 0 = per launch, 128 = never 64-row tiles, 64 = always
 
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
   if (bout.kind != LQER_Q_MXINT || bout.block == 16) return 0;
@@ -823,7 +824,8 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   {
     constexpr int CUS = 256;
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;
-    if (g_tile_rows.load(std::memory_order_relaxed) != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) {
+    const int pin = g_tile_rows.load(std::memory_order_relaxed);
+    if ((pin != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) || (pin == 64 && g.M > 64)) {
       g.tiles_m = (g.M + 63) / 64;
       g.tiles_m_rows = 64;
     }
@@ -839,7 +841,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
 }
 
 extern "C" int lqer_debug_set_tile_rows(int rows) {
-  g_tile_rows.store(rows == 128 ? 128 : 0, std::memory_order_relaxed);
+  g_tile_rows.store(rows == 128 ? 128 : (rows == 64 ? 64 : 0), std::memory_order_relaxed);
   return 0;
 }
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--also-128", action="store_true", help="time every build a second time with the 128-row tiles pinned (lqer_debug_set_tile_rows)")
+    ap.add_argument("--also-64", action="store_true", help="time every build once more with 64-row tiles forced (two workgroups per CU at large M)")
     ap.add_argument("--gap", type=int, default=0, help="tiny unrelated kernels launched between the quantizer and the GEMM (boundary-effect probe)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -45,17 +46,20 @@ def main():
     f4 = _lib.QFmt(_lib.Q_MXINT, 4, 16, 8, 127)
     desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
     libs = [(p, load(p)) for p in a.libs]
+    base = list(libs)
     if a.also_128:
-        libs += [(p + " [128-row tiles]", L) for p, L in list(libs)]
+        libs += [(p + " [128-row tiles]", L) for p, L in base]
+    if a.also_64:
+        libs += [(p + " [64-row tiles]", L) for p, L in base]
     st = torch.cuda.current_stream().cuda_stream
     nscr = libs[0][1].lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
     scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
 
     dummy = torch.zeros(64, device=dev)
 
-    def run(L, pin=False):
+    def run(L, pin=0):
         if hasattr(L, "lqer_debug_set_tile_rows"):
-            L.lqer_debug_set_tile_rows(128 if pin else 0)
+            L.lqer_debug_set_tile_rows(pin)
         # (a build whose GEMM sums the partial tiles of x A itself - lqer_decode_partials - gets no xaq: two launches)
         xa = None if L.lqer_decode_partials(C.byref(desc), M) else xaq.data_ptr()
         rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xa,
@@ -67,17 +71,18 @@ def main():
                                 _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
 
+    pin_of = lambda p: 128 if p.endswith("[128-row tiles]") else (64 if p.endswith("[64-row tiles]") else 0)
     times = {p: [] for p, _ in libs}
     for p, L in libs:
         for _ in range(10):
-            run(L, p.endswith("tiles]"))
+            run(L, pin_of(p))
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for p, L in libs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                run(L, p.endswith("tiles]"))
+                run(L, pin_of(p))
             e1.record()
             torch.cuda.synchronize()
             times[p].append(e0.elapsed_time(e1) / a.iters * 1e3)
@@ -85,7 +90,7 @@ def main():
     for p, _ in libs:
         t = sorted(times[p])
         med, mn = t[len(t) // 2], t[0]
-        print(f"{os.path.basename(p):28s} median {med:8.2f} us  min {mn:8.2f} us per step  {fl / med / 1e6:8.1f} TFLOP/s-equiv (median)")
+        print(f"{os.path.basename(p):44s} median {med:8.2f} us  min {mn:8.2f} us per step  {fl / med / 1e6:8.1f} TFLOP/s-equiv (median)")
 
 
 if __name__ == "__main__":
