@@ -101,6 +101,6 @@ def approximate_model(model: nn.Module, a_cfg: Optional[dict] = None, b_cfg: Opt
         if world > 1:
             dist.broadcast(m.A.data, src=owners[name])
             dist.broadcast(m.B.data, src=owners[name])
-        m.invalidate_packed()
+        m.invalidate_packed(weight_changed=False)  # A, B replaced: the weight stays quantized once
         out[f"{name}.A"], out[f"{name}.B"] = m.A.data.clone(), m.B.data.clone()
     return out

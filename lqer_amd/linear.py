@@ -47,6 +47,8 @@ class _LinearBase(nn.Linear):
         # exponent of a second pass).  Their images outlive invalidate_packed() until the dense parameter is reloaded.
         self._w_single = None      # single-copy packed weight image of the current `weight`
         self._bias_q = None        # fp32 [Np] b_quantizer(bias) of the current `bias`
+        self._w_ver = None         # (weight._version, bias._version) when the images were built: an in-place write to the
+                                   # parameters (`with torch.no_grad(): mod.weight.copy_(W2)`) is seen by the next forward
         self._group = None         # SharedActivation of Linears fed by the same tensor (models.quantize_model)
         self._fw_cache = {}        # token count -> (descriptor, workspace bytes)
         self._x_f16 = False        # pass-through fp16 activations on the fp16 MFMA route (decided when the images are built)
@@ -159,14 +161,19 @@ class _LinearBase(nn.Linear):
         return st
 
     # -- derived buffers -------------------------------------------------------------------------
-    def invalidate_packed(self, weight_changed: bool = False, bias_changed: bool = False) -> None:
-        """Drop the derived images; the next forward rebuilds them.  The weight / bias keep their quantized-once images
-        (and `w_is_quantized`) unless the dense parameter itself was replaced: pass weight_changed / bias_changed = True
-        after writing new unquantized values into `weight` / `bias` by hand (load_state_dict does it by itself)."""
+    def invalidate_packed(self, *, weight_changed: bool, bias_changed: bool = False) -> None:
+        """Drop the derived images; the next forward rebuilds them.  `weight_changed` has no default on purpose: the caller
+        says whether `weight` now holds NEW unquantized values (True: it is quantized and packed again, as after
+        load_state_dict, which passes it by itself) or the values this module already quantized (False: the
+        quantized-once image is kept - .to() / .half() / A, B reloaded; block_fp quantization is not idempotent, reference
+        linear.py:149-153 runs it once).  Writes through `weight.data` are invisible to autograd's version counter, so
+        after `mod.weight.data.copy_(W2)` call `invalidate_packed(weight_changed=True)`; in-place writes to the parameter
+        itself (`mod.weight.copy_(W2)` under no_grad) are noticed by the next forward without any call."""
         self._packed = None
         self._fw_cache = {}
         self._x_f16 = False
         self._x_i8 = False
+        self._w_ver = None
         if weight_changed:
             self._w_single = None
             if self.is_ptq:
@@ -208,7 +215,7 @@ class _LinearBase(nn.Linear):
                 self._packed = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in p.items()}
         else:
             # .to() / .half(): the A / B images follow the new dtype and device; the weight stays quantized once
-            self.invalidate_packed()
+            self.invalidate_packed(weight_changed=False)
         return out
 
     # -- packed checkpoint (lqer_amd/checkpoint.py) ------------------------------------------------
@@ -312,6 +319,7 @@ class _LinearBase(nn.Linear):
                 p["a_t"], p["b_t"], p["a_limbs"], p["b_limbs"] = ops.pack_lowrank(self.A.data, self.B.data)
             self._packed = self._replicate(p)
         self.w_is_quantized = True
+        self._w_ver = (self.weight._version, None if self.bias is None else self.bias._version)
 
     # -- forward -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -327,6 +335,10 @@ class _LinearBase(nn.Linear):
 
     @torch.no_grad()
     def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
+        if self._w_ver is not None:  # the dense parameters were written in place since their images were built
+            wv, bv = self._w_ver
+            if self.weight._version != wv or (bv is not None and self.bias._version != bv):
+                self.invalidate_packed(weight_changed=self.weight._version != wv, bias_changed=True)
         if self._packed is None or self.w_is_quantized is False:
             self._pack()
         K, N = self.in_features, self.out_features
@@ -385,7 +397,7 @@ class SharedActivation:
     one block per row with equal power-of-two ranks (a multiple of 16), rank > 0 for every member, padded ranks summing
     to at most 256 (else `enabled` is False and nothing changes for the members)."""
 
-    _pool = {}  # device -> {"xq", "xaq", "scr": uint8 tensors, "owner": (id(group), round)} - see forward_member
+    _pool = {}  # (device, stream) -> {"xq", "xaq", "scr": uint8 tensors, "owner": (id(group), round)} - see forward_member
 
     def __init__(self, members):
         self.members = list(members)
@@ -416,12 +428,19 @@ class SharedActivation:
         self._round = 0       # rounds started by this group (pool ownership)
         self._cur = None
         self._served = set()  # members served from the current images
+        self._i8_route = {}   # (M, dtype) -> every member's GEMM takes the int8 kernel
         if self.enabled:
             for m in self.members:
                 m._group = self
 
     def invalidate(self):
         self._cat, self._x, self._cur, self._served = None, None, None, set()
+        self._i8_route = {}
+
+    @classmethod
+    def release_pool(cls):
+        """Free the shared image pools of every (device, stream) - they are grow-only and outlive the models that used them."""
+        cls._pool.clear()
 
     @torch.no_grad()
     def _pack_cat(self, dev):
@@ -466,15 +485,20 @@ class SharedActivation:
         # member: a member that comes back with the same tensor starts a new round
         ver = None if x.is_inference() else x._version
         idx = self.members.index(mod)
-        pool = SharedActivation._pool.get(dev)
+        pkey = (dev, ops._stream(dev))  # like ops.workspace: two streams driving two groups must not share images
+        pool = SharedActivation._pool.get(pkey)
         fresh = not (x is self._x and ver == self._ver and self._cur is not None and self._cur["M"] == M and idx not in self._served
                      and pool is not None and pool["owner"] == (id(self), self._round))  # (another group has used the pool since)
         # members on the int8 route (per-token activations): the shared image is int8 only if every member's GEMM takes the
         # int8 kernel at this token count, else everybody uses the bf16 image
-        i8 = all(m._x_i8 for m in self.members)
-        if i8:
-            dtc = ops.dtype_code(x2)
-            i8 = all(L.lqer_gemm_route(C.byref(m._desc()), M, dtc) == _lib.ROUTE_TILE256_I8 for m in self.members)
+        dtc = ops.dtype_code(x2)
+        i8 = self._i8_route.get((M, dtc))
+        if i8 is None:  # (decided once per token count and dtype: a descriptor + a route query per member is host time)
+            i8 = all(m._x_i8 for m in self.members) and \
+                all(L.lqer_gemm_route(C.byref(m._desc()), M, dtc) == _lib.ROUTE_TILE256_I8 for m in self.members)
+            if len(self._i8_route) > 64:
+                self._i8_route = {}
+            self._i8_route[(M, dtc)] = i8
         if fresh:
             gdesc = m0._desc(plain=not i8)
             gdesc.rank = self._cat["rp_total"]
@@ -486,7 +510,7 @@ class SharedActivation:
             nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(gdesc), M)
             need = {"xq": Mp * Kp * 2, "xaq": Mp * self._cat["rp_total"] * 2, "scr": max(nscr, 16)}
             if pool is None:
-                pool = SharedActivation._pool[dev] = {"owner": None}
+                pool = SharedActivation._pool[pkey] = {"owner": None}
             for name, nbytes in need.items():
                 if name not in pool or pool[name].numel() < nbytes:
                     pool[name] = torch.empty(nbytes, dtype=torch.uint8, device=dev)

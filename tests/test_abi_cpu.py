@@ -157,6 +157,10 @@ def test_module_mirrors_reference_interface():
     no_default = {k: v for k, v in MXINT_Q.items() if k != "default"}
     with pytest.raises(KeyError):
         cls(64, 48, q_config=no_default, l_config={"rank": 16})
+    with pytest.raises(TypeError):  # "did the weight change?" has no default
+        m.invalidate_packed()
+    m.invalidate_packed(weight_changed=True)
+    assert m.w_is_quantized is False
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(2, 64))
     with pytest.raises(NotImplementedError):

@@ -134,7 +134,7 @@ def test_int8_route_forward_vs_oracle_and_bf16_route(lq, dtype, tol, M, K, N, r,
     err = float((y.float().cpu() - ref).norm() / ref.norm())
     assert err <= tol, err
     mod.a8_native = False
-    mod.invalidate_packed()
+    mod.invalidate_packed(weight_changed=False)
     y2 = mod(xin.to(DEV))
     assert not mod._x_i8
     d = float((y.float() - y2.float()).norm() / y2.float().norm())
@@ -144,7 +144,7 @@ def test_int8_route_forward_vs_oracle_and_bf16_route(lq, dtype, tol, M, K, N, r,
         assert float((y != y2).float().mean()) <= 0.01
     # rows are independent: a slice that runs the small tiles of the bf16 route gives the bf16 route's bits
     mod.a8_native = True
-    mod.invalidate_packed()
+    mod.invalidate_packed(weight_changed=False)
     y3 = mod(xin[:100].to(DEV))
     assert mod._x_i8 and torch.equal(y3, y2[:100])
 

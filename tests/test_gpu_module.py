@@ -69,6 +69,42 @@ def test_weight_is_quantized_exactly_once(lq):
     assert (y4 - ref4).norm() / ref4.norm() <= 1e-3
 
 
+def test_new_weights_written_in_place_are_requantized(lq):
+    """invalidate_packed() used to mean "the weights changed".  Now (a) an in-place write to the parameter is
+    noticed by the next forward on its own (version counter), (b) a write through .data needs
+    invalidate_packed(weight_changed=True), and (c) the flag has no default, so an old-style call fails loudly."""
+    from bench import MXINT_Q, make_case
+
+    M, K, N, r = 24, 256, 128, 16
+    x, W, A, B = make_case(M, K, N, r, seed=31)
+    W2 = make_case(M, K, N, r, seed=32)[1]
+    xd = x.to(DEV)
+
+    def fresh(Wv):
+        m = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+        m.load_state_dict({"weight": Wv, "A": A, "B": B})
+        return m.to(DEV)
+
+    want = fresh(W2)(xd)
+    m = fresh(W)
+    y1 = m(xd)
+    assert not torch.equal(y1, want)
+    with torch.no_grad():
+        m.weight.copy_(W2.to(DEV))  # (a) bumps weight._version
+    assert torch.equal(m(xd), want)
+    m = fresh(W)
+    m(xd)
+    m.weight.data.copy_(W2.to(DEV))  # (b) invisible to the version counter
+    with pytest.raises(TypeError):
+        m.invalidate_packed()  # (c)
+    m.invalidate_packed(weight_changed=True)
+    assert m.w_is_quantized is False
+    assert torch.equal(m(xd), want)
+    # and the other direction: dropping only the derived images does not quantize a second time
+    m.invalidate_packed(weight_changed=False)
+    assert m.w_is_quantized and torch.equal(m(xd), want)
+
+
 def test_bias_is_quantized_exactly_once(lq):
     from bench import OPT_Q, make_case
 
@@ -155,12 +191,24 @@ def test_shared_activation_groups_share_one_image_pool(lq):
         for mods, xd, ref in zip(groups, xs, alone):
             for m, a in zip(mods, ref):
                 assert close(a, m(xd))
-        pool = SharedActivation._pool[xs[0].device]
+        pkey = (xs[0].device, torch.cuda.current_stream(xs[0].device).cuda_stream)  # one pool per (device, stream)
+        pool = SharedActivation._pool[pkey]
         ptr = pool["xq"].data_ptr()
         # interleaved: g0.m0, g1.m0, g0.m1, g1.m1
         y00 = groups[0][0](xs[0]); y10 = groups[1][0](xs[1]); y01 = groups[0][1](xs[0]); y11 = groups[1][1](xs[1])
         assert close(alone[0][0], y00) and close(alone[1][0], y10) and close(alone[0][1], y01) and close(alone[1][1], y11)
-        assert SharedActivation._pool[xs[0].device]["xq"].data_ptr() == ptr  # still the one pool
+        assert SharedActivation._pool[pkey]["xq"].data_ptr() == ptr  # still the one pool
+        # a second stream gets its own images (two streams driving two groups must not race on one pool)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ys = [m(xs[0]) for m in groups[0]]
+        side.synchronize()
+        assert all(close(a, y) for a, y in zip(alone[0], ys))
+        assert (xs[0].device, side.cuda_stream) in SharedActivation._pool and len(SharedActivation._pool) >= 2
+        assert SharedActivation._pool[pkey]["xq"].data_ptr() == ptr
+    SharedActivation.release_pool()
+    assert not SharedActivation._pool
 
 
 @pytest.mark.parametrize("r,members,enabled", [(128, 3, False), (128, 2, True), (80, 3, True)])

@@ -551,7 +551,7 @@ def test_passthrough_packed_checkpoint_single_copy(ops, tmp_path):
     mod = mod.to(DEV).half()
     Kp, Np = 320, 512
     for native in (False, True):
-        mod.invalidate_packed()
+        mod.invalidate_packed(weight_changed=False)
         mod.a16_native = native
         y = mod(x.half().to(DEV))
         st = mod.packed_state()
