@@ -186,7 +186,6 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
     f32x16 t = acc[i];
     if constexpr (LOWRANK) {
       if constexpr (BOUT != 0) {
-        const int mb = g.bout.mbits;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           float amax;
@@ -199,13 +198,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
             amax = g.bout_amax[(int64_t)(m0 + i * 32 + l31) * g.bout_nblk + (n0 + wn * 32 + 16 * b) / g.bout_L];
           }
           const int e = block_exponent(amax, g.bout);  // amax = 0: every element takes the pass-through
+          float blk[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const float v = t[8 * b + k];
-            const float m = fminf(rintf(ldexpf(fabsf(v) + 1e-9f, mb - e)), g.bout.mmax);
-            const float q = copysignf(ldexpf(m, e - mb), v);
-            t[8 * b + k] = fabsf(v) <= 1e-8f ? v : q;
-          }
+          for (int k = 0; k < 8; ++k) blk[k] = t[8 * b + k];
+          mxint_requant_fast(blk, e, g.bout);  // two elements per packed fp32 instruction (common.h)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[8 * b + k] = blk[k];
         }
       }
     }
