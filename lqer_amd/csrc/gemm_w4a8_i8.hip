@@ -20,6 +20,11 @@
 //    MFMA from an LDS-staged xAq tile, in the summation order of the k_bout_amax pre-pass; 16-bit outputs are
 //    transposed through a per-wave LDS region so that every lane stores 16 bytes.
 //
+// Persistent tile loop: the grid is at most one workgroup per CU and a workgroup walks its tiles (virtual block id
+// blockIdx.x + i * gridDim.x through the XCD-aware tile map).  With one 64-column panel of xAq (padded rank x limbs <= 64)
+// the epilogue keeps out of ring slot 0, and the NEXT tile's first step is requested before the epilogue starts - its
+// latency passes under the conversion / side product / stores of the current tile.
+//
 // Tile, ring and wave structure are those of gemm_w4a8_m256.hip: 256(m) x 256(n) per workgroup, 8 waves side by side
 // along n, LDS-DMA into a 3-slot ring two steps ahead (one step = 128 k = 128 B per activation row, the same row
 // pitch and swizzle), LOAD / COMPUTE ping-pong between the two waves of a SIMD, half a step (4 token tiles) per phase.
@@ -184,26 +189,43 @@ __global__ __launch_bounds__(256) void k_i8_unpack(const uint8_t* __restrict__ i
 template <int DT, bool LOWRANK, int BOUT, bool SHIFT>
 __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
+  const int lane_k = threadIdx.x & 63;
+  const int wave_k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef LQER_CLOCKPROBE
   unsigned long long cp_c[4], cp_r[4], cp_e1 = 0, cp_e1r = 0, cp_e2 = 0, cp_e2r = 0;
   I8_STAMP(cp_c[0], cp_r[0]);
 #endif
 
   const int nt = g.tiles_m * g.tiles_n;
-  int tile;
-  {
-    const int b = blockIdx.x, xcd = b & 7, q8 = nt >> 3, r8 = nt & 7;
-    tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
-  }
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  // XCD-aware tile order of a virtual block id (blocks b, b + 8, ... share an XCD; the grid is a multiple of 8 or covers nt)
+  auto tile_of = [&](int b) {
+    const int xcd = b & 7, q8 = nt >> 3, r8 = nt & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  };
   const int Kp8 = g.Kp;  // (the int8 image's row stride)
   const int nk = Kp8 / I8_BK;
   const uint8_t* const xq8 = (const uint8_t*)g.xq;
+  int vb = blockIdx.x;
+  int tile = tile_of(vb);
+  int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  int m0 = tm * BM, n0 = tn * BN;
 
+  // with ONE 64-column panel of xAq the epilogue lives in ring slots 1 and 2 (stage: activation slot 1; output transposes:
+  // activation slot 2, waves 6 and 7 in weight slot 2), so that slot 0 can take the next tile's first step meanwhile
+  const bool one_panel = !LOWRANK || g.rp <= 64;  // (wave-uniform)
+  const int ep_stage = one_panel ? A_SLOT : EP_STAGE;
+  static_assert(2 * A_SLOT + 6 * EP_OUT_WAVE <= 3 * A_SLOT && 2 * EP_OUT_WAVE <= W_SLOT, "epilogue regions of the persistent loop");
+  float t_xs = 0.f, t_amax = 0.f;  // this lane's row constants of the tile whose tables are written next
+  bool first = true;
+
+  for (;;) {  // ---- tiles of this workgroup ----------------------------------------------------------------------------
+  // Per-lane constants are re-derived for every tile from laundered ids (an empty asm the optimiser cannot look through):
+  // kept in registers across the epilogue - which needs all 256 - they would be spilled to scratch.
+  int lane_l = lane_k, wave_l = wave_k;
+  asm volatile("" : "+v"(lane_l));
+  asm volatile("" : "+s"(wave_l));
+  const int lane = lane_l, wave = wave_l, tid = wave * 64 + lane;
+  const int l31 = lane & 31, lh = lane >> 5;
   // ---- staging addresses (per lane, fixed for the kernel) ------------------------------------------------------------
   // activations: wave w stages rows [32w, 32w+32) of the tile as 4 pieces of 8 rows x 128 B, chunk-swizzled on the source side
   int a_voff[4];
@@ -218,13 +240,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int w_voff0 = (2 * wave) * 1024 + lane * 16, w_voff1 = w_voff0 + 1024, s_voff = 256 * 64 + lane * 4;
   const uint8_t* const a_base = xq8 + (int64_t)m0 * Kp8;
   const uint8_t* const w_base = g.w8 + (size_t)tn * nk * I8_WBLOCK;
-  const unsigned long long a_base64 = (unsigned long long)a_base, w_base64 = (unsigned long long)w_base;
-  const u32x4 a_rs = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a_base64),
-                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a_base64 >> 32)) & 0xffffu, (uint32_t)(BM * Kp8),
-                      0x00020000u};
-  const u32x4 w_rs = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w_base64),
-                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w_base64 >> 32)) & 0xffffu,
-                      (uint32_t)(nk * I8_WBLOCK), 0x00020000u};
+  auto make_rs = [](const uint8_t* base, uint32_t range) {
+    const unsigned long long b64 = (unsigned long long)base;
+    return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64),
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) & 0xffffu, range, 0x00020000u};
+  };
+  const u32x4 a_rs = make_rs(a_base, (uint32_t)(BM * Kp8)), w_rs = make_rs(w_base, (uint32_t)(nk * I8_WBLOCK));
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
   const uint32_t m0_a = lds0 + OFF_A + wave * 32 * 128;    // + slot * A_SLOT + piece * 1024
   const uint32_t m0_w = lds0 + OFF_W + (2 * wave) * 1024;  // + slot * W_SLOT (+ 1024: second piece)
@@ -244,9 +265,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const uint32_t fs_addr = lds0 + OFF_W + 256 * 64 + rw;
 
   // one LDS-DMA batch = the operands of one step: 6 loads per wave (wave 0: 7)
-  auto issue_step = [&](int kt, int slot) {
-    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, BM * Kp8, 0x00020000);
-    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_base, 0, nk * I8_WBLOCK, 0x00020000);
+  auto issue_step = [&](const uint8_t* ab, const uint8_t* wb, int kt, int slot) {
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, BM * Kp8, 0x00020000);
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, nk * I8_WBLOCK, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + OFF_A + slot * A_SLOT + wave * 32 * 128 + i * 1024), 16,
@@ -259,29 +280,36 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + slot * W_SLOT + 256 * 64), 4, s_voff, kt * I8_WBLOCK,
                                                0, 0);
   };
-  // per-row constants of the epilogue: requested now, written to LDS (asm: invisible to hipcc's waitcnt pass, which would
+  // per-row constants of the epilogue: requested ahead, written to LDS (asm: invisible to hipcc's waitcnt pass, which would
   // drain the ring fill in front of a visible LDS store) once the ring fill has been issued
-  float t_xs = 0.f, t_amax = 0.f;
-  if (tid < 256) {
-    t_xs = g.xscale[m0 + tid];
-    if constexpr (LOWRANK && BOUT == 2) t_amax = g.bout_amax[(int64_t)(m0 + tid) * g.bout_nblk];
-  }
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) issue_step(d, d);  // (past the end of K: dropped by the buffer range check)
-  if (tid < 256) {
-    const uint32_t ta = lds0 + EP_TAB + 4 * tid;
-    asm volatile("ds_write_b32 %0, %1" ::"v"(ta), "v"(t_xs) : "memory");
-    if constexpr (LOWRANK && BOUT == 2) {
-      // both B_out scales as normal floats: mbits - e lies in [-121, 134] for an 8-bit exponent field; rows with
-      // e < mbits - 126 have |s| < 2^-119 <= 1e-8 everywhere (a zero row: e = -127), i.e. every element takes the
-      // pass-through whatever the scale - clamp, the result does not change
-      int up = g.bout.mbits - block_exponent(t_amax, g.bout);
-      up = up > 126 ? 126 : (up < -126 ? -126 : up);
-      asm volatile("ds_write_b32 %0, %1 offset:1024\n\tds_write_b32 %0, %2 offset:2048" ::"v"(ta),
-                   "v"((uint32_t)(127 + up) << 23), "v"((uint32_t)(127 - up) << 23)
-                   : "memory");
+  auto load_tables = [&](int m0_) {
+    if (tid < 256) {
+      t_xs = g.xscale[m0_ + tid];
+      if constexpr (LOWRANK && BOUT == 2) t_amax = g.bout_amax[(int64_t)(m0_ + tid) * g.bout_nblk];
     }
-  }
+  };
+  auto write_tables = [&]() {
+    if (tid < 256) {
+      const uint32_t ta = lds0 + EP_TAB + 4 * tid;
+      asm volatile("ds_write_b32 %0, %1" ::"v"(ta), "v"(t_xs) : "memory");
+      if constexpr (LOWRANK && BOUT == 2) {
+        // both B_out scales as normal floats: mbits - e lies in [-121, 134] for an 8-bit exponent field; rows with
+        // e < mbits - 126 have |s| < 2^-119 <= 1e-8 everywhere (a zero row: e = -127), i.e. every element takes the
+        // pass-through whatever the scale - clamp, the result does not change
+        int up = g.bout.mbits - block_exponent(t_amax, g.bout);
+        up = up > 126 ? 126 : (up < -126 ? -126 : up);
+        asm volatile("ds_write_b32 %0, %1 offset:1024\n\tds_write_b32 %0, %2 offset:2048" ::"v"(ta),
+                     "v"((uint32_t)(127 + up) << 23), "v"((uint32_t)(127 - up) << 23)
+                     : "memory");
+      }
+    }
+  };
+  // the tile's first two steps (past the end of K: dropped by the buffer range check).  A later tile's step 0 is already in
+  // slot 0 when the epilogue before it kept out of that slot (one panel of xAq); its row constants were requested there too
+  if (first) load_tables(m0);
+  if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
+  issue_step(a_base, w_base, 1, 1);
+  write_tables();
 
   i32x16 R[8];
 #pragma unroll
@@ -446,8 +474,29 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   }
   // every wave is past its last LDS read of the ring: the epilogue may overwrite it after one more barrier
   asm volatile("s_barrier" ::: "memory");
+  // the next tile of this workgroup: its first step goes into ring slot 0 NOW (one panel of xAq: the epilogue keeps out of
+  // slot 0), its row constants are requested; the second step follows when the epilogue has released slot 1
+  const int vb_next = vb + (int)gridDim.x;
+  const bool has_next = vb_next < nt;  // (workgroup-uniform)
+  int m0_next = 0, n0_next = 0, tn_next = 0;
+  if (has_next) {
+    const int tile_n = tile_of(vb_next);
+    const int tm_n = tile_n / g.tiles_n;
+    tn_next = tile_n - tm_n * g.tiles_n;
+    m0_next = tm_n * BM, n0_next = tn_next * BN;
+    if (one_panel) issue_step(xq8 + (int64_t)m0_next * Kp8, g.w8 + (size_t)tn_next * nk * I8_WBLOCK, 0, 0);
+    load_tables(m0_next);
+  }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------------
+  {  // (its own per-lane constants from freshly laundered ids: see the head of the tile loop)
+  int lane_e = lane_k, wave_e = wave_k;
+  asm volatile("" : "+v"(lane_e));
+  asm volatile("" : "+s"(wave_e));
+  const int lane = lane_e, wave = wave_e;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int ep_out = one_panel ? (wave < 6 ? 2 * A_SLOT + wave * EP_OUT_WAVE : OFF_W + 2 * W_SLOT + (wave - 6) * EP_OUT_WAVE)
+                               : EP_OUT + wave * EP_OUT_WAVE;
   // lane: output column n = n0 + 32 wave + (lane & 31); register j of tile i: token row m0 + 32 i + (j&3) + 8 (j>>2) + 4 lh.
   // Everything per row is tabulated in LDS once (row scale, B_out exponent differences), everything per column is a lane
   // constant; the side product's code is fully static per (limbs, slices) pair.
@@ -461,6 +510,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // 16-deep slice) pairs - rank 64 with fp16 A / B, rank 128 with 8-bit A / B -, else re-fetched from L2 for every token
   // tile.  Their latency passes under the conversion of the integer tile (below).
   bf16x8 sb[LOWRANK ? 8 : 1];
+#pragma unroll
+  for (int i = 0; i < (LOWRANK ? 8 : 1); ++i) sb[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};  // (defined on every path: not carried around the tile loop)
   const int nslices = LOWRANK ? g.rp / 16 : 0;  // 16-deep slices per limb
   const bf16_t* const bt_lane = LOWRANK ? g.bt + (int64_t)n * g.rp + 8 * lh : nullptr;  // + l * Np * rp + 16 ks
   const int64_t bt_limb = (int64_t)g.Np * g.rp;
@@ -473,7 +524,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + i * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + EP_STAGE + pn * 32768 + wave * 32 * 128 + i * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + ep_stage + pn * 32768 + wave * 32 * 128 + i * 1024), 16,
                                                  row * g.xaq_ld * 2 + chunk * 16, pn * 128, 0, 0);
       }
   }
@@ -528,6 +579,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
           const f2 v = __builtin_elementwise_fma(rf * (f2){xs[q][t], xs[q][t + 1]}, ws2, bv2);
           R[i][j] = __float_as_int(v[0]), R[i][j + 1] = __float_as_int(v[1]);
         }
+      // (pinned here: left to itself the optimiser sinks a tile's conversion to its use in the store phase and keeps the 16
+      // table registers of every tile alive until then - scratch spills inside the tile loop)
+      asm volatile("" : "+v"(R[i]));
     }
   }
 #ifdef LQER_CLOCKPROBE
@@ -545,7 +599,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // xAq fragment addresses: row l31 (+ 32 i: + 4096 B), chunk 2 (ks & 3) + lh, panel ks >> 2
   uint32_t xaddr[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) xaddr[c] = EP_STAGE + swz(l31, 2 * c + lh);
+  for (int c = 0; c < 4; ++c) xaddr[c] = ep_stage + swz(l31, 2 * c + lh);
   // the side product of token tile i: static code for the common (limbs, slices per limb) pairs
   auto side_static = [&](int i, auto nl_c, auto nsl_c) {
     constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value;
@@ -580,12 +634,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     for (int l = 0; l < g.b_limbs; ++l)  // (the same order: limb-major, slices ascending)
       for (int ks = 0; ks < nslices; ++ks) {
         const bf16x8 bf = *(const bf16x8*)(bt_lane + l * bt_limb + ks * 16);
-        const bf16x8 xf = *(const bf16x8*)(smem + EP_STAGE + (ks >> 2) * 32768 + swz(l31 + 32 * i, 2 * (ks & 3) + lh));
+        const bf16x8 xf = *(const bf16x8*)(smem + ep_stage + (ks >> 2) * 32768 + swz(l31 + 32 * i, 2 * (ks & 3) + lh));
         sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, bf, sp, 0, 0, 0);
       }
     return sp;
   };
-  unsigned char* const out_w = smem + EP_OUT + wave * EP_OUT_WAVE;
+  unsigned char* const out_w = smem + ep_out;
   const int nb = n0 + wave * 32;
   const bool wide = DT != LQER_F32 && (g.ldy & 7) == 0 && nb + 32 <= g.N && (((uintptr_t)g.y) & 15) == 0;  // wave-uniform
   // 16-byte stores of whole 8-column pieces through a buffer descriptor whose range ends with row M - 1: rows of the
@@ -670,6 +724,13 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       }
     }
   }
+  }  // epilogue
+  if (!has_next) break;
+  // every wave is done with the xAq stage, the row tables and its output region: the next tile may take them over
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  vb = vb_next, m0 = m0_next, n0 = n0_next, tn = tn_next;
+  first = false;
+  }  // tiles of this workgroup
 #ifdef LQER_CLOCKPROBE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   I8_STAMP(cp_c[3], cp_r[3]);
@@ -688,7 +749,10 @@ template <int DT>
 static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
-  const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n);
+  // persistent: at most one workgroup per CU (the LDS ring leaves room for one), each walks tiles b, b + grid, ...
+  constexpr int CUS = 256;
+  const int nt_all = g.tiles_m * g.tiles_n;
+  const unsigned grid = (unsigned)(nt_all < CUS ? nt_all : CUS);
 #define LQER_I8_LAUNCH(LR, BO)                                                                    \
   do {                                                                                            \
     if (g.i8_shift) {                                                                             \
