@@ -308,6 +308,10 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="capture G consecutive steps in one hipGraph and replay it steps/G times (launch-bound decode sizes; "
                          "G ~ the number of Linears a model pushes a token through)")
+    ap.add_argument("--rotate", type=int, default=None, metavar="R",
+                    help="decode workloads (M <= 64): walk R distinct copies of the packed operands round robin, so that the "
+                         "weight stream comes from HBM and not from the 256 MB Infinity Cache (default 48 = 451 MB of 4096 x 4096 "
+                         "images; 0 = one resident weight); the resident figure is reported beside it")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU, no kernel: the multi-rank host logic alone (launcher, partition, gloo broadcast / gather, "
                          "timed-region protocol, the JSON line) - value is null")
@@ -389,6 +393,20 @@ def main():
         mods.append((mod, xs[K], K, N, cnt * layers_here, y, wts))
     torch.cuda.synchronize()
 
+    # decode sizes: a model walks ~3.6 GB of DISTINCT weights per token, so one 9.4 MB image re-run from the Infinity Cache
+    # says little - R copies of the Linear (own packed images; same values, same output buffer) are walked round robin
+    rotate = args.rotate if args.rotate is not None else (48 if (M <= 64 and len(shapes) == 1 and layers == 1) else 0)
+    if rotate and not (M <= 64 and len(mods) == 1):
+        sys.exit("--rotate is for the single-Linear decode workloads")
+    rot_mods = list(mods)
+    if rotate > 1:
+        import copy
+
+        rot_mods += [(copy.deepcopy(mods[0][0]),) + mods[0][1:] for _ in range(rotate - 1)]
+        for m in rot_mods[1:]:
+            m[0](m[1])  # (its launch cache)
+        torch.cuda.synchronize()
+
     L = _lib.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
     gemm_events = []
@@ -400,7 +418,7 @@ def main():
     # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
     plans = []
     ws = ops.workspace(dev, max(ops.linear_sizes(mod._desc(), M).workspace for mod, *_ in mods))  # one buffer for all
-    for mod, xd, K, N, reps, y, _ in mods:
+    for mod, xd, K, N, reps, y, _ in rot_mods:
         desc = mod._desc()
         if mod._x_i8 and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) != _lib.ROUTE_TILE256_I8:
             desc = mod._desc(plain=True)  # token counts the int8 tile kernel does not serve: the bf16 kernels, same buffers
@@ -427,7 +445,7 @@ def main():
                           gscr=gscr, K=K, N=N, reps=reps, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16)))
 
     # M <= 8 with block_fp activations in blocks of 16: lqer_linear_forward issues ONE launch (not inside a captured graph)
-    one_launch = (M <= 8 and not args.graph and r > 0 and
+    one_launch = (M <= 8 and r > 0 and  # (capturable since round 3: the kernel's granule tag carries its dispatch id)
                   all(L.lqer_decode_partials(pl["dref"], M) and pl["a_limbs"] == 1 for pl in plans))
 
     # the C-ABI calls of a step with their arguments bound once per stream (the launch stream, or the capture stream of
@@ -454,8 +472,15 @@ def main():
             bound[st] = rows
         return bound[st]
 
+    rot_no = [0]
+    resident = [False]  # True: every step re-runs plan 0 (the weight stays in the Infinity Cache)
+
     def step(timed: bool, stream=stream):
-        for reps, K, N, fa, qa, ga in calls_for(stream):
+        rows = calls_for(stream)
+        if rotate > 1:
+            rows = rows[:1] if resident[0] else rows[rot_no[0] % rotate: rot_no[0] % rotate + 1]
+            rot_no[0] += 1
+        for reps, K, N, fa, qa, ga in rows:
             for _ in range(reps):
                 ev = timed and launch_no[0] % EV_EVERY == 0  # counts timed launches only: the first one is always sampled
                 if timed:
@@ -488,7 +513,13 @@ def main():
                     e1.record(stream)
                     gemm_events.append((e0, e1, K, N))
 
+    mrot_no = [0]
+
     def step_module():
+        if rotate > 1:
+            mod, xd = rot_mods[mrot_no[0] % rotate][:2]
+            mrot_no[0] += 1
+            return mod(xd)
         for mod, xd, K, N, reps, _, _ in mods:
             for _ in range(reps):
                 mod(xd)
@@ -546,6 +577,18 @@ def main():
         torch.cuda.synchronize()
     elapsed = sweep.max_over_ranks(elapsed_rank, dev)
 
+    # decode workloads: the same steps once more on ONE resident weight (what rounds 1-2 reported: an upper bound)
+    resident_fig = None
+    if rotate > 1 and graph is None:
+        rot_events, gemm_events = gemm_events, []
+        resident[0] = True
+        for _ in range(args.warmup):
+            step(False)
+        el_res = sweep.max_over_ranks(timed_region(run_abi, args.steps), dev)
+        resident[0] = False
+        res_events, gemm_events = gemm_events, rot_events
+        resident_fig = {"ms_per_step": round(el_res / args.steps * 1e3, 4), "events": res_events}
+
     # second timed region: the same K steps through the drop-in module (torch.empty, descriptor cache, ctypes marshalling
     # included) - the boundary the reference's callers use
     module = None
@@ -554,6 +597,20 @@ def main():
             step_module()
         el_mod = sweep.max_over_ranks(timed_region(lambda n: [step_module() for _ in range(n)], args.steps), dev)
         module = {"ms_per_step": round(el_mod / args.steps * 1e3, 4), "vs_c_abi": round(el_mod / elapsed, 4)}
+        if M <= 64 and graph is None:
+            # decode sizes are host-bound through the module (torch.empty + ctypes per call ~8 us on a ~8 us kernel): the way a
+            # serving loop runs them is ONE captured graph per token step - here G module forwards (one per rotated weight)
+            # captured by lqer_amd.graph.GraphedCallable and replayed; the one-launch decode route is capturable
+            from lqer_amd.graph import GraphedCallable
+
+            G = max(rotate, 1) * max(1, 48 // max(rotate, 1))
+            while args.steps % G:
+                G -= 1
+            gm = GraphedCallable(lambda: [step_module() for _ in range(G)][-1], warmup=2)
+            gm()
+            el_g = sweep.max_over_ranks(timed_region(lambda n: [gm() for _ in range(n // G)], args.steps), dev)
+            module.update(graph_ms_per_step=round(el_g / args.steps * 1e3, 4), graph_vs_c_abi=round(el_g / elapsed, 4),
+                          graph_forwards_per_replay=G)
 
     # third timed region (model workloads): the same Linears the way the model runs them - q/k/v and
     # gate/up receive ONE tensor, so its activation image and one side GEMM over the members' concatenated A are made once
@@ -679,7 +736,15 @@ def main():
             gbs = tot_by / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
-                        "traffic_source": traffic_source, "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch}
+                        "traffic_source": traffic_source, "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
+                        "weights_rotated": rotate if rotate > 1 else 1, "event_flags": hex(ev_flags)}
+            if resident_fig is not None:  # the same launches on ONE weight that stays in the Infinity Cache (an upper bound)
+                rms = sum(max(e0.elapsed_time(e1) - ev_overhead_ms, 1e-6) for e0, e1, _, _ in resident_fig["events"])
+                rn = max(len(resident_fig["events"]), 1)
+                rgbs = (tot_by / max(n_launch, 1)) * rn / (rms * 1e-3) / 1e9 if rms > 0 else 0.0
+                roofline["resident_weight"] = {"avg_launch_us": round(rms / rn * 1e3, 2), "achieved": round(rgbs, 1),
+                                               "frac": round(rgbs / HBM_PEAK_GBS, 4), "launches": rn,
+                                               "ms_per_step": resident_fig["ms_per_step"]}
         out = {
             "metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv",
             "value": round(value, 2),
@@ -694,7 +759,8 @@ def main():
             # the arithmetic type of the main loop's MFMA operands
             "dtype": "int8" if (M > 64 and int8) else ("f16" if mods[0][0]._x_f16 else "bf16"),
             "data": "synthetic",
-            "config": {"workload": desc_txt, "tokens_per_step": M, "rank": r,
+            "config": {"workload": desc_txt + (f" [{rotate} distinct packed weights walked round robin: {rotate * 9.4:.0f} MB > the 256 MB "
+                                                "Infinity Cache]" if rotate > 1 else ""), "tokens_per_step": M, "rank": r,
                        "formats": "x %s, W MXINT4/%s, A_out,B_out as x, y fp16" % (
                            "MXINT8/%s" % qc["x_quantizer"]["block_size"][-1] if qc["x_quantizer"]["name"] == "block_fp"
                            else ("fp16 pass-through (fp16 MFMA main loop)" if mods[0][0]._x_f16 else "fp16 pass-through (2 bf16 limbs)"),

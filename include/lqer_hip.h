@@ -183,9 +183,11 @@ int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype
  * pass-through or in blocks of 16 - lqer_decode_partials - and 16-byte aligned rows of x) lqer_linear_forward issues ONE
  * launch (csrc/decode1.hip): producer workgroups publish the split-K partial tiles of x A as {value, tag} granules in the
  * workspace, the weight-streaming workgroups quantize x themselves and read the tiles at their very end.  The tag is a
- * per-call value from a process-wide atomic counter - the library's only mutable state besides the thread-local error
- * text -, which is why a call under stream capture keeps the two-launch route (a replayed graph would carry the captured
- * tag).  The wait for the tiles is bounded; a workgroup that does not see them computes them itself (same bits). */
+ * per-LAUNCH value: a process-wide atomic call counter (the library's only mutable state besides the thread-local error
+ * text) mixed, inside the kernel, with the launch's AQL dispatch id and queue address - so the route is taken under stream
+ * capture as well: a replayed graph node carries the captured counter but gets a fresh dispatch id, and never accepts the
+ * previous replay's tiles.  The wait for the tiles is bounded; a workgroup that does not see them computes them itself
+ * (same bits). */
 
 /* test hook: poll sweeps of that wait before the fall-back (0 = every workgroup computes the tiles itself; < 0 = default) */
 int lqer_debug_set_decode_spin(int sweeps);

@@ -539,11 +539,9 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
     // up to 8 tokens: ONE launch (decode1.hip) - producer workgroups publish the partial tiles of x A, the weight-streaming
     // workgroups quantize x themselves and pick the tiles up at their very end
     const int esz = dtype == LQER_F32 ? 4 : 2;
-    // (not under stream capture: the granule tag is a per-call nonce, and a replayed graph would carry the captured one -
-    // a replay could then accept the previous replay's tiles; captured forwards keep the two-launch route)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cap);
-    if (cap == hipStreamCaptureStatusNone && M <= 8 && a_limbs == 1 && !x_is_f16(d) && ((uintptr_t)x & 15) == 0 &&
+    // (capturable: the kernel mixes its dispatch id into the granule tag, so a replayed graph node never accepts the
+    // previous replay's tiles although its arguments - the host's per-call counter among them - are frozen)
+    if (M <= 8 && a_limbs == 1 && !x_is_f16(d) && ((uintptr_t)x & 15) == 0 &&
         (ldx * esz) % 16 == 0 && b_limbs >= 1 && b_limbs <= 3) {
       GemmArgs g;
       memset(&g, 0, sizeof(g));

@@ -6,7 +6,7 @@
 // between them (11 us at M = 1 for 9.4 MB of weights).  Here one grid holds two kinds of workgroups:
 //   * producers (blocks 0 .. np-1, one per 256 k of K): quantize their slab of x, multiply it with the slab of A
 //     (v_mfma_f32_16x16x32_bf16: 4 waves x 2 k-slices, the waves' tiles summed in a fixed order) and publish the partial tile of x A as 8-byte
-//     {value, tag} granules - one write-through (sc1) store each, the tag is this call's nonce: no flag, no counter, nothing
+//     {value, tag} granules - one write-through (sc1) store each, the tag is this LAUNCH's nonce (host counter + dispatch id): no flag, no counter, nothing
 //     to reset (MI355X_MICROARCH.md, hand-off price list: data-tagged granules);
 //   * consumers (one per 16 output columns, as in gemm_smallm.hip): request their first weight panels, quantize ALL of x
 //     into an LDS image themselves (M x K <= 8 x 4096 elements: cheaper than waiting for another kernel), stream their
@@ -42,6 +42,7 @@ constexpr int RED_BYTES = (NW - 1) * 4 * 64 * 4;
 constexpr int XAQ_BYTES = MAXM * 64 * 2;
 constexpr int PSLAB_BYTES = MAXM * SLAB_K * 2;
 constexpr int PRED_BYTES = (NW - 1) * MAXNT * 4 * 64 * 4;
+constexpr int FLAG_BYTES = 16;  // the workgroup's "a granule was missing" vote: its own word behind everything else
 
 #ifndef LQER_D1_PREFETCH
 #define LQER_D1_PREFETCH 1  // where the first granule batch is requested: 0 after the combine, 1 at the end of the weight stream, 2 inside its last iteration
@@ -66,6 +67,11 @@ __device__ unsigned long long* g_d1_stamps = nullptr;  // diagnostic build: s_me
 #define D1_STAMP_AFTER(i, dep)
 #endif
 
+// llvm.amdgcn.dispatch.id: the position of this launch's AQL packet in its queue - the same value in every workgroup of a
+// launch, a new one for every launch, replayed hipGraph nodes included (clang has no builtin for it; the asm label binds
+// the intrinsic, and the kernel descriptor then requests the two system SGPRs)
+extern "C" __device__ unsigned long long lqer_dispatch_id() __asm("llvm.amdgcn.dispatch.id");
+
 struct Args {
   GemmArgs g;          // the consumer side: wp, bt, bias, y, ldy, M, N, Np, Kp, rp, b_limbs, aout, bout
   const void* x;       // [M, K] tokens, row stride ldx
@@ -74,7 +80,7 @@ struct Args {
   QP qx;
   const bf16_t* a_t;   // A^T bf16 image [rp][Kp] (one limb)
   uint32_t* gran;      // granules [np][MAXM][rp] x {value, tag}
-  uint32_t nonce;
+  uint32_t nonce;      // host part of the granule tag (a per-call counter); the kernel mixes in its dispatch id and queue
   int np;              // producers = ceil(Kp / 256)
   int spin;            // poll sweeps before a consumer computes the tiles itself
 };
@@ -184,6 +190,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int M = g.M, Kp = g.Kp, rp = g.rp;
+  // The granule tag of THIS launch: the host's per-call counter, the dispatch id (x odd constant: consecutive launches of one
+  // queue never share a tag; a replayed graph node gets a fresh one although its kernel arguments are frozen) and the queue's
+  // address (two queues that take turns on one workspace).  Scalar: the same in every lane and workgroup of the launch.
+  const uint32_t tag = (a.nonce + (uint32_t)lqer_dispatch_id() * 0x9E3779B1u) ^
+                       ((uint32_t)((unsigned long long)__builtin_amdgcn_queue_ptr() >> 6) * 0x85EBCA6Bu);
   const int xpitch = (Kp * 2 + 255) / 256 * 256;  // (the chunk XOR stays inside a 256-byte group)
   const int xs_bytes = M * xpitch;
   unsigned char* const xs = smem;
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   bf16_t* const xaq_l = (bf16_t*)(smem + xs_bytes + RED_BYTES);
   unsigned char* const pslab = smem + xs_bytes + RED_BYTES + XAQ_BYTES;
   float* const pred = (float*)(pslab + PSLAB_BYTES);
-  volatile uint32_t* const miss_flag = (volatile uint32_t*)(pred + 4 * 128 * 4);  // behind the [4][128] float4 group sums
+  volatile uint32_t* const miss_flag = (volatile uint32_t*)((unsigned char*)pred + PRED_BYTES);  // (not inside pred: produce() writes there)
   if (tid == 0) *miss_flag = 0u;  // (ordered before its use by the barriers below)
   const auto gran_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, a.np * MAXM * rp * 8, 0x00020000);
   const int nt16 = rp / 16;
@@ -262,7 +273,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
             float sum = acc[t][j];
 #pragma unroll
             for (int w2 = 0; w2 < PW - 1; ++w2) sum += pred[((w2 * MAXNT + t) * 4 + j) * 64 + lane];
-            const u32x2_t gv = {__float_as_uint(sum), a.nonce};
+            const u32x2_t gv = {__float_as_uint(sum), tag};
             __builtin_amdgcn_raw_buffer_store_b64(gv, gran_rsrc, (((p * MAXM + row) * rp) + 16 * t + l15) * 8, 0, 16);  // sc1
           }
         }
@@ -376,9 +387,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int p = p0 + 4 * u;
-      const int off = (it < items && p < a.np) ? (((p * MAXM + g_r) * rp) + 4 * g_c4) * 8 : 0x7ffffff0;  // (past the range: zeros)
-      b.v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);       // sc1: past this CU's L1
-      b.v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
+      const uint32_t off = (it < items && p < a.np) ? (uint32_t)((((p * MAXM + g_r) * rp) + 4 * g_c4) * 8) : 0x7ffffff0u;  // (past the range: zeros)
+      b.v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, (int)off, 0, 16);       // sc1: past this CU's L1
+      b.v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, (int)(off + 16u), 0, 16);
     }
   };
   GBatch gb;
@@ -437,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
         for (int p0 = pg; p0 < a.np; p0 += 16) {
           if (!(prefetched && p0 == pg)) gather_issue(p0, gb);
           auto tagged = [&](const u32x4_t& x0, const u32x4_t& x1) {
-            return x0[1] == a.nonce && x0[3] == a.nonce && x1[1] == a.nonce && x1[3] == a.nonce;
+            return x0[1] == tag && x0[3] == tag && x1[1] == tag && x1[3] == tag;
           };
           bool ok[4], all_ok = true;
 #pragma unroll
@@ -489,8 +500,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
       // a producer has not been seen: compute every partial tile here (same routine, same bits), then read them back
       for (int p = 0; p < a.np; ++p) produce(p);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) *miss_flag = 0u;  // the vote of the second gather starts clean (its first use is behind the barrier)
       __syncthreads();
       s = gather(64, complete, false);  // (written by this very workgroup: there after its own drain + barrier)
+      if (!complete) __builtin_trap();  // its own write-through stores not visible after vmcnt(0): never sum untagged bytes
     }
     D1_STAMP(7);
     // A_out in blocks of 16 = 4 consecutive threads
@@ -572,7 +585,7 @@ extern "C" int lqer_debug_set_decode_spin(int sweeps) {
 }
 
 size_t decode1_lds_bytes(int M, int64_t Kp) {
-  return (size_t)M * ((Kp * 2 + 255) / 256 * 256) + d1::RED_BYTES + d1::XAQ_BYTES + d1::PSLAB_BYTES + d1::PRED_BYTES;
+  return (size_t)M * ((Kp * 2 + 255) / 256 * 256) + d1::RED_BYTES + d1::XAQ_BYTES + d1::PSLAB_BYTES + d1::PRED_BYTES + d1::FLAG_BYTES;
 }
 
 size_t decode1_scratch_bytes(int64_t Kp, int rp) { return (size_t)((Kp + d1::SLAB_K - 1) / d1::SLAB_K) * d1::MAXM * rp * 8; }

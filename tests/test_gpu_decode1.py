@@ -1,7 +1,7 @@
 """The one-launch forward of decode sizes (csrc/decode1.hip, behind lqer_linear_forward for M <= 8; reference
 quantized_layers/linear.py:145-157): against the oracle, against the two-launch route it replaces, with the consumers'
 fall-back forced (every workgroup computes the partial tiles of x A itself), across calls that reuse the granule scratch,
-and under graph capture (which keeps the two-launch route).
+and under graph capture (the one-launch route is capturable: its granule tag carries the launch's dispatch id).
 Run on the GPU box:  python -m pytest tests -m gpu -x -q"""
 import ctypes as C
 
@@ -130,9 +130,12 @@ def test_granule_scratch_reused_across_calls_and_shapes(ops):
     assert want
 
 
-def test_captured_forward_keeps_the_two_launch_route(ops):
-    """A granule tag is a per-call nonce: a replayed graph would carry the captured one, so forwards issued under stream
-    capture take the two-launch route - replays with NEW inputs must follow the inputs."""
+def test_captured_forward_is_one_launch_and_replays_follow_their_inputs(ops):
+    """The granule tag mixes the launch's AQL dispatch id into the host's per-call counter, so the one-launch route is taken
+    under stream capture too: a replayed graph node carries frozen arguments but a fresh dispatch id.  Replays issued back to
+    back with NEW inputs (copied in on the same stream, no host synchronisation in between) must each follow their own
+    input bit for bit - a replay that accepted the previous replay's tiles of x A would show the previous input's side
+    product."""
     from bench import MXINT_Q
 
     mod, x, W, A, B, _ = _module(1024, 512, 32, False, MXINT_Q, torch.float16)
@@ -146,9 +149,41 @@ def test_captured_forward_keeps_the_two_launch_route(ops):
     torch.cuda.current_stream().wait_stream(s)
     with torch.cuda.graph(g):
         y = mod(xd)
-    for scale in (1.0, -0.5, 3.0):
-        xd.copy_((x[:4] * scale).half())
+        y2 = mod(y.repeat(1, 2).contiguous())  # a second Linear forward in the same graph, through the same workspace
+    scales = [1.0, -0.5, 3.0] + [0.1 * (i + 1) * (-1) ** i for i in range(40)]
+    inputs = [(x[:4] * sc).half().to(DEV) for sc in scales]
+    direct = []
+    for xi in inputs:  # the same two forwards outside any graph
+        yi = mod(xi)
+        direct.append((yi.clone(), mod(yi.repeat(1, 2).contiguous()).clone()))
+    got = []
+    for xi in inputs:
+        xd.copy_(xi)
         g.replay()
-        torch.cuda.synchronize()
-        ref = _ref((x[:4] * scale).half().float(), W, None, A, B, MXINT_Q, torch.float16)
-        assert float((y.float().cpu() - ref).norm() / ref.norm()) <= 1e-3, scale
+        got.append((y.clone(), y2.clone()))
+    torch.cuda.synchronize()
+    for i, ((a1, a2), (b1, b2)) in enumerate(zip(got, direct)):
+        assert torch.equal(a1, b1) and torch.equal(a2, b2), f"replay {i} (scale {scales[i]}) does not follow its input"
+    ref = _ref((x[:4] * scales[2]).half().float(), W, None, A, B, MXINT_Q, torch.float16)
+    assert float((got[2][0].float().cpu() - ref).norm() / ref.norm()) <= 1e-3
+
+
+def test_graphed_callable_runs_a_chain_of_module_forwards(ops):
+    """lqer_amd.graph.GraphedCallable: a chain of decode-size module forwards captured once and replayed with new inputs
+    equals the same chain run eagerly, bit for bit (one-launch route at M <= 8, two-launch route at M = 16)."""
+    from bench import MXINT_Q
+    from lqer_amd.graph import GraphedCallable
+
+    mod, x, W, A, B, _ = _module(1024, 1024, 32, False, MXINT_Q, torch.float16, M=16)
+    for M in (2, 16):
+        xs = x[:M].half().to(DEV).clone()
+        chain = lambda t: mod(mod(mod(t)))
+        gc = GraphedCallable(chain, xs, warmup=1)
+        for scale in (1.0, 0.37, -2.0):
+            xn = (x[:M] * scale).half().to(DEV)
+            want = chain(xn)
+            got = gc(xn).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (M, scale)
+    with pytest.raises(ValueError):
+        gc(xs[:1])
