@@ -60,9 +60,10 @@ extern "C" {
 #define LQER_Q_INT 4 /* "integer" (reference quantizers/integer.py:10-43): fixed point, clamp(rne(x 2^frac), lo, hi) / 2^frac with
                         lo, hi = -2^(width-1), 2^(width-1)-1 (signed) or 0, 2^width-1.  Fields: width; exp_bias = frac_width;
                         exp_width = is_signed (1 / 0); block is ignored.  Implemented for the x, b and A_out quantizers (width
-                        <= 9 signed / 8 unsigned, so that every value is a bf16 number) and in lqer_quantize_mxint; a 4-bit
-                        integer weight (codes -8..7) does not fit the sign-magnitude weight image and B_out needs the
-                        quantizer inside the fused kernels: both return LQER_E_UNSUPPORTED */
+                        <= 9 signed / 8 unsigned, so that every value is a bf16 number), for B_out (any width <= 24: applied to
+                        the fp32 side product inside the tile kernels' prologues - the reference's fall-back when x_quantizer is
+                        integer, linear.py:115-119; decode sizes then take the tile kernel) and in lqer_quantize_mxint; a 4-bit
+                        integer WEIGHT (codes -8..7) does not fit the sign-magnitude weight image: LQER_E_UNSUPPORTED */
 
 /* Geometry of the packed operands (fixed by the kernels; exported so callers can size buffers). */
 #define LQER_K_ALIGN 64     /* K is zero-padded to a multiple of this                        */

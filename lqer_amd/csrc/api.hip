@@ -41,10 +41,10 @@ static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
   }
   if (f->kind == LQER_Q_INT) {  // fixed point: exp_bias = frac_width, exp_width = is_signed
     const bool role_ok = !strcmp(name, "x_quantizer") || !strcmp(name, "b_quantizer") || !strcmp(name, "A_out_quantizer") ||
-                         !strcmp(name, "quantize_mxint");
+                         !strcmp(name, "B_out_quantizer") || !strcmp(name, "quantize_mxint");
     if (!role_ok) {
-      set_error("%s: the integer quantizer is implemented for x, b and A_out (a 4-bit integer weight has the code -8, which the "
-                "sign-magnitude weight image cannot hold; B_out is quantized inside the fused kernels, block_fp / passthrough only)", name);
+      set_error("%s: the integer quantizer is implemented for x, b, A_out and B_out (a 4-bit integer weight has the code -8, which "
+                "the sign-magnitude weight image cannot hold)", name);
       return false;
     }
     const int maxw = f->exp_width ? max_width : max_width - 1;  // unsigned: one magnitude bit more per width

@@ -206,9 +206,11 @@ __device__ __forceinline__ void mxint16_bf16_fast(const float (&v)[16], int e, c
   }
 }
 
-// In place: N (even) fp32 values that share the block exponent e -> their block_fp images (block_fp.py:55-65, 79-80), two per
-// packed fp32 instruction - the B_out re-quantization of the tile kernels' side product:
-//   q = sign(v) min(rne((|v| + 1e-9) 2^(mbits-e)), mmax) 2^(e-mbits);  |v| <= 1e-8 keeps v.
+// In place: N (even) fp32 values that share the block exponent e -> their quantizer images, two per packed fp32 instruction -
+// the B_out re-quantization of the tile kernels' side product.  block_fp (block_fp.py:55-65, 79-80):
+//   q = sign(v) min(rne((|v| + 1e-9) 2^(mbits-e)), mmax) 2^(e-mbits);  |v| <= 1e-8 keeps v;
+// integer (quantizers/integer.py:37-40; the QP carries eps = 0, tiny = -1, the two's-complement negative clamp, e = 0):
+//   q = clamp(rne(v 2^frac), lo, hi) 2^-frac.
 // Same arithmetic as mxint16_bf16_fast (fma on the signed value, 1.5 * 2^23 rounding, v_med3 clamp): the results of
 // mxint_mantissa + ldexpf element by element; exponents whose scale factors are not normal floats take that route.
 template <int N>
@@ -217,26 +219,25 @@ __device__ __forceinline__ void mxint_requant_fast(float (&v)[N], int e, const Q
   if (mxint16_fast_ok(e, q)) {
     const float s = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
     const float inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
-    const float es = 1e-9f * s, hi = q.mmax;
+    const float es = q.eps * s, hi = q.mmax, lo = -q.mneg, tiny = q.tiny;
     const f2 magic = {12582912.0f, 12582912.0f};
 #pragma unroll
     for (int i = 0; i < N; i += 2) {
       const f2 x = {v[i], v[i + 1]};
       const f2 c = {copysignf(es, x[0]), copysignf(es, x[1])};
       f2 r = (__builtin_elementwise_fma(x, (f2){s, s}, c) + magic) - magic;
-      r[0] = __builtin_amdgcn_fmed3f(r[0], -hi, hi);
-      r[1] = __builtin_amdgcn_fmed3f(r[1], -hi, hi);
+      r[0] = __builtin_amdgcn_fmed3f(r[0], lo, hi);
+      r[1] = __builtin_amdgcn_fmed3f(r[1], lo, hi);
       const f2 val = r * (f2){inv, inv};
       // (a negative v that rounds to zero: -0 here, copysign(0, v) = -0 in the element routine as well)
-      v[i] = fabsf(x[0]) <= 1e-8f ? x[0] : val[0];
-      v[i + 1] = fabsf(x[1]) <= 1e-8f ? x[1] : val[1];
+      v[i] = fabsf(x[0]) <= tiny ? x[0] : val[0];
+      v[i + 1] = fabsf(x[1]) <= tiny ? x[1] : val[1];
     }
   } else {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const float t = v[i];
-      const float m = fminf(rintf(ldexpf(fabsf(t) + 1e-9f, q.mbits - e)), q.mmax);
-      v[i] = fabsf(t) <= 1e-8f ? t : copysignf(ldexpf(m, e - q.mbits), t);
+      v[i] = fabsf(t) <= q.tiny ? t : ldexpf(mxint_mantissa(t, e, q), e - q.mbits);
     }
   }
 }

@@ -341,8 +341,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
             for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[i][8 * b + k]));
             amax = pair32_max(amax);
           } else {
-            // block of L columns (L a multiple of 16): its max was reduced by k_bout_amax
-            amax = g.bout_amax[(int64_t)(m0 + i * 32 + l31) * g.bout_nblk + (n0 + wn * 32 + 16 * b) / g.bout_L];
+            // block of L columns (L a multiple of 16): its max was reduced by k_bout_amax.  (No buffer: the integer
+            // quantizer - fixed point, its "exponent" is pinned to 0 by the QP's clamp whatever amax says)
+            amax = g.bout_amax ? g.bout_amax[(int64_t)(m0 + i * 32 + l31) * g.bout_nblk + (n0 + wn * 32 + 16 * b) / g.bout_L] : 1.0f;
           }
           const int e = block_exponent(amax, g.bout);  // amax = 0: every element takes the pass-through
           float blk[8];
@@ -748,6 +749,10 @@ static int bout_mode(const GemmArgs& g, bool lowrank, int* L_out) {
     if (L_out) *L_out = L;
     return 2;
   }
+  if (lowrank && g.bout.kind == LQER_Q_INT) {  // fixed point: elementwise, no block maxima - the "any block" code without its pre-pass
+    if (L_out) *L_out = 0;
+    return 2;
+  }
   if (lowrank && g.bout.kind != LQER_Q_PASSTHROUGH) {
     set_error("B_out_quantizer kind %d not implemented", g.bout.kind);
     return LQER_E_UNSUPPORTED;
@@ -760,7 +765,7 @@ int gemm_route(const GemmArgs& g, bool lowrank) {
   if (bout < 0) return bout;
   if (g.w8) {  // LQER_Q_MXINT_I8: the int8 kernel or nothing (the caller falls back to LQER_Q_MXINT on the same buffers)
     GemmArgs t = g;
-    if (bout == 2) {
+    if (bout == 2 && g.bout.kind == LQER_Q_MXINT) {
       const int L = (g.bout.block <= 0 || g.bout.block >= g.N) ? g.Np : g.bout.block;
       t.bout_nblk = (g.Np + L - 1) / L;
     }
@@ -778,7 +783,9 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   int L = 0;
   const int bout = bout_mode(g, lowrank, &L);
   if (bout < 0) return bout;
-  if (bout == 2) {
+  if (bout == 2 && g.bout.kind == LQER_Q_INT) {
+    g.bout_L = 16, g.bout_nblk = 0, g.bout_amax = nullptr;
+  } else if (bout == 2) {
       g.bout_L = L;
       g.bout_nblk = (g.Np + L - 1) / L;
       const size_t need = (size_t)lqer_padded_m(g.M) * g.bout_nblk * sizeof(float);

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_m256(GemmArgs g) {
             for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(t[8 * b + k]));
             amax = pair32_max(amax);
           } else {
-            amax = g.bout_amax[(int64_t)(m0 + i * 32 + l31) * g.bout_nblk + (n0 + wn * 32 + 16 * b) / g.bout_L];
+            amax = g.bout_amax ? g.bout_amax[(int64_t)(m0 + i * 32 + l31) * g.bout_nblk + (n0 + wn * 32 + 16 * b) / g.bout_L] : 1.0f;  // (null: integer B_out)
           }
           const int e = block_exponent(amax, g.bout);  // amax = 0: every element takes the pass-through
           float blk[8];

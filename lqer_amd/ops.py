@@ -66,11 +66,10 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
         return QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
     if name == "integer":
         # fixed point (reference quantizers/integer.py:10-43): clamp(rne(x 2^frac_width), lo, hi) / 2^frac_width
-        if role in ("w", "B_out"):
+        if role == "w":
             raise NotImplementedError(
-                f"the integer quantizer is not implemented for {role} on the HIP path: a 4-bit integer weight has the code -8, "
-                "which the sign-magnitude weight image cannot hold, and B_out is quantized inside the fused kernels "
-                "(block_fp / passthrough) - give B_out_quantizer explicitly when x_quantizer is integer")
+                "the integer quantizer is not implemented for the weight on the HIP path: a 4-bit integer weight has the code -8, "
+                "which the sign-magnitude weight image cannot hold (no template configuration uses a fixed-point weight)")
         signed = bool(cfg.get("is_signed", True))
         return QFmt(_lib.Q_INT, int(cfg["width"]), -1, 1 if signed else 0, int(cfg["frac_width"]))
     if name != "block_fp":

@@ -177,6 +177,11 @@ def main():
     a16row_q = dict(a16_q, w_quantizer=bfp_cfg(4, [1, -1], False))
     a16mix_q = dict(a16_q, B_out_quantizer=bfp_cfg(8, [1, 16], True))  # pass-through x and A_out, block_fp B_out
     abq = dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[16, 1], skip_first_dim=False)
+    # fixed-point ("integer", quantizers/integer.py:10-43) activations: A_out and B_out fall back to the x quantizer's config
+    # (linear.py:115-124), so the side product is re-quantized to the same 8-bit fixed-point grid twice (round 3)
+    intx_q = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=dict(name="integer", width=8, frac_width=4),
+                  w_quantizer=bfp_cfg(4, [1, 16], False), b_quantizer=dict(name="integer", width=8, frac_width=6))
+    intx5_q = dict(intx_q, x_quantizer=dict(name="integer", width=8, frac_width=5))  # saturating outlier channels
 
     cases = [
         # name, x shape, K, N, r, bias, q_config, A/B quantizer, act-scale
@@ -191,6 +196,8 @@ def main():
         ("a16", (9, 256), 256, 96, 64, False, a16_q, None, True),
         ("a16row", (2, 5, 176), 176, 64, 16, True, a16row_q, None, False),
         ("a16mix", (70, 128), 128, 160, 32, False, a16mix_q, None, False),
+        ("intx", (12, 192), 192, 112, 32, True, intx_q, abq, False),
+        ("intx70", (2, 35, 128), 128, 160, 16, False, intx5_q, None, True),
     ]
     f = {}
     for name, xs, K, N, r, has_b, qc, abc, use_s in cases:

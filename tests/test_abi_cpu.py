@@ -119,9 +119,9 @@ def test_make_qfmt_schema():
     fi = ops.make_qfmt(dict(name="integer", width=8, frac_width=4), "x")
     assert (fi.kind, fi.width, fi.exp_width, fi.exp_bias) == (_lib.Q_INT, 8, 1, 4)
     assert ops.make_qfmt(dict(name="integer", width=8, frac_width=6, is_signed=False), "b").exp_width == 0
-    for role in ("w", "B_out"):  # never a silent approximation: -8 does not fit the weight image, B_out lives in the fused kernels
-        with pytest.raises(NotImplementedError):
-            ops.make_qfmt(dict(name="integer", width=4, frac_width=2), role)
+    with pytest.raises(NotImplementedError):  # never a silent approximation: the code -8 does not fit the sign-magnitude weight image
+        ops.make_qfmt(dict(name="integer", width=4, frac_width=2), "w")
+    assert ops.make_qfmt(dict(name="integer", width=8, frac_width=4), "B_out").kind == _lib.Q_INT  # (round 3: inside the tile kernels)
     # the role decides how a one-entry block_size is right-aligned (quantizers/utils.py:42-67, :261-284): per row for
     # activations / weights with skip_first_dim = true (the quantizer's default) and for the 1-D bias; a 2-D tensor with
     # skip_first_dim = false reads [L] as tiles of ALL rows x L - not on the HIP path, and never silently per row

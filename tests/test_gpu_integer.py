@@ -72,7 +72,7 @@ def test_integer_activation_image(ops, golden_q):
 
 @pytest.mark.parametrize("M,K,N,r,bias", [(7, 96, 80, 16, True), (300, 512, 384, 32, True), (2048, 1024, 512, 32, False)])
 def test_forward_with_integer_quantizers_vs_oracle(ops, M, K, N, r, bias):
-    """x, bias and A_out through the integer quantizer (B_out given explicitly: block_fp), every kernel size class."""
+    """x, bias and A_out through the integer quantizer, B_out block_fp and (fall-back) integer, every kernel size class."""
     import lqer_amd
     from bench import _bfp, make_case
 
@@ -95,6 +95,45 @@ def test_forward_with_integer_quantizers_vs_oracle(ops, M, K, N, r, bias):
     assert err <= 1e-5, err
     if bias:  # like the reference, the bias parameter now holds the quantized values
         assert torch.equal(mod.bias.detach().cpu(), O.integer_quantize(b, 8, 6))
-    # the default B_out (= the x quantizer, linear.py:115-119) would be integer: refused at construction, never approximated
-    with pytest.raises(NotImplementedError):
-        lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config={k: v for k, v in qc.items() if k != "B_out_quantizer"}, l_config={"rank": r})
+    # the reference's fall-back (linear.py:115-124): no A_out / B_out entries -> both are the x quantizer, i.e. integer: the
+    # side product is re-quantized to the fixed-point grid inside the tile kernels' prologues (M <= 64 takes the tile kernel too)
+    qd = {k: v for k, v in qc.items() if k not in ("A_out_quantizer", "B_out_quantizer")}
+    mod2 = lqer_amd.LinearFlexibleLqer(K, N, bias=bias, q_config=qd, l_config={"rank": r})
+    mod2.load_state_dict(sd)
+    y2 = mod2.to(DEV)(x.to(DEV)).cpu()
+    ref2 = O.lqer_linear_forward(x, W, b, A, B, qd)
+    assert float((y2 - ref2).norm() / ref2.norm()) <= 1e-5
+    assert mod2._fmt["B_out"].kind == mod2._fmt["x"].kind  # integer, by fall-back
+    with pytest.raises(NotImplementedError):  # a fixed-point WEIGHT stays refused (the code -8), never approximated
+        lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=dict(qc, w_quantizer=dict(name="integer", width=4, frac_width=5)), l_config={"rank": r})
+
+
+@pytest.mark.parametrize("name", ["intx", "intx70"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_integer_fallback_forward_vs_reference_vectors(ops, golden_fwd, name, dtype):
+    """x_quantizer = integer with NO A_out / B_out entries (both fall back to it, reference linear.py:115-124): the module
+    against the reference's own outputs (tests/golden/make_golden.py cases intx / intx70), fp32 and fp16."""
+    import lqer_amd
+
+    g, cfgs = golden_fwd
+    t = lambda k: torch.from_numpy(g[f"{name}/{k}"])
+    qc = cfgs[name]
+    assert "B_out_quantizer" not in qc and qc["x_quantizer"]["name"] == "integer"
+    has_b = f"{name}/bias" in g.files
+    x, W, A, B = t("x"), t("W"), t("A"), t("B")
+    mod = lqer_amd.LinearFlexibleLqer(W.shape[1], W.shape[0], bias=has_b, q_config=qc, l_config={"rank": int(g[f"{name}/rank"][0])})
+    sd = {"weight": W, "A": A, "B": B}
+    if has_b:
+        sd["bias"] = t("bias")
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).to(dtype)
+    y = mod(x.to(DEV).to(dtype)).float().cpu()
+    if dtype == torch.float32:
+        ref = t("y")
+        assert float((y - ref).norm() / ref.norm()) <= 1e-5
+        assert torch.equal(mod.weight.detach().cpu(), t("wq"))
+    else:
+        h = lambda v: v.half().float()
+        ref = O.lqer_linear_forward(h(x), h(W), h(t("bias")) if has_b else None, h(A), h(B), qc)
+        assert float((y - ref).norm() / ref.norm()) <= 1e-3
+    assert y.shape == t("y").shape
