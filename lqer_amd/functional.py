@@ -5,8 +5,10 @@ opt_decoder.py:125,190):   product = matmul(x_quantizer(x), w_quantizer(y)).
 Blocks run along the last dim of each operand, which for y is NOT the contraction dim (llama-7b.toml:110-126).  With the
 templates' settings (block_fp, width <= 8, blocks of 16) the whole product is ONE fused HIP GEMM (lqer_matmul_q,
 csrc/matmul_q.hip): x is quantized in the GEMM's load path - read from HBM once, no quantized copy -, y through a small bf16
-image, bf16 MFMA with fp32 accumulation of exact products.  Other block lengths run the library's quantizer kernels on both
-operands and hand the two quantized images to torch.matmul / torch.bmm.  Quantizer settings outside what the kernels
+image, bf16 MFMA with fp32 accumulation of exact products; 4-D [bsz, heads, ..] operands are folded into one batch dim.  Other
+block lengths (no template uses them: the fused kernels keep one block of 16 per thread, so that block maxima need no
+cross-lane work) and operands whose leading dims broadcast run the library's quantizer kernels on both operands and hand the two
+quantized images to torch.matmul / torch.bmm - the same bits.  Quantizer settings outside what the kernels
 implement raise - there is no software fallback.
 """
 from __future__ import annotations
@@ -45,11 +47,18 @@ def _fused_fmt(cfg: dict):
     return fmt if fmt.block == 16 else None
 
 
+_MAX_GRID_Z = 65535  # the kernels put the batch on grid.z
+
+
 @torch.no_grad()
 def _matmul_fused(x: torch.Tensor, y: torch.Tensor, fx, fy) -> torch.Tensor:
-    """x [b, S1, K] @ y [b, K, S2] (or both 2-D) through lqer_matmul_q."""
+    """x [.., S1, K] @ y [.., K, S2] (equal leading dims, or both 2-D) through lqer_matmul_q.  Leading dims are folded into
+    one batch dim (the llama call sites hand over 4-D [bsz, heads, ...] operands, llama_decoder.py:263,294) - as a view
+    where the strides allow, e.g. the transposed view of K in Q K^T -, and batches beyond the grid limit go in chunks."""
+    lead = x.shape[:-2]
     squeeze = x.dim() == 2
-    x3, y3 = (x[None], y[None]) if squeeze else (x, y)
+    x3 = x[None] if squeeze else (x.flatten(0, -3) if x.dim() > 3 else x)
+    y3 = y[None] if squeeze else (y.flatten(0, -3) if y.dim() > 3 else y)
     b, S1, K = x3.shape
     S2 = y3.shape[2]
     if x3.stride(2) != 1 or x3.stride(1) < K:
@@ -58,14 +67,18 @@ def _matmul_fused(x: torch.Tensor, y: torch.Tensor, fx, fy) -> torch.Tensor:
         y3 = y3.contiguous()
     out = torch.empty(b, S1, S2, dtype=x.dtype, device=x.device)
     L = _lib.lib()
-    nws = L.lqer_matmul_q_workspace_bytes(b, K, S2)
     with torch.cuda.device(x.device):
-        ws = ops.workspace(x.device, max(nws, 16))
-        ys = y3.stride()
-        _lib.check(L.lqer_matmul_q(x3.data_ptr(), y3.data_ptr(), out.data_ptr(), ops.dtype_code(x3), b, S1, K, S2, x3.stride(0), x3.stride(1),
-                                   ys[0], ys[1], ys[2], C.byref(fx), C.byref(fy), ws.data_ptr(), ws.numel(), ops._stream(x.device)),
-                   "lqer_matmul_q")
-    return out[0] if squeeze else out
+        for b0 in range(0, b, _MAX_GRID_Z):
+            xb, yb, ob = x3[b0:b0 + _MAX_GRID_Z], y3[b0:b0 + _MAX_GRID_Z], out[b0:b0 + _MAX_GRID_Z]
+            nb = xb.shape[0]
+            nws = L.lqer_matmul_q_workspace_bytes(nb, K, S2)
+            ws = ops.workspace(x.device, max(nws, 16))
+            ys = yb.stride()
+            _lib.check(L.lqer_matmul_q(xb.data_ptr(), yb.data_ptr(), ob.data_ptr(), ops.dtype_code(x3), nb, S1, K, S2, xb.stride(0),
+                                       xb.stride(1), ys[0], ys[1], ys[2], C.byref(fx), C.byref(fy), ws.data_ptr(), ws.numel(),
+                                       ops._stream(x.device)),
+                       "lqer_matmul_q")
+    return out[0] if squeeze else out.reshape(*lead, S1, S2)
 
 
 def generic_matmul_flexible(x: torch.Tensor, y: torch.Tensor, q_config: dict, style: str = "matmul") -> torch.Tensor:
@@ -74,8 +87,9 @@ def generic_matmul_flexible(x: torch.Tensor, y: torch.Tensor, q_config: dict, st
     x_cfg = deepcopy(q_config.get("x_quantizer", q_config["default"]))
     w_cfg = deepcopy(q_config.get("w_quantizer", q_config["default"]))
     fx, fy = _fused_fmt(x_cfg), _fused_fmt(w_cfg)
-    if (fx is not None and fy is not None and x.dtype == y.dtype and x.dtype in ops._DT and x.dim() == y.dim() and x.dim() in (2, 3)
-            and x.shape[-1] == y.shape[-2] and (x.dim() == 2 or x.shape[0] == y.shape[0]) and x.numel() > 0 and y.numel() > 0):
+    if (fx is not None and fy is not None and x.dtype == y.dtype and x.dtype in ops._DT and x.dim() == y.dim() and x.dim() >= 2
+            and (style == "matmul" or x.dim() == 3)  # (torch.bmm takes 3-D operands only: anything else raises below, as there)
+            and x.shape[-1] == y.shape[-2] and x.shape[:-2] == y.shape[:-2] and x.numel() > 0 and y.numel() > 0):
         ops._need_gpu(x, y)
         return _matmul_fused(x, y, fx, fy)
     return matmul(_quantize(x, x_cfg), _quantize(y, w_cfg))

@@ -377,6 +377,42 @@ def test_fused_quantized_matmul_vs_oracle(ops, dtype, tol, bh, s1, s2, d):
     assert torch.equal(lqer_amd.matmul_flexible(q[0].to(DEV), kt[0], qc), out[0])
 
 
+def test_fused_quantized_matmul_takes_4d_operands_and_large_batches(ops, monkeypatch):
+    """The llama call sites hand matmul_flexible 4-D [bsz, heads, ..] operands (reference llama_decoder.py:263,294): they are
+    folded into one batch dim and run the fused kernel - same bits as head by head; a batch beyond the grid.z limit goes in
+    chunks (limit lowered here); broadcasting leading dims keep the two-step route."""
+    import json
+
+    import lqer_amd
+    from lqer_amd import functional
+
+    qc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matmul_config.json")))
+    g = torch.Generator().manual_seed(4)
+    bsz, h, s, d = 2, 3, 70, 64
+    q = torch.randn(bsz, h, s, d, generator=g).half().to(DEV)
+    k = torch.randn(bsz, h, s, d, generator=g).half().to(DEV)
+    v = torch.randn(bsz, h, s, d, generator=g).half().to(DEV)
+    calls = []
+    real = functional._matmul_fused
+    monkeypatch.setattr(functional, "_matmul_fused", lambda *a: (calls.append(a[0].shape), real(*a))[1])
+    s4 = lqer_amd.matmul_flexible(q, k.transpose(2, 3), qc)
+    o4 = lqer_amd.matmul_flexible(torch.softmax(s4.float(), -1).half(), v, qc)
+    assert len(calls) == 2 and s4.shape == (bsz, h, s, s) and o4.shape == (bsz, h, s, d)
+    s3 = lqer_amd.matmul_flexible(q.reshape(bsz * h, s, d), k.reshape(bsz * h, s, d).transpose(1, 2), qc)
+    assert torch.equal(s4.reshape(bsz * h, s, s), s3)
+    ref = O.matmul_flexible(q[1, 2].float().cpu(), k[1, 2].float().cpu().t(), qc)
+    assert float((s4[1, 2].float().cpu() - ref).norm() / ref.norm()) <= 1e-3
+    monkeypatch.setattr(functional, "_MAX_GRID_Z", 4)  # 6 heads -> chunks of 4 + 2
+    assert torch.equal(lqer_amd.matmul_flexible(q, k.transpose(2, 3), qc), s4)
+    # leading dims that broadcast ([1, h, ..] x [bsz, h, ..]): not the fused kernel, the same bits
+    n_before = len(calls)
+    sb = lqer_amd.matmul_flexible(q[:1], k.transpose(2, 3), qc)
+    assert len(calls) == n_before and sb.shape == s4.shape
+    assert float((sb[0].float() - s4[0].float()).norm() / s4[0].float().norm()) <= 1e-3  # (another GEMM's summation order)
+    with pytest.raises(RuntimeError):  # torch.bmm's own rule
+        lqer_amd.bmm_flexible(q, k.transpose(2, 3), qc)
+
+
 @pytest.mark.parametrize("M", [4, 300])
 def test_forward_captured_in_a_graph(ops, M):
     """include/lqer_hip.h: calls are stream-ordered, perform no host synchronisation and may be captured in a
