@@ -318,6 +318,10 @@ class _LinearBase(nn.Linear):
             if self.rank > 0:
                 p["a_t"], p["b_t"], p["a_limbs"], p["b_limbs"] = ops.pack_lowrank(self.A.data, self.B.data)
             self._packed = self._replicate(p)
+            if self._x_i8:
+                # the int8 route's buffer starts with the sign-magnitude image: keep a VIEW of it as the single copy instead of a
+                # second full 4.5-bit image for the module's lifetime (several GB on a 7B W4A8-INT model)
+                self._w_single = self._single_copy("w")
         self.w_is_quantized = True
         self._w_ver = (self.weight._version, None if self.bias is None else self.bias._version)
 
