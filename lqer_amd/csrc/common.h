@@ -407,6 +407,7 @@ struct GemmArgs {
   QP bout;
   int tiles_m, tiles_n;
   int tiles_m_rows;     // rows of a tile of the 128-row kernel family: 128, or 64 for token counts that leave its grid thin
+  int xcd_bm;           // > 0: an XCD's tiles form a block of xcd_bm token tiles x (tiles / 8 / xcd_bm) weight tiles (128-row kernel)
   float* bout_amax;     // [Mp][bout_nblk] row-block maxima of xAq @ B (B_out blocks other than 16), else null
   int bout_L, bout_nblk;
   // int8 route: xq holds the int8 activation image (+ row scales), w8 the two's-complement weight image

@@ -151,7 +151,14 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     const int b = blockIdx.x, xcd = b & 7, q8 = nt >> 3, r8 = nt & 7;
     tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   }
-  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  if (g.xcd_bm > 0) {
+    // XCD-local tile BLOCKS (the host checked divisibility): xcd_bm token tiles x nt / 8 / xcd_bm weight tiles per XCD, the XCDs
+    // as a (tiles_m / xcd_bm) x (rest) grid - the bytes an XCD pulls through its L2 become W / gn + x / gm instead of W + x / 8
+    const int b = blockIdx.x, xcd = b & 7, l = b >> 3;
+    const int bn = (nt >> 3) / g.xcd_bm, gm = g.tiles_m / g.xcd_bm;
+    tm = (xcd % gm) * g.xcd_bm + l % g.xcd_bm, tn = (xcd / gm) * bn + l / g.xcd_bm;
+  }
   const int m0 = tm * BMk, n0 = tn * BN;
   const int nk = g.Kp / BK;
 
@@ -728,6 +735,7 @@ extern "C" int lqer_debug_set_stamp_buffer(void* p) {
 }
 #endif
 
+static std::atomic<int> g_xcd_bm{0};  // experiment hook (lqer_debug_set_xcd_block): token tiles per XCD-local tile block, 0 = rows of tiles
 static std::atomic<int> g_tile_rows{0};  // test hook (lqer_debug_set_tile_rows): 0 = per launch, 128 = never 64-row tiles, 64 = always
 
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
@@ -836,6 +844,13 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
     }
   }
 #endif
+  {
+    const int bm = g_xcd_bm.load(std::memory_order_relaxed), nt = g.tiles_m * g.tiles_n;
+    g.xcd_bm = 0;
+    if (bm > 0 && nt % 8 == 0 && (nt / 8) % bm == 0 && g.tiles_m % bm == 0 && 8 % (g.tiles_m / bm) == 0 &&
+        g.tiles_n % (8 / (g.tiles_m / bm)) == 0 && (nt / 8) / bm == g.tiles_n / (8 / (g.tiles_m / bm)))
+      g.xcd_bm = bm;
+  }
   switch (dtype) {
     case LQER_F32: return launch_gemm<LQER_F32>(g, lowrank, bout, st);
     case LQER_F16: return g.x_f16 ? launch_gemm<LQER_F16X>(g, lowrank, bout, st) : launch_gemm<LQER_F16>(g, lowrank, bout, st);
@@ -843,6 +858,11 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   }
   set_error("unknown dtype %d", dtype);
   return LQER_E_INVALID;
+}
+
+extern "C" int lqer_debug_set_xcd_block(int bm) {
+  g_xcd_bm.store(bm > 0 ? bm : 0, std::memory_order_relaxed);
+  return 0;
 }
 
 extern "C" int lqer_debug_set_tile_rows(int rows) {

@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--bout", type=int, default=1, help="1: B_out MXINT8/16, 0: passthrough, 2: MXINT8, one block per row (pre-pass)")
+    ap.add_argument("--xcd-bm", type=int, nargs="*", default=[], help="also time every build with XCD-local tile blocks of this many "
+                    "token tiles (lqer_debug_set_xcd_block; 128-row kernel)")
     ap.add_argument("--blimbs", type=int, default=1, help="bf16 limbs of B (1: MXINT8 values, 2: fp16 values)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -53,12 +55,18 @@ def main():
     fb = {0: _lib.QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127), 1: f8, 2: _lib.QFmt(_lib.Q_MXINT, 8, -1, 8, 127)}[a.bout]
     desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, fb)
     libs = [(p, load(p)) for p in a.libs]
+    base = list(libs)
+    for bm in a.xcd_bm:
+        libs += [(f"{p} [xcd block {bm}]", L) for p, L in base if hasattr(L, "lqer_debug_set_xcd_block")]
+    bm_of = lambda p: int(p.rsplit("[xcd block ", 1)[1][:-1]) if p.endswith("]") and "[xcd block " in p else 0
     st = torch.cuda.current_stream().cuda_stream
 
     nscr = libs[0][1].lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
     scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
 
-    def run(L):
+    def run(L, bm=0):
+        if hasattr(L, "lqer_debug_set_xcd_block"):
+            L.lqer_debug_set_xcd_block(bm)
         rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr() if r else None,
                                 bt.data_ptr() if r else None, a.blimbs, None, y.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
@@ -66,14 +74,14 @@ def main():
     times = {p: [] for p, _ in libs}
     for p, L in libs:
         for _ in range(5):
-            run(L)
+            run(L, bm_of(p))
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for p, L in libs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                run(L)
+                run(L, bm_of(p))
             e1.record()
             torch.cuda.synchronize()
             times[p].append(e0.elapsed_time(e1) / a.iters * 1e3)
@@ -81,7 +89,7 @@ def main():
     for p, _ in libs:
         t = sorted(times[p])
         med, mn = t[len(t) // 2], t[0]
-        print(f"{os.path.basename(p):40s} median {med:8.2f} us  min {mn:8.2f} us   {fl / med / 1e6:8.1f} TFLOP/s (median)")
+        print(f"{os.path.basename(p):46s} median {med:8.2f} us  min {mn:8.2f} us   {fl / med / 1e6:8.1f} TFLOP/s (median)")
 
 
 if __name__ == "__main__":
