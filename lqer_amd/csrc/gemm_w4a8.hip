@@ -641,24 +641,32 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
   for (int u = 0; u < RG; ++u) cur[u] = 0.f;
   auto commit = [&]() {
 #pragma unroll
-    for (int u = 0; u < RG; ++u)
+    for (int u = 0; u < RG; ++u) {
+      const float m = pair32_max(cur[u]);  // lanes l and l ^ 32 hold the two column halves of the same token row
       if (lh == 0 && rowv[u] >= 0)
-        atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(cur[u]));
+        atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(m));
+    }
   };
+  // (counters of round 2: 10 vector instructions per MFMA - accumulator zeroing, 8 max + a lane swap per 16 columns - made this
+  // kernel VALU-bound at a third of its MFMA time.  Now: the first MFMA of a chain takes a literal zero accumulator, and a
+  // lane keeps ONE running maximum per row group - every register of its accumulator is the same token row - folded with
+  // v_max3_f32; the lane pair is combined once, at the commit.)
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int tn = t_begin; tn < t_end; ++tn) {
     f32x16 acc[RG];
-#pragma unroll
-    for (int u = 0; u < RG; ++u)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) acc[u][k] = 0.f;
     for (int l = 0; l < g.b_limbs; ++l) {
       const bf16_t* brow = g.bt + ((int64_t)l * g.Np + tn * 32 + l31) * g.rp + 8 * lh;
 #pragma unroll
       for (int ks = 0; ks < MAXKS; ++ks)
         if (ks < nks) {
           const bf16x8 bb = *(const bf16x8*)(brow + ks * 16);
+          if (l == 0 && ks == 0) {
 #pragma unroll
-          for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa[u][ks], acc[u], 0, 0, 0);
+            for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa[u][0], zero, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa[u][ks], acc[u], 0, 0, 0);
+          }
         }
     }
 #pragma unroll
@@ -672,10 +680,10 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
       }
 #pragma unroll
       for (int u = 0; u < RG; ++u) {
-        float amax = 0.f;
+        float m = cur[u];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(acc[u][8 * b + k]));
-        cur[u] = fmaxf(cur[u], pair32_max(amax));
+        for (int k = 0; k < 8; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[u][8 * b + k])), fabsf(acc[u][8 * b + k + 1]));  // v_max3_f32 |.|
+        cur[u] = m;
       }
     }
   }

@@ -7,10 +7,15 @@
 //                  the exact bf16 image the fused GEMM's prologue consumes.
 // A comes as exact bf16 limbs (pack.hip), x as the exact bf16 image of the activation quantizer, so every
 // product is exact in fp32; only the fp32 accumulation order differs from the reference's torch.matmul.
+#include <type_traits>
+
 #include "common.h"
 
 namespace lqer {
 
+#ifndef LQER_XA_PF2
+#define LQER_XA_PF2 1  // int8 activation image: loads two windows ahead (k_xa_partial)
+#endif
 constexpr int XA_ROWS = 32;       // token rows per wave
 constexpr int XA_MAX_TILES = 8;   // rp <= 256
 #ifndef LQER_XA_TARGET
@@ -99,7 +104,10 @@ __device__ __forceinline__ void i8x32_to_f16(const u32x4& lo, const u32x4& hi, b
   }
 }
 
-template <int NT, int RG, bool XF16 = false, bool AFPF = false, bool XI8 = false>
+// PF2 (XI8 with AFPF): the activation loads run TWO windows ahead (two named register stages, the loop unrolled by two) - at
+// M = 16384 a wave holds 64 rows x 64 bytes per window, 4 waves per CU: one window ahead leaves 16 KB per CU in flight and the
+// HBM latency, not the bandwidth, sets the pace (84 MB in 49 us = 1.7 TB/s).
+template <int NT, int RG, bool XF16 = false, bool AFPF = false, bool XI8 = false, bool PF2 = false>
 __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ xq, int64_t M, int64_t Kp, int64_t Kx,
                                                     const bf16_t* __restrict__ a_t, int a_limbs, int rp, XaPlan plan,
                                                     float* __restrict__ part) {
@@ -129,20 +137,26 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
       xrow[u] = xq + (row < M ? row : M - 1) * Kx + 32 * h;
   }
   // the next window's activation loads are issued before this window's MFMAs (the stream from HBM is the bound)
-  bf16x8 xn[RG][XI8 ? 2 : 4];  // XI8: the raw 32 bytes
-  auto load_x = [&](int64_t k0) {
+  constexpr int NST = PF2 ? 2 : 1;  // register stages of the activation prefetch
+  bf16x8 xn[NST][RG][XI8 ? 2 : 4];  // XI8: the raw 32 bytes
+  auto load_x = [&](int64_t k0, auto st_c) {
+    constexpr int ST = decltype(st_c)::value;
 #pragma unroll
     for (int u = 0; u < RG; ++u) {
       if constexpr (XI8) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xn[u][i] = *(const bf16x8*)((const uint8_t*)xrow[u] + k0 + 16 * i);
+        for (int i = 0; i < 2; ++i) xn[ST][u][i] = *(const bf16x8*)((const uint8_t*)xrow[u] + k0 + 16 * i);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xn[u][i] = *(const bf16x8*)(xrow[u] + k0 + 8 * i);
+        for (int i = 0; i < 4; ++i) xn[ST][u][i] = *(const bf16x8*)(xrow[u] + k0 + 8 * i);
       }
     }
   };
-  load_x(k_begin);
+  using std::integral_constant;
+  load_x(k_begin, integral_constant<int, 0>{});
+  if constexpr (PF2) {
+    if (k_begin + 64 < k_end) load_x(k_begin + 64, integral_constant<int, 1>{});
+  }
   // (limb, tile) fragment sets held one window ahead; the fp16 image of the int8 route is ONE limb: half the registers
   constexpr int LMAX = AFPF ? ((XF16 && XI8) ? 1 : 4 / NT) : 1;
   constexpr int PAIRS = AFPF ? LMAX * NT : 1;
@@ -166,20 +180,22 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
     }
   };
   load_af(k_begin);
-  for (int64_t k0 = k_begin; k0 < k_end; k0 += 64) {
+  // one 64-k window out of register stage ST; its stage is refilled NST windows ahead
+  auto window = [&](int64_t k0, auto st_c) {
+    constexpr int ST = decltype(st_c)::value;
     bf16x8 xf[RG][4];
 #pragma unroll
     for (int u = 0; u < RG; ++u) {
       if constexpr (XI8 && XF16) {
-        i8x32_to_f16(__builtin_bit_cast(u32x4, xn[u][0]), __builtin_bit_cast(u32x4, xn[u][1]), xf[u]);
+        i8x32_to_f16(__builtin_bit_cast(u32x4, xn[ST][u][0]), __builtin_bit_cast(u32x4, xn[ST][u][1]), xf[u]);
       } else if constexpr (XI8) {
-        i8x32_to_bf16(__builtin_bit_cast(u32x4, xn[u][0]), __builtin_bit_cast(u32x4, xn[u][1]), xf[u]);
+        i8x32_to_bf16(__builtin_bit_cast(u32x4, xn[ST][u][0]), __builtin_bit_cast(u32x4, xn[ST][u][1]), xf[u]);
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xf[u][i] = xn[u][i];
+        for (int i = 0; i < 4; ++i) xf[u][i] = xn[ST][u][i];
       }
     }
-    if (k0 + 64 < k_end) load_x(k0 + 64);
+    if (k0 + 64 * NST < k_end) load_x(k0 + 64 * NST, st_c);
     if constexpr (AFPF) {
       bf16x8 afc[PAIRS][4];
 #pragma unroll
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc[u][t] = mfma_32x32x16<XF16>(xf[u][i], afc[l * NT + t][i], acc[u][t]);
           }
-      continue;
+      return;
     }
     for (int l = 0; l < a_limbs; ++l) {
 #pragma unroll
@@ -218,6 +234,12 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
           for (int i = 0; i < 4; ++i) acc[u][t] = mfma_32x32x16<XF16>(xf[u][i], af[i], acc[u][t]);
       }
     }
+  };
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += 64 * NST) {
+    window(k0, integral_constant<int, 0>{});
+    if constexpr (PF2) {
+      if (k0 + 64 < k_end) window(k0 + 64, integral_constant<int, 1>{});
+    }
   }
   // D layout: col n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 h.  part[c][rg*32 + m][n]
 #pragma unroll
@@ -236,6 +258,137 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
     }
   }
 }
+
+// ---- int8 activation image x ONE fp16 image of A^T, operands staged through LDS (the W4A8 INT configurations at prefill sizes) ----
+// k_xa_partial reads both operands with one 16-byte load per lane and ROW: 32-64 different cache lines per wave instruction.
+// Counters (tools/r03_sidepmc.sh, C4): the texture addresser is busy for the kernel's whole duration, stalled on the L1 tag
+// lookups (TA_BUSY ~ 84 k of ~90 k cycles, TA_ADDR_STALLED_BY_TC 18.5 M summed) - 84 MB of activations move at 1.7-2.2 TB/s.
+// Here a workgroup (4 waves) owns 128 token rows x one K chunk and walks it in steps of 128 k: the step's activation tile
+// (128 rows x 128 B) and A^T slab (rp rows x 256 B) arrive by LDS-DMA in whole 128-byte lines, three slots, two steps ahead
+// (source-side XOR swizzles: fragment reads are conflict-free); wave w multiplies rows 32 w .. 32 w + 31 on the fp16 MFMA.
+// Same partial-tile layout as k_xa_partial (the reduce kernels do not change); the k order inside a step is permuted the same
+// way for both operands.
+namespace xal {
+constexpr int ROWS = 128, BK = 128;
+constexpr int X_SLOT = ROWS * BK;  // 16 KiB int8
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int NT>  // 32-column rank tiles: rp = 32 NT
+__global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restrict__ xq8, int64_t Kx, const bf16_t* __restrict__ a_f16,
+                                                        int64_t Kp, int row_groups, int nchunk, int steps_per_chunk, int steps_total,
+                                                        float* __restrict__ part) {
+  constexpr int RP = 32 * NT, A_SLOT = RP * BK * 2, SLOT = X_SLOT + A_SLOT, NA = 2 * NT;  // NA: A^T pieces per wave and step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x / nchunk, c = blockIdx.x - tile * nchunk;
+  const int s_begin = c * steps_per_chunk;
+  const int s_end = s_begin + steps_per_chunk < steps_total ? s_begin + steps_per_chunk : steps_total;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+  // staging: wave w brings rows 32 w .. 32 w + 31 of the activation tile (4 pieces of 8 rows x 128 B) and 4 NT rows-of-4 pieces of A^T
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(xq8 + (int64_t)tile * ROWS * Kx), 0, (int)(ROWS * Kx), 0x00020000);
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_f16, 0, (int)(RP * Kp * 2), 0x00020000);
+  int x_voff[4], a_voff[4];  // (NA entries used: an array sized by a template-dependent constant, captured by a lambda, makes hipcc's
+                             // HOST pass drop the kernel's stub without a diagnostic - gemm_w4a8.hip has the same note)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    x_voff[i] = row * (int)Kx + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = 4 * (wave * NA + i) + (lane >> 4);
+    a_voff[i] = row * (int)Kp * 2 + (((lane & 15) ^ (row & 15)) << 4);
+  }
+  auto issue = [&](int st) {  // (past the chunk's end: not issued - the slot is never read)
+    const int slot = st % 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + slot * SLOT + (wave * 4 + i) * 1024), 16, x_voff[i], st * BK, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + slot * SLOT + X_SLOT + (wave * NA + i) * 1024), 16, a_voff[i],
+                                               st * BK * 2, 0, 0);
+  };
+  // fragment addresses (slot 0): activation row 32 w + r31, 16-byte chunk 2 j + h; A^T row n = 32 t + r31, chunks 4 j + 2 h (+ 1)
+  const int xrow = wave * 32 + r31;
+  uint32_t xa[4], aa[2][4][2];  // (NT tiles used)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xa[j] = lds0 + xrow * 128 + (((2 * j + h) ^ ((xrow >> 1) & 7)) << 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int n = 32 * t + r31;
+        aa[t][j][u] = lds0 + X_SLOT + n * 256 + (((4 * j + 2 * h + u) ^ (n & 15)) << 4);
+      }
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  issue(s_begin);
+  if (s_begin + 1 < s_end) issue(s_begin + 1);
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const h2 bias = {(_Float16)-1152.0f, (_Float16)-1152.0f};
+  for (int st = s_begin; st < s_end; ++st) {
+    // own loads of step st landed (the batch of st + 1 may stay in flight), then everybody's
+    if (st + 1 < s_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");  // (also: every wave has finished its reads of step st - 1, whose slot is filled next)
+    if (st + 2 < s_end) issue(st + 2);
+    const uint32_t so = (uint32_t)((st % 3) * SLOT);
+    u32x4 xr[4];
+    bf16x8 ar[2][4][2];
+    // (asm: hipcc would put vmcnt(0) in front of LDS reads it can see while an LDS-DMA is in flight)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xr[j]) : "v"(xa[j] + so));
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(ar[t][j][u]) : "v"(aa[t][j][u] + so));
+    }
+    if constexpr (NT == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(ar[0][0][0]), "+v"(ar[0][0][1]), "+v"(ar[0][1][0]),
+                     "+v"(ar[0][1][1]), "+v"(ar[0][2][0]), "+v"(ar[0][2][1]), "+v"(ar[0][3][0]), "+v"(ar[0][3][1]), "+v"(ar[1][0][0]),
+                     "+v"(ar[1][0][1]), "+v"(ar[1][1][0]), "+v"(ar[1][1][1]), "+v"(ar[1][2][0]), "+v"(ar[1][2][1]), "+v"(ar[1][3][0]),
+                     "+v"(ar[1][3][1]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(ar[0][0][0]), "+v"(ar[0][0][1]), "+v"(ar[0][1][0]),
+                     "+v"(ar[0][1][1]), "+v"(ar[0][2][0]), "+v"(ar[0][2][1]), "+v"(ar[0][3][0]), "+v"(ar[0][3][1]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {  // bytes 8 u .. 8 u + 7 of the chunk -> 8 halves (i8x32_to_f16's arithmetic)
+        u32x4 f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const uint32_t tb = xr[j][2 * u + d] ^ 0x80808080u;
+          f[2 * d] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, tb, 0x04010400u)) + bias);
+          f[2 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, tb, 0x04030402u)) + bias);
+        }
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16<true>(xf, ar[t][j][u], acc[t]);
+      }
+  }
+  // D layout: col n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 h.  part[c][rg * 32 + m][n]
+  const int rg = tile * 4 + wave;
+  if (rg < row_groups) {
+    float* dst = part + ((int64_t)c * row_groups + rg) * XA_ROWS * RP;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * h) * RP + 32 * t + r31] = acc[t][e];
+  }
+}
+}  // namespace xal
 
 // Fixed-order sum over the chunks + A_out + bf16 store.  One lane per 4 consecutive rank entries; the G = L/4
 // lanes of a block (G a power of two <= 64, lanes of one wave) share their max through xor-shuffles.
@@ -612,8 +765,34 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
     set_error("lowrank_xa: scratch %zu B < %zu B", scratch_bytes, need);
     return LQER_E_WORKSPACE;
   }
-  // row groups per wave: two while RG x NT accumulator tiles + two activation windows fit the register file
   const int nt = (rp + 31) / 32;
+#ifndef LQER_XA_NO_LDS
+  bool staged = false;
+  XaPlan plan_l = plan;
+  if (a_f16 && (rp == 32 || rp == 64) && M >= 512 && Kx % xal::BK == 0) {
+    // the LDS-staged kernel: 128-row tiles x K chunks of whole 128-k steps (the int8 image is zero-padded to 128 k)
+    const int steps_total = (int)(Kx / xal::BK), tiles = (int)((M + xal::ROWS - 1) / xal::ROWS);
+    int nch = plan.nchunk < steps_total ? plan.nchunk : steps_total;
+    const int spc = (steps_total + nch - 1) / nch;
+    nch = (steps_total + spc - 1) / spc;
+    plan_l.nchunk = nch;
+    static LdsLimitOnce once1, once2;
+    if (rp == 32) {
+      once1.set((const void*)xal::k_xa_partial_lds<1>, 3 * (xal::X_SLOT + 32 * xal::BK * 2));
+      xal::k_xa_partial_lds<1><<<(unsigned)(tiles * nch), 256, 3 * (xal::X_SLOT + 32 * xal::BK * 2), st>>>(
+          (const uint8_t*)xq, Kx, a_t, Kp, plan.row_groups, nch, spc, steps_total, scratch);
+    } else {
+      once2.set((const void*)xal::k_xa_partial_lds<2>, 3 * (xal::X_SLOT + 64 * xal::BK * 2));
+      xal::k_xa_partial_lds<2><<<(unsigned)(tiles * nch), 256, 3 * (xal::X_SLOT + 64 * xal::BK * 2), st>>>(
+          (const uint8_t*)xq, Kx, a_t, Kp, plan.row_groups, nch, spc, steps_total, scratch);
+    }
+    staged = true;
+  }
+#else
+  const bool staged = false;
+  const XaPlan plan_l = plan;
+#endif
+  // row groups per wave: two while RG x NT accumulator tiles + two activation windows fit the register file
   const int rgw = nt <= 4 ? 2 : 1;
   const int wave_rows = (plan.row_groups + rgw - 1) / rgw;
   const unsigned grid = (unsigned)((wave_rows * plan.nchunk + 3) / 4);
@@ -623,9 +802,9 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
       if (x_f16)                                                                                             \
         k_xa_partial<NT, RG, true, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch);  \
       else if (a_f16)                                                                                        \
-        k_xa_partial<NT, RG, true, (NT <= 2), true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
+        k_xa_partial<NT, RG, true, (NT <= 2), true, LQER_XA_PF2 != 0><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
       else if (x_i8)                                                                                         \
-        k_xa_partial<NT, RG, false, (NT <= 2), true><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
+        k_xa_partial<NT, RG, false, (NT <= 2), true, LQER_XA_PF2 != 0><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
       else                                                                                                   \
         k_xa_partial<NT, RG, false, (NT <= 2)><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch); \
     } else if (x_f16)                                                                                        \
@@ -637,7 +816,7 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
     else                                                                                                     \
       k_xa_partial<NT, RG><<<grid, 256, 0, st>>>(xq, M, Kp, Kx, a_t, a_limbs, rp, plan, scratch);            \
     break;
-  switch (nt) {
+  if (!staged) switch (nt) {
     XA_CASE(1, 2) XA_CASE(2, 2) XA_CASE(3, 2) XA_CASE(4, 2) XA_CASE(5, 1) XA_CASE(6, 1) XA_CASE(7, 1) XA_CASE(8, 1)
   }
 #undef XA_CASE
@@ -646,25 +825,25 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
     const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
     const unsigned grid2 = (unsigned)((items + 255) / 256);
     if (xa_limbs == 2)
-      k_xa_reduce_limbs<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq, rowscale);
+      k_xa_reduce_limbs<2><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, xaq, rowscale);
     else
-      k_xa_reduce_limbs<3><<<grid2, 256, 0, st>>>(scratch, plan, rp, xaq, rowscale);
+      k_xa_reduce_limbs<3><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, xaq, rowscale);
   } else if (L % 4 == 0 && (G & (G - 1)) == 0 && G <= 64) {
     const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
     const unsigned grid2 = (unsigned)((items + 255) / 256);
     switch (G) {
-      case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
-      case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
-      case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
-      case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
-      case 16: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
-      case 32: k_xa_reduce4<32><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
-      default: k_xa_reduce4<64><<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale); break;
+      case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 16: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 32: k_xa_reduce4<32><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      default: k_xa_reduce4<64><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
     }
   } else {
     const int64_t total = (int64_t)plan.row_groups * XA_ROWS * (rp / L);
     const unsigned grid2 = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    k_xa_reduce_blk<<<grid2, 256, 0, st>>>(scratch, plan, rp, q, xaq, rowscale);
+    k_xa_reduce_blk<<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale);
   }
   return check_launch("lowrank_xa");
 }

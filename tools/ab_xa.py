@@ -2,6 +2,7 @@
 """A/B timing of lqer_quantize_act_xa (activation stage + side path x A) across library builds for the configurations
 that do not take the fused blocks-of-16 kernel.
 usage: python tools/ab_xa.py M K r cfg lib_a.so [lib_b.so ...]     cfg = int (8-bit per-token x, whole-row A_out) |
+       i8 (the same on the int8 route: int8 activation image, ONE fp16 image of A^T) |
        a16 (fp16 route, x is its own image) | opt (blocks of 16, rank > 64: unfused)"""
 import ctypes as C, os, sys
 import torch
@@ -16,12 +17,14 @@ w4 = _lib.QFmt(1, 4, 128, 8, 127)
 none = _lib.QFmt(0, 0, 0, 8, 127)
 if cfg == "int":
     fx = _lib.QFmt(1, 8, -1, 8, 127); desc = _lib.LinearDesc(K, N, r, 0, fx, w4, none, fx, fx); a_limbs = 2
+elif cfg == "i8":
+    fx = _lib.QFmt(1, 8, -1, 8, 127); desc = _lib.LinearDesc(K, N, r, 0, _lib.QFmt(3, 8, -1, 8, 127), w4, none, fx, fx); a_limbs = -1
 elif cfg == "a16":
     desc = _lib.LinearDesc(K, N, r, 0, _lib.QFmt(2, 11, 0, 8, 127), w4, none, _lib.QFmt(0, 16, 0, 8, 127), none); a_limbs = 1
 else:
     fx = _lib.QFmt(1, 8, 16, 8, 127); desc = _lib.LinearDesc(K, N, r, 0, fx, w4, none, fx, fx); a_limbs = 1
 rp = (r + 15) // 16 * 16
-at = (0.01 * torch.randn(3, rp, K)).to(torch.float16 if cfg == "a16" else torch.bfloat16).to(dev)
+at = (0.01 * torch.randn(3, rp, K)).to(torch.float16 if cfg in ("a16", "i8") else torch.bfloat16).to(dev)
 xq = x if cfg == "a16" else torch.empty(M, K, dtype=torch.bfloat16, device=dev)
 xaq = torch.empty(M, 3 * rp, dtype=torch.bfloat16, device=dev)
 libs = [(os.path.basename(p), load(p)) for p in sys.argv[5:]]
