@@ -606,12 +606,20 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 // prologue); the per-16-column maxima are folded into amax[m][n / L] with atomicMax on the fp32 bit pattern
 // (non-negative floats order like unsigned integers; max is order-independent, so the result is
 // reproducible).  The buffer is zeroed on the stream before this kernel.
-template <int RG>  // 32-row groups per wave: every B^T fragment feeds RG MFMAs (the B^T stream from L2 is the bound)
+// RG 32-row groups per wave (every B^T fragment feeds RG MFMAs), NKS 16-deep slices of the padded rank (exact: no per-slice branch).
+// Round 3: the kernel was a chain of load -> vmcnt(0) -> 4 MFMAs per slice (a branch per slice kept hipcc from batching the
+// loads; 228 registers: two waves per SIMD) - a third of its MFMA time.  Now a (column tile, limb) BATCH of NKS fragments is
+// requested one batch ahead of the MFMAs that consume it (two named register sets), the first MFMA of a tile takes a literal
+// zero accumulator, and a lane keeps one running maximum per row group (every register of its accumulator is the same token
+// row), folded with v_max3_f32; the lane pair is combined once, at the commit.
+#ifndef LQER_AMAX_WAVES
+#define LQER_AMAX_WAVES 2048
+#endif
+template <int RG, int NKS>
 __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, int seg_tiles) {
   // One wave = 32 RG token rows x a run of `seg_tiles` 32-column tiles: the rows' xAq fragments stay in registers, the
   // running maximum of the current B_out block stays in a register and is committed (one atomicMax per row) when
   // the run leaves the block - a handful of atomics per row instead of one per 16 columns.
-  constexpr int MAXKS = 16 / RG;  // rank <= 256 / RG
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t groups = ((g.M + 31) / 32 + RG - 1) / RG;
@@ -619,19 +627,16 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
   if (wid >= groups * nseg) return;
   const int tg = (int)(wid / nseg), sg = (int)(wid - (int64_t)tg * nseg);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int nks = g.rp / 16;
   const int Mp = (g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;  // rows of xaq / bout_amax that exist
-  bf16x8 xa[RG][MAXKS];
+  bf16x8 xa[RG][NKS];
   int rowv[RG];
 #pragma unroll
   for (int u = 0; u < RG; ++u) {
     const int row = (tg * RG + u) * 32 + l31;
     rowv[u] = row < Mp ? row : -1;
+    const int rc = row < Mp ? row : Mp - 1;  // (a clamped duplicate: computed, never committed)
 #pragma unroll
-    for (int ks = 0; ks < MAXKS; ++ks) {
-      xa[u][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (ks < nks && row < Mp) xa[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)row * g.xaq_ld + ks * 16 + 8 * lh);
-    }
+    for (int ks = 0; ks < NKS; ++ks) xa[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)rc * g.xaq_ld + ks * 16 + 8 * lh);
   }
   const int t_begin = sg * seg_tiles;
   const int t_end = t_begin + seg_tiles < tiles_n32 ? t_begin + seg_tiles : tiles_n32;
@@ -647,45 +652,59 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
         atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(m));
     }
   };
-  // (counters of round 2: 10 vector instructions per MFMA - accumulator zeroing, 8 max + a lane swap per 16 columns - made this
-  // kernel VALU-bound at a third of its MFMA time.  Now: the first MFMA of a chain takes a literal zero accumulator, and a
-  // lane keeps ONE running maximum per row group - every register of its accumulator is the same token row - folded with
-  // v_max3_f32; the lane pair is combined once, at the commit.)
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int tn = t_begin; tn < t_end; ++tn) {
-    f32x16 acc[RG];
-    for (int l = 0; l < g.b_limbs; ++l) {
-      const bf16_t* brow = g.bt + ((int64_t)l * g.Np + tn * 32 + l31) * g.rp + 8 * lh;
+  const int nb = (t_end - t_begin) * g.b_limbs;  // batches: (tile, limb), limb fastest - the GEMM kernels' summation order
+  const int64_t limb_stride = (int64_t)g.Np * g.rp;
+  const bf16_t* const b_lane = g.bt + (int64_t)l31 * g.rp + 8 * lh;
+  bf16x8 ba[NKS], bb[NKS];
+  auto load = [&](int i, bf16x8 (&dst)[NKS]) {  // batch i (past the end: the last one again - never used)
+    const int ii = i < nb ? i : nb - 1;
+    const int tn = t_begin + ii / g.b_limbs, l = ii - (ii / g.b_limbs) * g.b_limbs;
+    const bf16_t* p = b_lane + l * limb_stride + (int64_t)tn * 32 * g.rp;
 #pragma unroll
-      for (int ks = 0; ks < MAXKS; ++ks)
-        if (ks < nks) {
-          const bf16x8 bb = *(const bf16x8*)(brow + ks * 16);
-          if (l == 0 && ks == 0) {
+    for (int ks = 0; ks < NKS; ++ks) dst[ks] = *(const bf16x8*)(p + ks * 16);
+  };
+  f32x16 acc[RG];
+  int tn = t_begin, l = 0;
+  auto consume = [&](const bf16x8 (&src)[NKS]) {
 #pragma unroll
-            for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa[u][0], zero, 0, 0, 0);
-          } else {
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (l == 0 && ks == 0) {
 #pragma unroll
-            for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, xa[u][ks], acc[u], 0, 0, 0);
-          }
+        for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(src[0], xa[u][0], zero, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(src[ks], xa[u][ks], acc[u], 0, 0, 0);
+      }
+    }
+    if (++l == g.b_limbs) {  // the tile's product is complete: fold it into the running maxima
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int blk = (tn * 32 + 16 * b) / g.bout_L;  // wave-uniform
+        if (blk != cur_blk) {
+          commit();
+          cur_blk = blk;
+#pragma unroll
+          for (int u = 0; u < RG; ++u) cur[u] = 0.f;
         }
-    }
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int blk = (tn * 32 + 16 * b) / g.bout_L;  // wave-uniform
-      if (blk != cur_blk) {
-        commit();
-        cur_blk = blk;
+        for (int u = 0; u < RG; ++u) {
+          float m = cur[u];
 #pragma unroll
-        for (int u = 0; u < RG; ++u) cur[u] = 0.f;
+          for (int k = 0; k < 8; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[u][8 * b + k])), fabsf(acc[u][8 * b + k + 1]));  // v_max3_f32 |.|
+          cur[u] = m;
+        }
       }
-#pragma unroll
-      for (int u = 0; u < RG; ++u) {
-        float m = cur[u];
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[u][8 * b + k])), fabsf(acc[u][8 * b + k + 1]));  // v_max3_f32 |.|
-        cur[u] = m;
-      }
+      l = 0, ++tn;
     }
+  };
+  if (nb > 0) load(0, ba);
+  for (int i = 0; i < nb; i += 2) {
+    load(i + 1, bb);
+    consume(ba);
+    if (i + 1 >= nb) break;
+    load(i + 2, ba);
+    consume(bb);
   }
   commit();
 }
@@ -812,19 +831,36 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
       g.bout_amax = (float*)scratch;
       (void)hipMemsetAsync(scratch, 0, need, st);
       const int tiles_n32 = g.Np / 32;
+      // padded rank (x limbs of x A) -> 16-deep slices (a template parameter: exact, no per-slice branch) and row groups per wave
+      const int nks = g.rp / 16;
       const int RG = g.rp <= 64 ? 4 : (g.rp <= 128 ? 2 : 1);
       const int64_t groups = ((g.M + 31) / 32 + RG - 1) / RG;
-      int nseg = (int)(4096 / groups);  // about 16 waves per CU in total
+      int nseg = (int)(LQER_AMAX_WAVES / groups);  // one round of two waves per SIMD (the kernel holds 184-256 registers)
       nseg = nseg < 1 ? 1 : (nseg > tiles_n32 ? tiles_n32 : nseg);
       const int seg_tiles = (tiles_n32 + nseg - 1) / nseg;
       const int64_t waves = groups * ((tiles_n32 + seg_tiles - 1) / seg_tiles);
       const unsigned grid = (unsigned)((waves + 3) / 4);
-      if (RG == 4)
-        k_bout_amax<4><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
-      else if (RG == 2)
-        k_bout_amax<2><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
-      else
-        k_bout_amax<1><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles);
+#define LQER_AMAX(RGv, NKSv) k_bout_amax<RGv, NKSv><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles)
+      switch (nks) {
+        case 1: LQER_AMAX(4, 1); break;
+        case 2: LQER_AMAX(4, 2); break;
+        case 3: LQER_AMAX(4, 3); break;
+        case 4: LQER_AMAX(4, 4); break;
+        case 5: LQER_AMAX(2, 5); break;
+        case 6: LQER_AMAX(2, 6); break;
+        case 7: LQER_AMAX(2, 7); break;
+        case 8: LQER_AMAX(2, 8); break;
+        case 9: LQER_AMAX(1, 9); break;
+        case 10: LQER_AMAX(1, 10); break;
+        case 11: LQER_AMAX(1, 11); break;
+        case 12: LQER_AMAX(1, 12); break;
+        case 13: LQER_AMAX(1, 13); break;
+        case 14: LQER_AMAX(1, 14); break;
+        case 15: LQER_AMAX(1, 15); break;
+        case 16: LQER_AMAX(1, 16); break;
+        default: set_error("B_out pre-pass: padded rank %d x limbs > 256", g.rp); return LQER_E_UNSUPPORTED;
+      }
+#undef LQER_AMAX
   }
   if (g.w8) {  // LQER_Q_MXINT_I8: xq is the int8 image - only the int8 kernel can read it
     if (!i8_eligible(g, bout)) {
