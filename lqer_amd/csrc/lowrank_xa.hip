@@ -16,6 +16,9 @@ namespace lqer {
 #ifndef LQER_XA_PF2
 #define LQER_XA_PF2 1  // int8 activation image: loads two windows ahead (k_xa_partial)
 #endif
+#ifndef LQER_XAL_WGS
+#define LQER_XAL_WGS 256  // workgroups the LDS-staged side GEMM aims for (128-row tiles x K chunks): one per CU - 512 measured 10-25 % slower
+#endif
 constexpr int XA_ROWS = 32;       // token rows per wave
 constexpr int XA_MAX_TILES = 8;   // rp <= 256
 #ifndef LQER_XA_TARGET
@@ -259,25 +262,35 @@ __global__ __launch_bounds__(256) void k_xa_partial(const bf16_t* __restrict__ x
   }
 }
 
-// ---- int8 activation image x ONE fp16 image of A^T, operands staged through LDS (the W4A8 INT configurations at prefill sizes) ----
+// ---- side GEMM with both operands staged through LDS (prefill sizes) ---------------------------------------------------------
 // k_xa_partial reads both operands with one 16-byte load per lane and ROW: 32-64 different cache lines per wave instruction.
 // Counters (tools/r03_sidepmc.sh, C4): the texture addresser is busy for the kernel's whole duration, stalled on the L1 tag
 // lookups (TA_BUSY ~ 84 k of ~90 k cycles, TA_ADDR_STALLED_BY_TC 18.5 M summed) - 84 MB of activations move at 1.7-2.2 TB/s.
-// Here a workgroup (4 waves) owns 128 token rows x one K chunk and walks it in steps of 128 k: the step's activation tile
-// (128 rows x 128 B) and A^T slab (rp rows x 256 B) arrive by LDS-DMA in whole 128-byte lines, three slots, two steps ahead
-// (source-side XOR swizzles: fragment reads are conflict-free); wave w multiplies rows 32 w .. 32 w + 31 on the fp16 MFMA.
+// Here a workgroup (4 waves) owns 128 token rows x one K chunk and walks it in steps of 128 BYTES of activation row: the
+// step's activation tile (128 rows x 128 B) and A^T slab arrive by LDS-DMA in whole 128-byte lines, three slots, two steps
+// ahead (source-side XOR swizzles: fragment reads are conflict-free); wave w multiplies rows 32 w .. 32 w + 31.  Two operand
+// formats:
+//   I8  (the W4A8 INT configurations): int8 mantissas (128 k per step) x ONE fp16 image of A^T (256 B per rank row and step),
+//       v_mfma_f32_32x32x16_f16 after the byte -> half conversion of k_xa_partial;
+//   B16 (block_fp activations, rank > 64 - the OPT configurations): the bf16 activation image (64 k per step) x one bf16
+//       limb of A^T (128 B per rank row and step), v_mfma_f32_32x32x16_bf16.
 // Same partial-tile layout as k_xa_partial (the reduce kernels do not change); the k order inside a step is permuted the same
 // way for both operands.
 namespace xal {
-constexpr int ROWS = 128, BK = 128;
-constexpr int X_SLOT = ROWS * BK;  // 16 KiB int8
+constexpr int ROWS = 128, BKB = 128;  // token rows per workgroup, activation bytes per row and step
+constexpr int X_SLOT = ROWS * BKB;    // 16 KiB
 typedef __attribute__((address_space(3))) void lds_void;
+constexpr int a_row_bytes(bool i8) { return i8 ? 256 : 128; }
+constexpr int lds_bytes(int nt, bool i8) { return 3 * (X_SLOT + 32 * nt * a_row_bytes(i8)); }
 
-template <int NT>  // 32-column rank tiles: rp = 32 NT
-__global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restrict__ xq8, int64_t Kx, const bf16_t* __restrict__ a_f16,
+template <int NT, bool I8>  // 32-column rank tiles: rp = 32 NT
+__global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restrict__ xq, int64_t x_ld, const bf16_t* __restrict__ a_img,
                                                         int64_t Kp, int row_groups, int nchunk, int steps_per_chunk, int steps_total,
                                                         float* __restrict__ part) {
-  constexpr int RP = 32 * NT, A_SLOT = RP * BK * 2, SLOT = X_SLOT + A_SLOT, NA = 2 * NT;  // NA: A^T pieces per wave and step
+  constexpr int RP = 32 * NT, AROW = a_row_bytes(I8), A_SLOT = RP * AROW, SLOT = X_SLOT + A_SLOT;
+  constexpr int APR = 1024 / AROW;        // A^T rows per 1-KiB piece (4 or 8)
+  constexpr int NA = RP / APR / 4;        // A^T pieces per wave and step
+  constexpr int ACH = AROW / 16;          // 16-byte chunks per A^T row and step (16 or 8)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -286,45 +299,58 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
   const int s_begin = c * steps_per_chunk;
   const int s_end = s_begin + steps_per_chunk < steps_total ? s_begin + steps_per_chunk : steps_total;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  // staging: wave w brings rows 32 w .. 32 w + 31 of the activation tile (4 pieces of 8 rows x 128 B) and 4 NT rows-of-4 pieces of A^T
-  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(xq8 + (int64_t)tile * ROWS * Kx), 0, (int)(ROWS * Kx), 0x00020000);
-  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_f16, 0, (int)(RP * Kp * 2), 0x00020000);
+  // staging: wave w brings rows 32 w .. 32 w + 31 of the activation tile (4 pieces of 8 rows x 128 B) and NA pieces of A^T
+  // (x_ld: bytes per activation row)
+  const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(xq + (int64_t)tile * ROWS * x_ld), 0, (int)(ROWS * x_ld), 0x00020000);
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_img, 0, (int)(RP * Kp * 2), 0x00020000);
   int x_voff[4], a_voff[4];  // (NA entries used: an array sized by a template-dependent constant, captured by a lambda, makes hipcc's
                              // HOST pass drop the kernel's stub without a diagnostic - gemm_w4a8.hip has the same note)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + (lane >> 3);
-    x_voff[i] = row * (int)Kx + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    x_voff[i] = row * (int)x_ld + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    a_voff[i] = 0;
   }
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = 4 * (wave * NA + i) + (lane >> 4);
-    a_voff[i] = row * (int)Kp * 2 + (((lane & 15) ^ (row & 15)) << 4);
+    if constexpr (I8) {  // 4 rows x 256 B per piece, 16 chunks per row
+      const int row = 4 * (wave * NA + i) + (lane >> 4);
+      a_voff[i] = row * (int)Kp * 2 + (((lane & 15) ^ (row & 15)) << 4);
+    } else {             // 8 rows x 128 B per piece: the activation tile's swizzle
+      const int row = 8 * (wave * NA + i) + (lane >> 3);
+      a_voff[i] = row * (int)Kp * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
   }
-  auto issue = [&](int st) {  // (past the chunk's end: not issued - the slot is never read)
+  auto issue = [&](int st) {
     const int slot = st % 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + slot * SLOT + (wave * 4 + i) * 1024), 16, x_voff[i], st * BK, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + slot * SLOT + (wave * 4 + i) * 1024), 16, x_voff[i], st * BKB, 0, 0);
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + slot * SLOT + X_SLOT + (wave * NA + i) * 1024), 16, a_voff[i],
-                                               st * BK * 2, 0, 0);
+                                               st * AROW, 0, 0);
   };
-  // fragment addresses (slot 0): activation row 32 w + r31, 16-byte chunk 2 j + h; A^T row n = 32 t + r31, chunks 4 j + 2 h (+ 1)
+  // fragment addresses (slot 0): activation row 32 w + r31, 16-byte chunk 2 j + h; A^T row n = 32 t + r31: I8 chunks 4 j + 2 h (+ 1),
+  // B16 chunk 2 j + h
   const int xrow = wave * 32 + r31;
-  uint32_t xa[4], aa[2][4][2];  // (NT tiles used)
+  uint32_t xa[4], aa[4][4][2];  // (NT tiles, I8: two reads per (tile, j))
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     xa[j] = lds0 + xrow * 128 + (((2 * j + h) ^ ((xrow >> 1) & 7)) << 4);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      const int n = 32 * t + r31;
+      if constexpr (I8) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int n = 32 * t + r31;
-        aa[t][j][u] = lds0 + X_SLOT + n * 256 + (((4 * j + 2 * h + u) ^ (n & 15)) << 4);
+        for (int u = 0; u < 2; ++u) aa[t][j][u] = lds0 + X_SLOT + n * 256 + (((4 * j + 2 * h + u) ^ (n & 15)) << 4);
+      } else {
+        aa[t][j][0] = lds0 + X_SLOT + n * 128 + (((2 * j + h) ^ ((n >> 1) & 7)) << 4);
+        aa[t][j][1] = 0;
       }
+    }
   }
+  static_assert(ACH == (I8 ? 16 : 8), "A^T chunk geometry");
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -341,42 +367,47 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
     asm volatile("s_barrier" ::: "memory");  // (also: every wave has finished its reads of step st - 1, whose slot is filled next)
     if (st + 2 < s_end) issue(st + 2);
     const uint32_t so = (uint32_t)((st % 3) * SLOT);
+    // (asm: hipcc would put vmcnt(0) in front of LDS reads it can see while an LDS-DMA is in flight; every read's result is
+    // pinned behind the lgkmcnt(0) below by a "+v" operand)
     u32x4 xr[4];
-    bf16x8 ar[2][4][2];
-    // (asm: hipcc would put vmcnt(0) in front of LDS reads it can see while an LDS-DMA is in flight)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[j]) : "v"(xa[j] + so));
+    bf16x8 ar[4][4][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < (I8 ? 2 : 1); ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(ar[t][j][u]) : "v"(aa[t][j][u] + so));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < (I8 ? 2 : 1); ++u) asm volatile("" : "+v"(ar[t][j][u]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      asm volatile("ds_read_b128 %0, %1" : "=v"(xr[j]) : "v"(xa[j] + so));
+      if constexpr (I8) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+        for (int u = 0; u < 2; ++u) {  // bytes 8 u .. 8 u + 7 of the chunk -> 8 halves (i8x32_to_f16's arithmetic)
+          u32x4 f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) asm volatile("ds_read_b128 %0, %1" : "=v"(ar[t][j][u]) : "v"(aa[t][j][u] + so));
-    }
-    if constexpr (NT == 2)
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(ar[0][0][0]), "+v"(ar[0][0][1]), "+v"(ar[0][1][0]),
-                     "+v"(ar[0][1][1]), "+v"(ar[0][2][0]), "+v"(ar[0][2][1]), "+v"(ar[0][3][0]), "+v"(ar[0][3][1]), "+v"(ar[1][0][0]),
-                     "+v"(ar[1][0][1]), "+v"(ar[1][1][0]), "+v"(ar[1][1][1]), "+v"(ar[1][2][0]), "+v"(ar[1][2][1]), "+v"(ar[1][3][0]),
-                     "+v"(ar[1][3][1]));
-    else
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(ar[0][0][0]), "+v"(ar[0][0][1]), "+v"(ar[0][1][0]),
-                     "+v"(ar[0][1][1]), "+v"(ar[0][2][0]), "+v"(ar[0][2][1]), "+v"(ar[0][3][0]), "+v"(ar[0][3][1]));
+          for (int d = 0; d < 2; ++d) {
+            const uint32_t tb = xr[j][2 * u + d] ^ 0x80808080u;
+            f[2 * d] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, tb, 0x04010400u)) + bias);
+            f[2 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, tb, 0x04030402u)) + bias);
+          }
+          const bf16x8 xf = __builtin_bit_cast(bf16x8, f);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {  // bytes 8 u .. 8 u + 7 of the chunk -> 8 halves (i8x32_to_f16's arithmetic)
-        u32x4 f;
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-          const uint32_t tb = xr[j][2 * u + d] ^ 0x80808080u;
-          f[2 * d] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, tb, 0x04010400u)) + bias);
-          f[2 * d + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, __builtin_amdgcn_perm(0x64646464u, tb, 0x04030402u)) + bias);
+          for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16<true>(xf, ar[t][j][u], acc[t]);
         }
-        const bf16x8 xf = __builtin_bit_cast(bf16x8, f);
+      } else {
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, xr[j]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16<true>(xf, ar[t][j][u], acc[t]);
+        for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16<false>(xf, ar[t][j][0], acc[t]);
       }
+    }
   }
   // D layout: col n = lane & 31, row m = (reg & 3) + 8 (reg >> 2) + 4 h.  part[c][rg * 32 + m][n]
   const int rg = tile * 4 + wave;
@@ -387,6 +418,15 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * h) * RP + 32 * t + r31] = acc[t][e];
   }
+}
+
+template <int NT, bool I8>
+static void launch(const void* xq, int64_t x_ld, const bf16_t* a_img, int64_t Kp, int row_groups, int tiles, int nch, int spc,
+                   int steps_total, float* part, hipStream_t st) {
+  static LdsLimitOnce once;
+  once.set((const void*)k_xa_partial_lds<NT, I8>, lds_bytes(NT, I8));
+  k_xa_partial_lds<NT, I8><<<(unsigned)(tiles * nch), 256, lds_bytes(NT, I8), st>>>((const uint8_t*)xq, x_ld, a_img, Kp, row_groups, nch,
+                                                                                    spc, steps_total, part);
 }
 }  // namespace xal
 
@@ -769,22 +809,26 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
 #ifndef LQER_XA_NO_LDS
   bool staged = false;
   XaPlan plan_l = plan;
-  if (a_f16 && (rp == 32 || rp == 64) && M >= 512 && Kx % xal::BK == 0) {
-    // the LDS-staged kernel: 128-row tiles x K chunks of whole 128-k steps (the int8 image is zero-padded to 128 k)
-    const int steps_total = (int)(Kx / xal::BK), tiles = (int)((M + xal::ROWS - 1) / xal::ROWS);
-    int nch = plan.nchunk < steps_total ? plan.nchunk : steps_total;
+  // the LDS-staged kernel (xal): the int8 route's images at any rank tile count up to 2; the bf16 image x one bf16 limb of A^T
+  // for ranks beyond the fused quantizer's (rank 65..128: the OPT configurations).  128-row tiles x K chunks of whole steps,
+  // about one workgroup per CU (fewer, longer chunks than the wave-per-chunk plan: less for the reduce pass to read)
+  const bool lds_i8 = a_f16 && (rp == 32 || rp == 64) && Kx % xal::BKB == 0;
+  const bool lds_b16 = !x_f16 && !x_i8 && x_limbs == 1 && a_limbs == 1 && rp % 32 == 0 && rp > 64 && rp <= 128;
+  if ((lds_i8 || lds_b16) && M >= 512) {
+    const int64_t x_ld = lds_i8 ? Kx : Kp * 2;  // bytes per activation row (both zero-padded to whole 128-byte steps)
+    const int steps_total = (int)(x_ld / xal::BKB), tiles = (int)((M + xal::ROWS - 1) / xal::ROWS);
+    int nch = LQER_XAL_WGS / tiles;
+    nch = nch < 1 ? 1 : (nch > plan.nchunk ? plan.nchunk : nch);
+    nch = nch < steps_total ? nch : steps_total;
     const int spc = (steps_total + nch - 1) / nch;
     nch = (steps_total + spc - 1) / spc;
     plan_l.nchunk = nch;
-    static LdsLimitOnce once1, once2;
-    if (rp == 32) {
-      once1.set((const void*)xal::k_xa_partial_lds<1>, 3 * (xal::X_SLOT + 32 * xal::BK * 2));
-      xal::k_xa_partial_lds<1><<<(unsigned)(tiles * nch), 256, 3 * (xal::X_SLOT + 32 * xal::BK * 2), st>>>(
-          (const uint8_t*)xq, Kx, a_t, Kp, plan.row_groups, nch, spc, steps_total, scratch);
+    if (lds_i8) {
+      if (nt == 1) xal::launch<1, true>(xq, x_ld, a_t, Kp, plan.row_groups, tiles, nch, spc, steps_total, scratch, st);
+      else xal::launch<2, true>(xq, x_ld, a_t, Kp, plan.row_groups, tiles, nch, spc, steps_total, scratch, st);
     } else {
-      once2.set((const void*)xal::k_xa_partial_lds<2>, 3 * (xal::X_SLOT + 64 * xal::BK * 2));
-      xal::k_xa_partial_lds<2><<<(unsigned)(tiles * nch), 256, 3 * (xal::X_SLOT + 64 * xal::BK * 2), st>>>(
-          (const uint8_t*)xq, Kx, a_t, Kp, plan.row_groups, nch, spc, steps_total, scratch);
+      if (nt == 3) xal::launch<3, false>(xq, x_ld, a_t, Kp, plan.row_groups, tiles, nch, spc, steps_total, scratch, st);
+      else xal::launch<4, false>(xq, x_ld, a_t, Kp, plan.row_groups, tiles, nch, spc, steps_total, scratch, st);
     }
     staged = true;
   }
