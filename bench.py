@@ -680,7 +680,7 @@ def main():
         print(f"# parity vs CPU oracle ({len(idx)} rows x {len(mods)} shapes): rel-L2 {parity:.3e}", file=sys.stderr)
 
     if rank == 0:
-        # dominant kernel = the fused GEMM; algorithmic FLOPs per launch = 2MKN + 2MrN (DESIGN.md §Kernels)
+        # dominant kernel = the fused GEMM; algorithmic FLOPs per launch = 2MKN + 2MrN (DESIGN.md §4)
         # an event pair around a kernel also measures the gap between the first event and the kernel's start: the
         # same pair around nothing, recorded right behind a kernel, gives that overhead (median of 32), which is
         # subtracted - the result agrees with the kernel durations of the rocprofv3 trace of the same command

@@ -877,7 +877,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   g.tiles_m_rows = BM;
 #ifndef LQER_NO_H64
   // Token counts whose 128-row grid covers at most half of the CUs: 64-row tiles (twice the workgroups, half the MFMA work
-  // per expanded weight fragment - the k-step is then paced by the weight expand, §4.1) as long as they still fit one round.
+  // per expanded weight fragment - the k-step is then paced by the weight expand, NOTEBOOK.md §4.1) as long as they still fit one round.
   {
     constexpr int CUS = 256;
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Exponent-pair histogram for the block-scaled MFMA question.
+"""Exponent-pair histogram for the block-scaled MFMA question (DESIGN.md §4 "fp6 block-scaled MFMA", NOTEBOOK.md §8.4).
 
 `v_mfma_scale_f32_32x32x64_f8f6f4` applies ONE E8M0 scale per 32 k; the MXINT formats of the path carry one exponent per
 16 k (llama-7b.toml:82-97).  A pair of 16-blocks (e1, e2) fits one scale E = max(e1, e2) only if the block with the smaller

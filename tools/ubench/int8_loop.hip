@@ -1,4 +1,4 @@
-// Compute-side ceiling of an int8 main loop for the per-token INT configurations (DESIGN.md §7 "next"): per 128-k step
+// Compute-side ceiling of an int8 main loop for the per-token INT configurations (NOTEBOOK.md §7): per 128-k step
 // a wave that owns a 128 x 32 tile (the 128-row kernel's geometry: i32 + fp32 accumulators = 128 registers) expands 16
 // words of 4-bit sign-magnitude codes to int8, issues 16 v_mfma_i32_32x32x32_i8 (4 k-slices x 4 m-tiles) and folds the
 // i32 tile into fp32 accumulators with one scale per output column (weight blocks of 128).  No memory traffic: operands are register constants - this measures only

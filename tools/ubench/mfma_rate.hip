@@ -1,4 +1,4 @@
-// Issue rate of the MFMA forms discussed in DESIGN.md §4.1, one wave per SIMD, 4 independent accumulators:
+// Issue rate of the MFMA forms discussed in NOTEBOOK.md §4.1, one wave per SIMD, 4 independent accumulators:
 //   v_mfma_f32_32x32x16_bf16 (the kernels' instruction), v_mfma_i32_32x32x16_i8 (one 16-k block per instruction),
 //   v_mfma_i32_32x32x32_i8 (full-rate int8), v_mfma_f32_32x32x16_f16.
 // build: hipcc --offload-arch=gfx950 -O2 -o mfma_rate mfma_rate.hip ; run on one MI355X.

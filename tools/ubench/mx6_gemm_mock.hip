@@ -1,5 +1,5 @@
 // Feed + compute mock of an e3m2 ("fp6 signed-digit") main loop at the C2 geometry (M 2048, K 4096, N 4096), the gate for
-// building that route: does the operand feed - 25.6 KB of LDS-DMA per 64-k step of a
+// building that route (DESIGN.md §4 "fp6 block-scaled MFMA", NOTEBOOK.md §8.4): does the operand feed - 25.6 KB of LDS-DMA per 64-k step of a
 // 128 x 256 tile, twice the rate of the bf16 kernel - keep 4x-rate scaled MFMAs busy?  Everything of the real loop that
 // costs time is here (global -> LDS ring by LDS-DMA with the real footprints and L2 sharing, fragment reads, scaled MFMAs,
 // one barrier per step); the data are random bits, there is no prologue / epilogue and nothing is checked.

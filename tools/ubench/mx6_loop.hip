@@ -1,4 +1,4 @@
-// Block-scaled MFMA as the main loop of the MXINT-16 configurations: exactness of the
+// Block-scaled MFMA as the main loop of the MXINT-16 configurations (DESIGN.md §4 "fp6 block-scaled MFMA", NOTEBOOK.md §8.4): exactness of the
 // operand encoding on the device, and the compute-side ceiling of such a loop against the shipped bf16 loop.
 //
 // Encoding under test.  v_mfma_scale_f32_32x32x64_f8f6f4 with BOTH operands in e3m2 ("bf6", cbsz = blgp = 3): a lane holds

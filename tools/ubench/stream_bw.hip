@@ -1,6 +1,6 @@
 // What a streaming kernel can get from HBM on this device when the working set exceeds the 256 MB Infinity Cache:
 // grid-stride copy (read + write) and read-only sum over buffers of 32 MiB .. 1 GiB, 16-byte accesses.  Reference
-// point for the per-token quantizer and the side GEMM of the INT configurations (168 MB activations: DESIGN.md §7).
+// point for the per-token quantizer and the side GEMM of the INT configurations (168 MB activations: NOTEBOOK.md §7).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ __launch_bounds__(256) void k_copy(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
