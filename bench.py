@@ -737,7 +737,12 @@ def main():
             roofline = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
                         "traffic_source": traffic_source, "kernel": kernels, "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch,
-                        "weights_rotated": rotate if rotate > 1 else 1, "event_flags": hex(ev_flags)}
+                        "weights_rotated": rotate if rotate > 1 else 1, "event_flags": hex(ev_flags),
+                        "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
+                        # (a ~6 us kernel: the subtracted pair overhead is half of what the pair measures, and rocprofv3's own
+                        # kernel durations carry 1.5-3 us of instrumentation at this size - profiles/README.md; the bound that
+                        # needs no calibration is ms_per_step, one launch + one launch gap per forward)
+                        "avg_launch_us_upper_bound": round(ms_per_step * 1e3, 2) if one_launch else None}
             if resident_fig is not None:  # the same launches on ONE weight that stays in the Infinity Cache (an upper bound)
                 rms = sum(max(e0.elapsed_time(e1) - ev_overhead_ms, 1e-6) for e0, e1, _, _ in resident_fig["events"])
                 rn = max(len(resident_fig["events"]), 1)
