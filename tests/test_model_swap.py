@@ -394,3 +394,40 @@ def test_mistral_gqa_shared_groups_gpu():
     with torch.no_grad():
         la, lb = a(input_ids=ids).logits.float().cpu(), b(input_ids=ids).logits.float().cpu()
     assert torch.isfinite(la).all() and (la - lb).norm() / lb.norm() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens", [1, 6, 40])
+def test_whole_model_forward_replayed_from_one_graph_gpu(tokens):
+    """A serving loop captures the model's token step once and replays it (lqer_amd.graph.GraphedCallable): every quantized
+    Linear (shared q/k/v and gate/up inputs), both quantized attention products and the rest of the HF model inside ONE
+    hipGraph.  1 and 6 tokens take the one-launch decode kernel (capturable since round 3: its hand-off tag carries the
+    launch's dispatch id), 40 tokens the two-launch route.  Replays with new token ids equal the eager logits bit for bit."""
+    import json
+    import os
+
+    from lqer_amd import attention as A
+    from lqer_amd.graph import GraphedCallable
+    from lqer_amd.models import load_low_rank_dict, quantize_model
+
+    mm_cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matmul_config.json")))
+    qc = {"linear": MXINT_Q, "matmul": mm_cfg}
+    model = quantize_model(_tiny_llama(), qc, {"linear": {"rank": 16}}, share_inputs=True)
+    load_low_rank_dict(model, _ab_dict(model, 16))
+    A.enable_quantized_attention(model, qc)
+    model = model.to("cuda:0").half()
+    g = torch.Generator().manual_seed(5)
+    ids = [torch.randint(0, 320, (1, tokens), generator=g).to("cuda:0") for _ in range(4)]
+    # (the causal mask as a ready 4-D tensor: transformers builds its own with a host-to-device scalar copy, which a capture refuses)
+    mask = torch.full((1, 1, tokens, tokens), float("-inf"), dtype=torch.float16, device="cuda:0").triu(1)
+    run = lambda t: model(input_ids=t, attention_mask=mask, use_cache=False).logits
+    with torch.no_grad():
+        eager = [run(i).clone() for i in ids]
+        static_ids = ids[0].clone()
+        step = GraphedCallable(run, static_ids, warmup=2)
+        for i, want in zip(ids, eager):
+            got = step(i).clone()
+            torch.cuda.synchronize()
+            assert torch.isfinite(got).all()
+            assert torch.equal(got, want)
+    assert not torch.equal(eager[0], eager[1])
