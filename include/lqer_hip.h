@@ -194,8 +194,15 @@ int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype
 int lqer_debug_set_decode_spin(int sweeps);
 
 /* test hook: tile height of the 128-row kernel family (LQER_ROUTE_TILE128): 0 = chosen per launch (64-row tiles when the
- * 128-row grid covers at most half of the CUs), 128 = always 128 rows.  Both heights give the same bits. */
+ * 128-row grid covers at most half of the CUs), 128 = always 128 rows, 64 = always 64 rows (two workgroups per CU).  All
+ * give the same bits. */
 int lqer_debug_set_tile_rows(int rows);
+
+/* experiment hook (round 3): XCD-local tile BLOCKS in the 128-row kernel - an XCD's tiles form a block of `token_tiles` token
+ * tiles x (tiles / 8 / token_tiles) weight tiles instead of rows of weight tiles; applied only where the tile grid divides
+ * (e.g. 16 x 16 tiles: 8, 4 or 16), 0 = off.  Same bits, same time (the weight stream through every XCD's L2 is served by
+ * the Infinity Cache and is not what the main loop waits for): kept for measurement (tools/ab_gemm.py --xcd-bm). */
+int lqer_debug_set_xcd_block(int token_tiles);
 
 /* The same, split for callers that share one quantized activation between several Linears
  * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "lqer_decode_partials": (_i, [_dp, _i64]),
     "lqer_debug_set_decode_spin": (_i, [_i]),
     "lqer_debug_set_tile_rows": (_i, [_i]),
+    "lqer_debug_set_xcd_block": (_i, [_i]),
     "lqer_gemm_route": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),

@@ -72,3 +72,30 @@ def test_64_row_tiles_equal_128_row_tiles_and_the_oracle(lq, M, K, N, r, bias, b
     ref = O.lqer_linear_forward(h(x), h(W), h(bvec), h(A) if r > 0 else None, h(B) if r > 0 else None, qc)
     err = float((y64.float().cpu() - ref).norm() / ref.norm())
     assert err <= (4e-3 if dtype == torch.bfloat16 else 1e-3), err
+
+
+def test_forced_64_row_tiles_and_xcd_blocks_give_the_same_bits(lq):
+    """Round-3 experiment hooks of the 128-row kernel at the C2 shape (16 x 16 tiles, one per CU): 64-row tiles forced at
+    M = 2048 (two workgroups per CU, 69.6 KB of LDS each) and XCD-local tile blocks (8 / 4 / 16 token tiles per XCD) are pure
+    re-mappings of the same arithmetic - bit-identical outputs."""
+    from bench import MXINT_Q, make_case
+    from lqer_amd import _lib
+
+    M, K, N, r = 2048, 1024, 4096, 32  # (K short: the mapping, not the loop length, is under test)
+    x, W, A, B = make_case(M, K, N, r, seed=77)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).half()
+    xd = x.half().to(DEV)
+    L = _lib.lib()
+    y0 = mod(xd).clone()
+    try:
+        L.lqer_debug_set_tile_rows(64)
+        assert torch.equal(mod(xd), y0)
+        L.lqer_debug_set_tile_rows(0)
+        for bm in (8, 4, 16, 3):  # (3 does not divide the grid: ignored)
+            L.lqer_debug_set_xcd_block(bm)
+            assert torch.equal(mod(xd), y0), bm
+    finally:
+        L.lqer_debug_set_tile_rows(0)
+        L.lqer_debug_set_xcd_block(0)
