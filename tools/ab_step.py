@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--also-128", action="store_true", help="time every build a second time with the 128-row tiles pinned (lqer_debug_set_tile_rows)")
     ap.add_argument("--also-64", action="store_true", help="time every build once more with 64-row tiles forced (two workgroups per CU at large M)")
+    ap.add_argument("--spin0", action="store_true", help="also time every build with the in-launch hand-offs' poll bound at 0 (every workgroup sums its own rows)")
     ap.add_argument("--gap", type=int, default=0, help="tiny unrelated kernels launched between the quantizer and the GEMM (boundary-effect probe)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -51,6 +52,8 @@ def main():
         libs += [(p + " [128-row tiles]", L) for p, L in base]
     if a.also_64:
         libs += [(p + " [64-row tiles]", L) for p, L in base]
+    if a.spin0:
+        libs += [(p + " [spin 0]", L) for p, L in base]
     st = torch.cuda.current_stream().cuda_stream
     nscr = libs[0][1].lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
     scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
@@ -59,7 +62,8 @@ def main():
 
     def run(L, pin=0):
         if hasattr(L, "lqer_debug_set_tile_rows"):
-            L.lqer_debug_set_tile_rows(pin)
+            L.lqer_debug_set_tile_rows(pin if pin > 0 else 0)
+        L.lqer_debug_set_decode_spin(0 if pin == -1 else -1)
         # (a build whose GEMM sums the partial tiles of x A itself - lqer_decode_partials - gets no xaq: two launches)
         xa = None if L.lqer_decode_partials(C.byref(desc), M) else xaq.data_ptr()
         rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xa,
@@ -71,7 +75,7 @@ def main():
                                 _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
 
-    pin_of = lambda p: 128 if p.endswith("[128-row tiles]") else (64 if p.endswith("[64-row tiles]") else 0)
+    pin_of = lambda p: 128 if p.endswith("[128-row tiles]") else (64 if p.endswith("[64-row tiles]") else (-1 if p.endswith("[spin 0]") else 0))
     times = {p: [] for p, _ in libs}
     for p, L in libs:
         for _ in range(10):
