@@ -333,7 +333,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # (LQER_BENCH_FORCE_DIST=1 under a launcher: a single rank still goes through RCCL - the rehearsal a one-GPU box allows)
+    if world > 1 or (os.environ.get("LQER_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
