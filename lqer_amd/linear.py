@@ -432,14 +432,14 @@ class SharedActivation:
         self._round = 0       # rounds started by this group (pool ownership)
         self._cur = None
         self._served = set()  # members served from the current images
-        self._i8_route = {}   # (M, dtype) -> every member's GEMM takes the int8 kernel
+        self._plans = {}      # (M, dtype) -> launch constants of the group quantizer and of every member's GEMM
         if self.enabled:
             for m in self.members:
                 m._group = self
 
     def invalidate(self):
         self._cat, self._x, self._cur, self._served = None, None, None, set()
-        self._i8_route = {}
+        self._plans = {}
 
     @classmethod
     def release_pool(cls):
@@ -493,54 +493,60 @@ class SharedActivation:
         pool = SharedActivation._pool.get(pkey)
         fresh = not (x is self._x and ver == self._ver and self._cur is not None and self._cur["M"] == M and idx not in self._served
                      and pool is not None and pool["owner"] == (id(self), self._round))  # (another group has used the pool since)
-        # members on the int8 route (per-token activations): the shared image is int8 only if every member's GEMM takes the
-        # int8 kernel at this token count, else everybody uses the bf16 image
+        # per token count and dtype, built once (descriptors, route and size queries are host time a 60-us GEMM does not hide):
+        # members on the int8 route (per-token activations) share an int8 image only if every member's GEMM takes the int8
+        # kernel at this token count, else everybody uses the bf16 image
         dtc = ops.dtype_code(x2)
-        i8 = self._i8_route.get((M, dtc))
-        if i8 is None:  # (decided once per token count and dtype: a descriptor + a route query per member is host time)
+        plan = self._plans.get((M, dtc))
+        if plan is None:
             i8 = all(m._x_i8 for m in self.members) and \
                 all(L.lqer_gemm_route(C.byref(m._desc()), M, dtc) == _lib.ROUTE_TILE256_I8 for m in self.members)
-            if len(self._i8_route) > 64:
-                self._i8_route = {}
-            self._i8_route[(M, dtc)] = i8
-        if fresh:
             gdesc = m0._desc(plain=not i8)
             gdesc.rank = self._cat["rp_total"]
             gdesc.a_out_fmt.block = self._aout_block  # (one block per member row -> blocks of a member's rank)
             Mp, Kp = L.lqer_padded_m(M), L.lqer_padded_k(K)
+            nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(gdesc), M)
+            a_img = (self._cat["a_t_f16"].data_ptr(), -1) if i8 and "a_t_f16" in self._cat \
+                else (self._cat["a_t"].data_ptr(), self._cat["a_limbs"])
+            mem = []
+            for m in self.members:  # (plain data and ctypes structs only)
+                d = m._desc(plain=not i8)
+                pk = m._packed
+                mem.append((d, L.lqer_linear_gemm_scratch_bytes(C.byref(d), M), pk["w"].data_ptr(), pk["b_t"].data_ptr(),
+                            pk["b_limbs"], ops._ptr(pk.get("bias")), m.out_features))
+            if len(self._plans) > 64:
+                self._plans = {}
+            plan = self._plans[(M, dtc)] = {
+                "gdesc": gdesc, "nscr": nscr, "a_img": a_img, "members": mem,
+                "need": {"xq": Mp * Kp * 2, "xaq": Mp * self._cat["rp_total"] * 2, "scr": max(nscr, 16)}}
+        st = ops._stream(dev)
+        if fresh:
             # the images live in ONE grow-only pool per device, shared by every group (the groups of a model run one after
             # the other; 64 private copies would pin ~1 GiB at M = 2048): a group owns the pool from its first member's call
             # of a round to its last; a member that finds another owner re-makes the images (always correct, only slower)
-            nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(gdesc), M)
-            need = {"xq": Mp * Kp * 2, "xaq": Mp * self._cat["rp_total"] * 2, "scr": max(nscr, 16)}
             if pool is None:
                 pool = SharedActivation._pool[pkey] = {"owner": None}
-            for name, nbytes in need.items():
+            for name, nbytes in plan["need"].items():
                 if name not in pool or pool[name].numel() < nbytes:
                     pool[name] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._round += 1
             pool["owner"] = (id(self), self._round)
-            b = {"xq": pool["xq"], "xaq": pool["xaq"], "scr": pool["scr"], "nscr": nscr}
-            check(L.lqer_quantize_act_xa(C.byref(gdesc), x2.data_ptr(), ops.dtype_code(x2), M, x2.stride(0) if M > 1 else K,
-                                         *((self._cat["a_t_f16"].data_ptr(), -1) if i8 and "a_t_f16" in self._cat
-                                           else (self._cat["a_t"].data_ptr(), self._cat["a_limbs"])), b["xq"].data_ptr(),
-                                         b["xaq"].data_ptr(), b["scr"].data_ptr(), b["nscr"], ops._stream(dev)),
-                  "lqer_quantize_act_xa (shared input)")
+            b = {"xq": pool["xq"].data_ptr(), "xaq": pool["xaq"].data_ptr(), "keep": (pool["xq"], pool["xaq"])}
+            rc = L.lqer_quantize_act_xa(C.byref(plan["gdesc"]), x2.data_ptr(), dtc, M, x2.stride(0) if M > 1 else K,
+                                        *plan["a_img"], b["xq"], b["xaq"], pool["scr"].data_ptr(), plan["nscr"], st)
+            if rc:
+                check(rc, "lqer_quantize_act_xa (shared input)")
             self._x, self._ver, self._cur, self._served = x, ver, dict(b, M=M), set()
         cur = self._cur
         self._served.add(idx)
         if len(self._served) == len(self.members):
             self._x = None  # every member has been served: do not pin the activation tensor until the next call
-        off = self._cat["offs"][idx]
-        desc = mod._desc(plain=not i8)
-        p = mod._packed
-        gs = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+        desc, gs, w_ptr, bt_ptr, b_limbs, bias_ptr, N = plan["members"][idx]
         scr = ops.workspace(dev, max(gs, 16))
-        check(L.lqer_linear_gemm_ld(C.byref(desc), cur["xq"].data_ptr(), M, p["w"].data_ptr(),
-                                    cur["xaq"].data_ptr() + 2 * off, self._cat["rp_total"], p["b_t"].data_ptr(),
-                                    p["b_limbs"], ops._ptr(p.get("bias")), y.data_ptr(), ops.dtype_code(x2), mod.out_features,
-                                    scr.data_ptr(), gs, ops._stream(dev)),
-              "lqer_linear_gemm_ld (shared input)")
+        rc = L.lqer_linear_gemm_ld(C.byref(desc), cur["xq"], M, w_ptr, cur["xaq"] + 2 * self._cat["offs"][idx],
+                                   self._cat["rp_total"], bt_ptr, b_limbs, bias_ptr, y.data_ptr(), dtc, N, scr.data_ptr(), gs, st)
+        if rc:
+            check(rc, "lqer_linear_gemm_ld (shared input)")
         return True
 
 
