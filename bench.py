@@ -312,6 +312,10 @@ def main():
                     help="decode workloads (M <= 64): walk R distinct copies of the packed operands round robin, so that the "
                          "weight stream comes from HBM and not from the 256 MB Infinity Cache (default 48 = 451 MB of 4096 x 4096 "
                          "images; 0 = one resident weight); the resident figure is reported beside it")
+    ap.add_argument("--shared-weights", action="store_true",
+                    help="model sweeps: re-run ONE packed image per projection shape for every layer (the round-1/2 behaviour: "
+                         "~60 MB of weights that never leave the Infinity Cache) instead of one distinct copy per Linear of the "
+                         "model (default: a Llama-7B rank walks 3.6 GB of packed operands per step, as the model does)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU, no kernel: the multi-rank host logic alone (launcher, partition, gloo broadcast / gather, "
                          "timed-region protocol, the JSON line) - value is null")
@@ -418,6 +422,8 @@ def main():
 
     # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
     plans = []
+    distinct = layers > 1 and not args.shared_weights and rotate <= 1
+    distinct_keep = []  # (the cloned images stay alive for the run)
     ws = ops.workspace(dev, max(ops.linear_sizes(mod._desc(), M).workspace for mod, *_ in mods))  # one buffer for all
     for mod, xd, K, N, reps, y, _ in rot_mods:
         desc = mod._desc()
@@ -439,7 +445,17 @@ def main():
         a_t, a_limbs = p["a_t"].data_ptr(), p["a_limbs"]
         if mod._x_i8 and "a_t_f16" in p and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) == _lib.ROUTE_TILE256_I8:
             a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # the int8 route's side GEMM: A as one fp16 image (as the module passes it)
-        plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=a_t, a_limbs=a_limbs, xq=xq, xaq=xaq,
+        # model sweeps: every Linear of the model owns its packed operands (same values, distinct addresses - layers differ
+        # in values, not in cost, but a weight that is re-read from the Infinity Cache 32 times is not what a model does)
+        copies = []
+        if distinct and reps > 1:
+            a_key = "a_t_f16" if a_limbs == -1 else "a_t"
+            for _ in range(reps - 1):
+                cw, ca, cb = p["w"].clone(), p[a_key].clone(), p["b_t"].clone()
+                cbias = p["bias"].clone() if p.get("bias") is not None else None
+                distinct_keep.append((cw, ca, cb, cbias))
+                copies.append((cw.data_ptr(), ca.data_ptr(), cb.data_ptr(), ops._ptr(cbias)))
+        plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=a_t, a_limbs=a_limbs, xq=xq, xaq=xaq, copies=copies,
                           ws=ws.data_ptr(), ws_bytes=ws.numel(),
                           xscr=xscr, nscr=nscr, w=p["w"].data_ptr(),
                           b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),
@@ -469,7 +485,15 @@ def main():
                 qa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"], pl["xq"], pl["xaq"], pl["xscr"], pl["nscr"], st)
                 ga = (pl["dref"], pl["xq"], M, pl["w"], pl["xaq"], pl["b_t"], pl["b_limbs"], pl["bias"], pl["y"], _lib.F16, N,
                       pl["xscr"], pl["gscr"], st)
-                rows.append((pl["reps"], K, N, fa, qa, ga))
+                per_unit = [(fa, qa, ga)]
+                for cw, ca, cb, cbias in pl["copies"]:  # the other Linears of this shape: own weight / A / B / bias images
+                    per_unit.append(((pl["dref"], pl["x"], _lib.F16, M, K, cw, ca, cb, pl["a_limbs"], pl["b_limbs"], cbias,
+                                      pl["y"], N, pl["ws"], pl["ws_bytes"], st),
+                                     (pl["dref"], pl["x"], _lib.F16, M, K, ca, pl["a_limbs"], pl["xq"], pl["xaq"], pl["xscr"],
+                                      pl["nscr"], st),
+                                     (pl["dref"], pl["xq"], M, cw, pl["xaq"], cb, pl["b_limbs"], cbias, pl["y"], _lib.F16, N,
+                                      pl["xscr"], pl["gscr"], st)))
+                rows.append((pl["reps"], K, N, per_unit))
             bound[st] = rows
         return bound[st]
 
@@ -481,8 +505,9 @@ def main():
         if rotate > 1:
             rows = rows[:1] if resident[0] else rows[rot_no[0] % rotate: rot_no[0] % rotate + 1]
             rot_no[0] += 1
-        for reps, K, N, fa, qa, ga in rows:
-            for _ in range(reps):
+        for reps, K, N, per_unit in rows:
+            for u in range(reps):
+                fa, qa, ga = per_unit[u % len(per_unit)]
                 ev = timed and launch_no[0] % EV_EVERY == 0  # counts timed launches only: the first one is always sampled
                 if timed:
                     launch_no[0] += 1
@@ -777,7 +802,11 @@ def main():
                        "sharding": ("decoder layers split over the ranks, ceil(L/G) consecutive layers each (infer_device_map.py:29-37)"
                                     if strong else "every rank runs its own Linear unit(s) of the workload") +
                                    "; x broadcast from rank 0 and per-rank results gathered outside the timed region, no data-path collective",
-                       "layers_per_rank": [int(row[2]) for row in gathered]},
+                       "layers_per_rank": [int(row[2]) for row in gathered],
+                       "weights": ("one packed image set per Linear of the model: %.2f GB walked per step on rank 0" % (
+                           sum(sum(t.numel() * t.element_size() for t in c if t is not None) for c in distinct_keep) / 1e9
+                           + sum(m[0]._packed["w"].numel() for m in mods) / 1e9) if distinct else
+                           ("one packed image set per projection shape, re-run for every layer" if layers > 1 else "one Linear"))},
             "tokens_per_s": round(M * args.steps / elapsed * (1 if strong else world), 1),
             "launch": ("hipGraph replay, %d steps per graph" % args.graph) if graph is not None else "direct launches",
             "prewarm_ms": args.prewarm_ms,
