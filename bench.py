@@ -312,6 +312,8 @@ def main():
                     help="decode workloads (M <= 64): walk R distinct copies of the packed operands round robin, so that the "
                          "weight stream comes from HBM and not from the 256 MB Infinity Cache (default 48 = 451 MB of 4096 x 4096 "
                          "images; 0 = one resident weight); the resident figure is reported beside it")
+    ap.add_argument("--no-two-streams", action="store_true",
+                    help="skip the secondary figure with the step's independent forwards issued alternately on two HIP streams")
     ap.add_argument("--shared-weights", action="store_true",
                     help="model sweeps: re-run ONE packed image per projection shape for every layer (the round-1/2 behaviour: "
                          "~60 MB of weights that never leave the Infinity Cache) instead of one distinct copy per Linear of the "
@@ -475,10 +477,11 @@ def main():
     new_pair = lambda: (HipEvent(ev_flags), HipEvent(ev_flags))
     ev_pool = [new_pair() for _ in range(64)]
 
-    def calls_for(st):
-        if st not in bound:
+    def calls_for(st, pls=None):
+        pls = plans if pls is None else pls
+        if (st, id(pls)) not in bound:
             rows = []
-            for pl in plans:
+            for pl in pls:
                 K, N = pl["K"], pl["N"]
                 fa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["w"], pl["a_t"], pl["b_t"], pl["a_limbs"], pl["b_limbs"], pl["bias"],
                       pl["y"], N, pl["ws"], pl["ws_bytes"], st)
@@ -494,8 +497,8 @@ def main():
                                      (pl["dref"], pl["xq"], M, cw, pl["xaq"], cb, pl["b_limbs"], cbias, pl["y"], _lib.F16, N,
                                       pl["xscr"], pl["gscr"], st)))
                 rows.append((pl["reps"], K, N, per_unit))
-            bound[st] = rows
-        return bound[st]
+            bound[(st, id(pls))] = rows
+        return bound[(st, id(pls))]
 
     rot_no = [0]
     resident = [False]  # True: every step re-runs plan 0 (the weight stays in the Infinity Cache)
@@ -681,6 +684,52 @@ def main():
         except Exception as e:  # (a secondary figure must not cost the bench line)
             model_shared = {"error": f"{type(e).__name__}: {e}"[:200]}
 
+    # secondary figure: the forwards of this workload are INDEPENDENT units - issued alternately on two HIP streams
+    # (own activation / x A images, scratch and output per stream) the second queue's quantizer, side GEMM and store phases
+    # run under the other forward's main loop.  A throughput figure for sweeps and serving batches; `value` stays the
+    # one-stream figure (a model's Linears form a chain: 8d sums their times)
+    two_streams = None
+    if not args.no_two_streams and layers_here > 0 and M > 64 and graph is None:
+        try:
+            s2 = torch.cuda.Stream(dev)
+            ws2 = torch.empty(ws.numel(), dtype=torch.uint8, device=dev)
+            plans2, ys2 = [], []
+            for pl in plans:
+                q = dict(pl)
+                for k in ("xq", "xaq", "xscr", "ws"):
+                    if q[k] is not None and ws.data_ptr() <= q[k] < ws.data_ptr() + ws.numel():
+                        q[k] = q[k] - ws.data_ptr() + ws2.data_ptr()
+                ys2.append(torch.empty(M, q["N"], dtype=torch.float16, device=dev))
+                q["y"] = ys2[-1].data_ptr()
+                plans2.append(q)
+            unit_no, on_b = [0], set()
+
+            def step_two():
+                ra, rb = calls_for(stream), calls_for(s2.cuda_stream, plans2)
+                for i, ((reps, K, N, pa), (_, _, _, pb)) in enumerate(zip(ra, rb)):
+                    for u in range(reps):
+                        if unit_no[0] % 2:
+                            on_b.add((i, u % len(pa)))
+                        _, qa, ga = (pa if unit_no[0] % 2 == 0 else pb)[u % len(pa)]
+                        unit_no[0] += 1
+                        rc = qxa(*qa) or gemm(*ga)
+                        if rc:
+                            _lib.check(rc, "two-stream step")
+
+            s2.wait_stream(torch.cuda.current_stream(dev))
+            for _ in range(max(2, args.warmup // 2)):
+                step_two()
+            torch.cuda.synchronize()
+            for i, ((mod, xd, K, N, reps, y, _), y2) in enumerate(zip(mods, ys2)):
+                # both queues produce the bits of the one-stream run (units of a plan that share one image set)
+                if any(pi == i for pi, _ in on_b):  # (every image set of a plan holds the same values)
+                    assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), "two-stream outputs differ"
+            el_two = sweep.max_over_ranks(timed_region(lambda n: [step_two() for _ in range(n)], args.steps), dev)
+            two_streams = {"ms_per_step": round(el_two / args.steps * 1e3, 4), "vs_one_stream": round(elapsed / el_two, 4)}
+            del ws2, ys2
+        except Exception as e:  # (a secondary figure must not cost the bench line)
+            two_streams = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     # ---- gather (outside the timed regions): per-rank elapsed time, a checksum of the first unit's output
     ysum = float(mods[0][5].float().sum().item()) if layers_here > 0 else 0.0
     gathered = sweep.gather_rows([elapsed_rank * 1e3 / args.steps, ysum, float(layers_here)], dev)
@@ -816,6 +865,9 @@ def main():
             # (model workloads) q/k/v and gate/up sharing one quantized input, as the model runs them; `value` does not use it
             "model_shared_inputs": model_shared if model_shared is None or "error" in model_shared else dict(
                 model_shared, value=round(flops_all / (model_shared["ms_per_step"] * 1e-3) / 1e12, 2)),
+            # independent forwards alternating on two HIP streams (throughput of sweeps / serving batches; not `value`)
+            "two_streams": two_streams if two_streams is None or "error" in two_streams else dict(
+                two_streams, value=round(flops_all / (two_streams["ms_per_step"] * 1e-3) / 1e12, 2)),
             "parity_rel_l2": None if parity is None else float(f"{parity:.3e}"),
             "parity_rows": None if parity is None else int(len(check_rows(M))),
             "rank_ms_per_step": [round(row[0], 4) for row in gathered],
