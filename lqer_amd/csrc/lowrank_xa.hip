@@ -437,13 +437,20 @@ __global__ __launch_bounds__(256) void k_xa_reduce4(const float* __restrict__ pa
                                                     bf16_t* __restrict__ xaq, const float* __restrict__ rowscale = nullptr) {
   const int64_t total = (int64_t)plan.row_groups * XA_ROWS * rp / 4;  // float4 items (rp/4 per row, a multiple of G)
   const int64_t chunk_stride = (int64_t)plan.row_groups * XA_ROWS * rp;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (64-thread workgroups when the grid would not fill the chip)
   const bool live = idx < total;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
     const float* src = part + idx * 4;
-    // chunks summed in ascending order, 8 loads in flight at a time
+    // chunks summed in ascending order, 16 (then 8) loads in flight at a time: a launch-latency kernel, every round trip counts
     int c = 0;
+    for (; c + 16 <= plan.nchunk; c += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = *(const float4*)(src + (c + u) * chunk_stride);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+    }
     for (; c + 8 <= plan.nchunk; c += 8) {
       float4 v[8];
 #pragma unroll
@@ -755,13 +762,14 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
 #undef QX_LAUNCH
   if (!xaq) return check_launch("quantize_act_xa");  // the consumer reduces the partial tiles itself
   const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
-  const unsigned grid2 = (unsigned)((items + 255) / 256);
+  const unsigned bs = items <= 128 * 256 ? 64 : 256;  // up to 32 Ki items (C2: 16 Ki): one wave per workgroup spreads them over all CUs
+  const unsigned grid2 = (unsigned)((items + bs - 1) / bs);
   switch (G) {
-    case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
-    case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
-    case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
-    case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
-    default: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    case 1: k_xa_reduce4<1><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    case 2: k_xa_reduce4<2><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    case 4: k_xa_reduce4<4><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    case 8: k_xa_reduce4<8><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    default: k_xa_reduce4<16><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
   }
   return check_launch("quantize_act_xa");
 }
@@ -874,15 +882,16 @@ int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, con
       k_xa_reduce_limbs<3><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, xaq, rowscale);
   } else if (L % 4 == 0 && (G & (G - 1)) == 0 && G <= 64) {
     const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
-    const unsigned grid2 = (unsigned)((items + 255) / 256);
+    const unsigned bs = items <= 128 * 256 ? 64 : 256;  // (as in the fused quantizer's reduce above)
+    const unsigned grid2 = (unsigned)((items + bs - 1) / bs);
     switch (G) {
-      case 1: k_xa_reduce4<1><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
-      case 2: k_xa_reduce4<2><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
-      case 4: k_xa_reduce4<4><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
-      case 8: k_xa_reduce4<8><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
-      case 16: k_xa_reduce4<16><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
-      case 32: k_xa_reduce4<32><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
-      default: k_xa_reduce4<64><<<grid2, 256, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 1: k_xa_reduce4<1><<<grid2, bs, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 2: k_xa_reduce4<2><<<grid2, bs, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 4: k_xa_reduce4<4><<<grid2, bs, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 8: k_xa_reduce4<8><<<grid2, bs, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 16: k_xa_reduce4<16><<<grid2, bs, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      case 32: k_xa_reduce4<32><<<grid2, bs, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
+      default: k_xa_reduce4<64><<<grid2, bs, 0, st>>>(scratch, plan_l, rp, q, xaq, rowscale); break;
     }
   } else {
     const int64_t total = (int64_t)plan.row_groups * XA_ROWS * (rp / L);
