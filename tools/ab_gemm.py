@@ -2,7 +2,7 @@
 """A/B timing of lqer_linear_gemm across several builds of the library in ONE process, interleaved
 rounds (cdna_hip_programming.md rule 24).  Usage on the GPU box:
     python tools/ab_gemm.py [--M 2048 --K 4096 --N 4096 --r 32] lib_a.so lib_b.so ...
-Operands are random (random 4-bit codes, gaussian bf16 activations); results are not checked here."""
+Operands: the bench's synthetic case packed by the module (tools/_operands.py); results are not checked here."""
 import argparse
 import ctypes as C
 import os
@@ -40,20 +40,11 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, K, N, r = a.M, a.K, a.N, a.r
-    Kp, Np, Mp, rp = (K + 63) // 64 * 64, (N + 255) // 256 * 256, (M + 255) // 256 * 256, (r + 15) // 16 * 16
-    g = torch.Generator(device="cpu").manual_seed(0)
-    xq = torch.randn(Mp, Kp, generator=g).to(torch.bfloat16).to(dev)
-    wp = torch.randint(0, 256, ((Np // 16) * (Kp // 64) * 576,), generator=g, dtype=torch.uint8)
-    wv = wp.view(-1, 576)
-    wv[:, 512:] = torch.randint(0, 3, (wv.shape[0], 64), generator=g, dtype=torch.uint8) + 250  # exponents -6..-4
-    wp = wp.to(dev)
-    xaq = (0.1 * torch.randn(Mp, max(rp, 16), generator=g)).to(torch.bfloat16).to(dev)
-    bt = (0.1 * torch.randn(3 * Np * max(rp, 16), generator=g)).to(torch.bfloat16).to(dev)
-    y = torch.empty(M, N, dtype=torch.float16, device=dev)
-    f8 = _lib.QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
-    f4 = _lib.QFmt(_lib.Q_MXINT, 4, 16, 8, 127)
-    fb = {0: _lib.QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127), 1: f8, 2: _lib.QFmt(_lib.Q_MXINT, 8, -1, 8, 127)}[a.bout]
-    desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, fb)
+    from tools._operands import real_operands
+
+    op = real_operands(M, K, N, r, bout=a.bout, blimbs=a.blimbs)
+    desc, xq, wp, xaq, bt, y = op["desc"], op["xq"], op["w"], op["xaq"], op["b_t"], op["y"]
+    b_limbs = op["b_limbs"]
     libs = [(p, load(p)) for p in a.libs]
     base = list(libs)
     for bm in a.xcd_bm:
@@ -61,14 +52,13 @@ def main():
     bm_of = lambda p: int(p.rsplit("[xcd block ", 1)[1][:-1]) if p.endswith("]") and "[xcd block " in p else 0
     st = torch.cuda.current_stream().cuda_stream
 
-    nscr = libs[0][1].lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
-    scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
+    scr, nscr = op["scr"], op["nscr"]
 
     def run(L, bm=0):
         if hasattr(L, "lqer_debug_set_xcd_block"):
             L.lqer_debug_set_xcd_block(bm)
         rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr() if r else None,
-                                bt.data_ptr() if r else None, a.blimbs, None, y.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, st)
+                                bt.data_ptr() if r else None, b_limbs, None, y.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
 
     times = {p: [] for p, _ in libs}

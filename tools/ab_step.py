@@ -2,7 +2,7 @@
 """A/B timing of the whole step (lqer_quantize_act_xa + lqer_linear_gemm: activation quantizer, side GEMM, reduce pass, fused
 GEMM - what bench.py times) across several builds of the library in ONE process, interleaved rounds.
     python tools/ab_step.py [--M 2048 --K 4096 --N 4096 --r 32] lib_a.so lib_b.so ...
-Operands as in tools/ab_gemm.py (random 4-bit codes, gaussian fp16 activations); results are not checked here."""
+Operands: the bench's synthetic case packed by the module (tools/_operands.py); results are not checked here."""
 import argparse
 import ctypes as C
 import os
@@ -31,21 +31,10 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, K, N, r = a.M, a.K, a.N, a.r
-    Kp, Np, Mp, rp = (K + 63) // 64 * 64, (N + 255) // 256 * 256, (M + 255) // 256 * 256, (r + 15) // 16 * 16
-    g = torch.Generator(device="cpu").manual_seed(0)
-    x = torch.randn(M, K, generator=g).half().to(dev)
-    xq = torch.empty(Mp, Kp, dtype=torch.bfloat16, device=dev)
-    wp = torch.randint(0, 256, ((Np // 16) * (Kp // 64) * 576,), generator=g, dtype=torch.uint8)
-    wv = wp.view(-1, 576)
-    wv[:, 512:] = torch.randint(0, 3, (wv.shape[0], 64), generator=g, dtype=torch.uint8) + 250
-    wp = wp.to(dev)
-    xaq = torch.empty(Mp, rp, dtype=torch.bfloat16, device=dev)
-    at = (0.01 * torch.randn(3 * rp * Kp, generator=g)).to(torch.bfloat16).to(dev)
-    bt = (0.1 * torch.randn(3 * Np * rp, generator=g)).to(torch.bfloat16).to(dev)
-    y = torch.empty(M, N, dtype=torch.float16, device=dev)
-    f8 = _lib.QFmt(_lib.Q_MXINT, 8, 16, 8, 127)
-    f4 = _lib.QFmt(_lib.Q_MXINT, 4, 16, 8, 127)
-    desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
+    from tools._operands import real_operands
+
+    op = real_operands(M, K, N, r)
+    desc, x, xq, wp, xaq, at, bt, y = op["desc"], op["x"], op["xq"], op["w"], op["xaq"], op["a_t"], op["b_t"], op["y"]
     libs = [(p, load(p)) for p in a.libs]
     base = list(libs)
     if a.also_128:
@@ -55,8 +44,7 @@ def main():
     if a.spin0:
         libs += [(p + " [spin 0]", L) for p, L in base]
     st = torch.cuda.current_stream().cuda_stream
-    nscr = libs[0][1].lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
-    scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
+    scr, nscr = op["scr"], op["nscr"]
 
     dummy = torch.zeros(64, device=dev)
 

@@ -14,15 +14,9 @@ M, N, r = 2048, 4096, 32
 dev = torch.device("cuda:0")
 buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
 assert L.lqer_debug_set_stamp_buffer(buf.data_ptr()) == 0
-xq = torch.randn(M, K).to(torch.bfloat16).to(dev)
-wp = torch.randint(0, 256, ((N // 16) * (K // 64) * 576,), dtype=torch.uint8)
-wv = wp.view(-1, 576); wv[:, 512:] = torch.randint(0, 3, (wv.shape[0], 64), dtype=torch.uint8) + 250
-wp = wp.to(dev)
-xaq = (0.1 * torch.randn(M, 32)).to(torch.bfloat16).to(dev)
-bt = (0.1 * torch.randn(3 * N * 32)).to(torch.bfloat16).to(dev)
-y = torch.empty(M, N, dtype=torch.float16, device=dev)
-f8 = _lib.QFmt(1, 8, 16, 8, 127); f4 = _lib.QFmt(1, 4, 16, 8, 127)
-desc = _lib.LinearDesc(K, N, r, 0, f8, f4, f8, f8, f8)
+from tools._operands import real_operands  # (real bit patterns: random image bytes give random block exponents -> inf / NaN)
+op = real_operands(M, K, N, r)
+desc, xq, wp, xaq, bt, y = op["desc"], op["xq"], op["w"], op["xaq"], op["b_t"], op["y"]
 def launch():
     assert L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr(), bt.data_ptr(), 1, None, y.data_ptr(), 1, N, None, 0, None) == 0
 t0 = time.time()
