@@ -420,6 +420,207 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
   }
 }
 
+// The B16 form of the kernel above with the ACTIVATION QUANTIZER in front of it (block_fp activations in blocks of 16, rank
+// 65..128: the OPT configurations and q/k/v groups, which the 32-row fused kernel k_quant_xa16 does not cover - its waves fetch
+// their own A^T fragments, 64 KB per workgroup at rank 128).  Instead of an LDS-DMA of the bf16 image, every wave loads the
+// 16-bit source of its 32 rows x 64 k (four 16-byte requests per lane and step, 8 lanes per 128-byte line, two steps ahead in
+// two register sets), quantizes it - a block of 16 = two neighbouring lanes, the maximum crosses with one DPP - and writes the
+// bf16 words both to the step's LDS slot (where the DMA would have put them: same source-side swizzle) and to the image the
+// GEMM reads.  One pass over x instead of two launches and a re-read of the image.  vmcnt counts loads, stores and LDS-DMA
+// together in issue order (MI355X_MICROARCH.md): behind a step's loads lie the previous step's 4 image stores and the next
+// step's 4 + NA requests.
+template <int DT, int NT>
+__global__ __launch_bounds__(256) void k_quant_xa128(const uint8_t* __restrict__ x, int64_t M, int64_t K, int64_t ldx_b, QP q,
+                                                     uint8_t* __restrict__ xq, int64_t Kp, const bf16_t* __restrict__ a_img,
+                                                     int row_groups, int nchunk, int steps_per_chunk, int steps_total,
+                                                     float* __restrict__ part) {
+  static_assert(DT == LQER_F16 || DT == LQER_BF16, "16-bit sources");
+  constexpr int RP = 32 * NT, AROW = 128, A_SLOT = RP * AROW, SLOT = X_SLOT + A_SLOT;
+  constexpr int NA = RP / 8 / 4;  // A^T pieces (8 rows x 128 B) per wave and step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r31 = lane & 31, h = lane >> 5;
+  const int tile = blockIdx.x / nchunk, c = blockIdx.x - tile * nchunk;
+  const int s_begin = c * steps_per_chunk;
+  const int s_end = s_begin + steps_per_chunk < steps_total ? s_begin + steps_per_chunk : steps_total;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
+  const int64_t row0 = (int64_t)tile * ROWS;
+  const int rows_here = (int)(M - row0 < ROWS ? M - row0 : ROWS);  // (>= 1: the grid has ceil(M / 128) tiles)
+  auto make_rs = [](const uint8_t* base, uint32_t range) {
+    const unsigned long long b64 = (unsigned long long)base;
+    return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64),
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) & 0xffffu,
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)range), 0x00020000u};
+  };
+  // rows of the tile beyond M read as zeros through the range check; the image has its padded rows
+  const u32x4 x_rs = make_rs(x + row0 * ldx_b, (uint32_t)(rows_here * ldx_b));
+  const u32x4 q_rs = make_rs(xq + row0 * Kp * 2, (uint32_t)(ROWS * Kp * 2));
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_img, 0, (int)(RP * Kp * 2), 0x00020000);
+  int gx_voff[4], qs_voff[4], kc[4], a_voff[4];
+  uint32_t ldw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int cs = (lane & 7) ^ ((row >> 1) & 7);  // the source chunk this lane's LDS position holds (k_xa_partial_lds's swizzle)
+    gx_voff[i] = row * (int)ldx_b + cs * 16;
+    qs_voff[i] = row * (int)Kp * 2 + cs * 16;
+    kc[i] = cs * 8;
+    ldw[i] = lds0 + (wave * 4 + i) * 1024 + lane * 16;
+    a_voff[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = 8 * (wave * NA + i) + (lane >> 3);
+    a_voff[i] = row * (int)Kp * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  // Every step issues the requests of step st + 2 - beyond the chunk with out-of-range offsets (zeros, no traffic; the LDS-DMA
+  // zero-fills a slot nobody reads) - so that ONE counted wait without a branch around it serves every step: a branch made
+  // hipcc copy the destination registers of the loads in front of the wait that retires them.
+  auto issue = [&](int st, u32x4& x0, u32x4& x1, u32x4& x2, u32x4& x3) {
+    const int slot = st % 3;
+    const int oob = st < s_end ? 0 : 0x40000000;  // (the voffset takes part in the range check)
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + slot * SLOT + X_SLOT + (wave * NA + i) * 1024), 16,
+                                               a_voff[i] | oob, st * AROW, 0, 0);
+    const int so = __builtin_amdgcn_readfirstlane(st * BKB);
+    asm volatile("buffer_load_dwordx4 %0, %4, %8, %9 offen\n\tbuffer_load_dwordx4 %1, %5, %8, %9 offen\n\t"
+                 "buffer_load_dwordx4 %2, %6, %8, %9 offen\n\tbuffer_load_dwordx4 %3, %7, %8, %9 offen"
+                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                 : "v"(gx_voff[0] | oob), "v"(gx_voff[1] | oob), "v"(gx_voff[2] | oob), "v"(gx_voff[3] | oob), "s"(x_rs), "s"(so)
+                 : "memory");
+  };
+  const int xrow = wave * 32 + r31;
+  uint32_t xa[4], aa[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xa[j] = lds0 + xrow * 128 + (((2 * j + h) ^ ((xrow >> 1) & 7)) << 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = 32 * t + r31;
+      aa[t][j] = lds0 + X_SLOT + n * 128 + (((2 * j + h) ^ ((n >> 1) & 7)) << 4);
+    }
+  }
+  f32x16 acc[4];  // (NT used; fixed sizes: an array sized by a template constant and captured by a lambda loses the kernel's host stub)
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  // quantize the lane's 8 values of piece i (step st), write LDS + image
+  auto quant_piece = [&](int st, int i, u32x4 wd) {
+    const bool valid = st * 64 + kc[i] < K;  // (k beyond K inside the padded step: zeros)
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = valid ? wd[j] : 0u;
+      if constexpr (DT == LQER_F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const h2 hv = __builtin_bit_cast(h2, u);
+        v[2 * j] = (float)hv[0], v[2 * j + 1] = (float)hv[1];
+      } else {
+        v[2 * j] = __uint_as_float(u << 16), v[2 * j + 1] = __uint_as_float(u & 0xffff0000u);
+      }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    // the block's other half lies in lane ^ 1 (chunks 2b, 2b + 1: the swizzle keeps the pair together)
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0xB1, 0xf, 0xf, true)));
+    const bool any = amax > 0.f;
+    const int e = block_exponent(any ? amax : 1.0f, q);
+    uint32_t w[4];
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!mxint16_fast_ok(e, q)) == 0, 1)) {
+      const float sc = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
+      const float inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
+      const float es = 1e-9f * sc, lo = -q.mneg, hi = q.mmax;
+      const f2 magic = {12582912.0f, 12582912.0f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // (mxint16_bf16_fast's arithmetic, common.h)
+        const f2 xv = {v[2 * j], v[2 * j + 1]};
+        const f2 cc = {copysignf(es, xv[0]), copysignf(es, xv[1])};
+        f2 r = (__builtin_elementwise_fma(xv, (f2){sc, sc}, cc) + magic) - magic;
+        r[0] = __builtin_amdgcn_fmed3f(r[0], lo, hi);
+        r[1] = __builtin_amdgcn_fmed3f(r[1], lo, hi);
+        const f2 val = r * (f2){inv, inv};
+        uint32_t b0 = __float_as_uint(val[0]), b1 = __float_as_uint(val[1]);
+        if constexpr (DT != LQER_F16) {  // (fp16 cannot hold a non-zero |x| <= 1e-8)
+          b0 = fabsf(xv[0]) <= 1e-8f ? 0u : b0;
+          b1 = fabsf(xv[1]) <= 1e-8f ? 0u : b1;
+        }
+        w[j] = any ? __builtin_amdgcn_perm(b1, b0, 0x07060302u) : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t b0 = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * j], e, q), e - q.mbits));
+        const uint32_t b1 = exact_bf16_bits(ldexpf(mxint_mantissa(v[2 * j + 1], e, q), e - q.mbits));
+        w[j] = any ? (b0 | (b1 << 16)) : 0u;
+      }
+    }
+    const u32x4 wv = {w[0], w[1], w[2], w[3]};
+    const int so = __builtin_amdgcn_readfirstlane(st * BKB);
+    // (s_nop: a VALU write of the data registers of a > 64-bit store needs a wait state the hazard recogniser cannot add here)
+    asm volatile("ds_write_b128 %0, %1\n\tbuffer_store_dwordx4 %1, %2, %3, %4 offen\n\ts_nop 1"
+                 :: "v"(ldw[i] + (uint32_t)((st % 3) * SLOT)), "v"(wv), "v"(qs_voff[i]), "s"(q_rs), "s"(so) : "memory");
+  };
+  auto body = [&](int st, u32x4& x0, u32x4& x1, u32x4& x2, u32x4& x3) {
+    // the step's own requests have landed: behind them lie at most the previous step's 4 image stores (waited for as well)
+    // and the next step's 4 + NA requests
+    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : [n] "n"(4 + NA) : "memory");
+    quant_piece(st, 0, x0), quant_piece(st, 1, x1), quant_piece(st, 2, x2), quant_piece(st, 3, x3);
+    // everybody's words of step st are in the slot (and every wave is past its reads of step st - 1, whose slot is filled next)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue(st + 2, x0, x1, x2, x3);
+    const uint32_t so = (uint32_t)((st % 3) * SLOT);
+    u32x4 xr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[j]) : "v"(xa[j] + so));
+    bf16x8 ar[4][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(ar[t][j]) : "v"(aa[t][j] + so));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ar[t][j]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, xr[j]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16<false>(xf, ar[t][j], acc[t]);
+    }
+  };
+  u32x4 p0, p1, p2, p3, q0, q1, q2, q3;  // the two register sets of source chunks in flight
+  issue(s_begin, p0, p1, p2, p3);
+  issue(s_begin + 1, q0, q1, q2, q3);
+  for (int st = s_begin; st < s_end; st += 2) {
+    body(st, p0, p1, p2, p3);
+    if (st + 1 < s_end) body(st + 1, q0, q1, q2, q3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last image stores)
+  const int rg = tile * 4 + wave;
+  if (rg < row_groups) {
+    float* dst = part + ((int64_t)c * row_groups + rg) * XA_ROWS * RP;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * h) * RP + 32 * t + r31] = acc[t][e];
+  }
+}
+
+template <int DT, int NT>
+static void launch_q(const void* x, int64_t M, int64_t K, int64_t ldx_b, const QP& q, bf16_t* xq, int64_t Kp, const bf16_t* a_img,
+                     int row_groups, int tiles, int nch, int spc, int steps_total, float* part, hipStream_t st) {
+  static LdsLimitOnce once;
+  once.set((const void*)k_quant_xa128<DT, NT>, lds_bytes(NT, false));
+  k_quant_xa128<DT, NT><<<(unsigned)(tiles * nch), 256, lds_bytes(NT, false), st>>>((const uint8_t*)x, M, K, ldx_b, q, (uint8_t*)xq, Kp,
+                                                                                   a_img, row_groups, nch, spc, steps_total, part);
+}
+
 template <int NT, bool I8>
 static void launch(const void* xq, int64_t x_ld, const bf16_t* a_img, int64_t Kp, int row_groups, int tiles, int nch, int spc,
                    int steps_total, float* part, hipStream_t st) {
@@ -736,12 +937,52 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
                             size_t scratch_bytes, hipStream_t st) {
   const int64_t Kp = lqer_padded_k(K);
   const int rp = (int)lqer_padded_r(r);
-  if (qx.kind != LQER_Q_MXINT || qx.block != 16 || qx.mbits > 8 || rp > 64 || qa.kind != LQER_Q_MXINT || qa.mbits > 8)
+  if (qx.kind != LQER_Q_MXINT || qx.block != 16 || qx.mbits > 8 || rp > 128 || qa.kind != LQER_Q_MXINT || qa.mbits > 8)
     return LQER_E_UNSUPPORTED;
   const int La = (qa.block <= 0 || qa.block >= rp) ? rp : qa.block;
   const int G = La / 4;
   if (rp % La != 0 || La % 4 != 0 || (G & (G - 1)) != 0 || G > 64) return LQER_E_UNSUPPORTED;
   if (M == 0) return LQER_OK;
+#ifndef LQER_NO_QXA128
+  if (rp > 64) {
+    // rank 65..128: 128-row tiles, both MFMA operands through LDS (xal::k_quant_xa128), the plan of the LDS-staged side GEMM
+    const int64_t ldx_b = ldx * 2;
+    if (rp % 32 != 0 || a_limbs != 1 || M < 512 || dtype == LQER_F32 || K % 8 != 0 || (uintptr_t)x % 16 != 0 || ldx_b % 16 != 0 ||
+        xal::ROWS * ldx_b >= 0x40000000)
+      return LQER_E_UNSUPPORTED;
+    const XaPlan base = xa_plan(M, Kp);
+    const int steps_total = (int)(Kp * 2 / xal::BKB), tiles = (int)((M + xal::ROWS - 1) / xal::ROWS);
+    int nch = LQER_XAL_WGS / tiles;
+    nch = nch < 1 ? 1 : (nch > base.nchunk ? base.nchunk : nch);
+    nch = nch < steps_total ? nch : steps_total;
+    const int spc = (steps_total + nch - 1) / nch;
+    nch = (steps_total + spc - 1) / spc;
+    XaPlan plan = base;
+    plan.nchunk = nch;
+    const size_t need = (size_t)nch * plan.row_groups * XA_ROWS * rp * sizeof(float);
+    if (!scratch || scratch_bytes < need) return LQER_E_UNSUPPORTED;
+    const int nt = rp / 32;
+#define QX128(DT) (nt == 3 ? xal::launch_q<DT, 3>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st) \
+                           : xal::launch_q<DT, 4>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st))
+    if (dtype == LQER_F16) QX128(LQER_F16); else QX128(LQER_BF16);
+#undef QX128
+    if (!xaq) return check_launch("quantize_act_xa");
+    const int64_t items = (int64_t)plan.row_groups * XA_ROWS * rp / 4;
+    const unsigned bs = items <= 128 * 256 ? 64 : 256;
+    const unsigned grid2 = (unsigned)((items + bs - 1) / bs);
+    switch (G) {
+      case 1: k_xa_reduce4<1><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+      case 2: k_xa_reduce4<2><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+      case 4: k_xa_reduce4<4><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+      case 8: k_xa_reduce4<8><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+      case 16: k_xa_reduce4<16><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+      default: k_xa_reduce4<32><<<grid2, bs, 0, st>>>(scratch, plan, rp, qa, xaq); break;
+    }
+    return check_launch("quantize_act_xa");
+  }
+#else
+  if (rp > 64) return LQER_E_UNSUPPORTED;
+#endif
   XaPlan plan;
   plan.row_groups = (int)((M + XA_ROWS - 1) / XA_ROWS);
   plan.nchunk = (int)((Kp + QX_K - 1) / QX_K);

@@ -48,6 +48,11 @@ CASES = [
     (200, 2048, 48, torch.float16, 16),    # three rank tiles
     (4096 + 8, 1024, 32, torch.float16, -1),  # A_out over the whole row
     (8192, 512, 32, torch.float16, 16),
+    # rank 65..128 at M >= 512: the 128-row fused kernel (xal::k_quant_xa128: quantizer + both MFMA operands through LDS)
+    (2048, 4096, 128, torch.float16, 16),   # C5
+    (700, 1096, 96, torch.bfloat16, 16),    # ragged last tile, K a multiple of 8 but not of 64 (padded step), three rank tiles
+    (1500, 1088, 128, torch.float16, -1),   # 17 steps over 15 chunks, A_out over the whole row
+    (640, 64, 128, torch.float16, 16),      # a single step
 ]
 
 
@@ -99,6 +104,17 @@ def test_side_path_vs_quantizer_and_oracle(ops, M, K, r, dtype, ablock):
     ref = O.mxint_quantize(torch.from_numpy(xq64).float() @ A, width=8, block_size=[1, ablock], skip_first_dim=True).numpy()
     print(f"xAq entries differing from the oracle's summation order: {(got != ref).mean():.4%}")
     assert (got != ref).mean() <= 0.03
+    # (2b) the fused routes against the two separate steps (standalone quantizer, then lqer_lowrank_xa on its image): where
+    # both walk the same K chunks in the same order - the 128-row kernels of rank 65..128 - the bits are the same
+    if rp > 64 and M >= 512:
+        img = torch.zeros(Mp, Kp, dtype=torch.bfloat16, device=DEV)
+        img[:M] = ref_img[:M]
+        xaq3 = torch.full((Mp, rp), 7.0, dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.lqer_lowrank_xa(C.byref(desc), img.data_ptr(), M, a_t.data_ptr(), a_limbs, xaq3.data_ptr(), scr.data_ptr(), nscr,
+                                     None), "lowrank_xa")
+        torch.cuda.synchronize()
+        assert torch.equal(xaq3[:M, :r].view(torch.int16), xaq[:M, :r].view(torch.int16))
+        assert float(xq[:M, K:].float().abs().max()) == 0.0 if Kp > K else True  # (the padded k of the image are zeros)
     # (3) run-to-run bit stability (fixed-order combine), fresh output buffers
     xq2, xaq2 = torch.zeros_like(xq), torch.zeros_like(xaq)
     run(xq2, xaq2)
