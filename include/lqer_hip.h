@@ -208,7 +208,8 @@ int lqer_debug_set_xcd_block(int token_tiles);
  * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */
 /* x_quantizer + side path in one call: xq and (rank > 0) xaq.  Uses a fused kernel (the activation
  * image is quantized and multiplied by A from LDS, never re-read from HBM) when x blocks are 16 and the
- * padded rank <= 64, the two separate steps otherwise.  scratch as for lqer_lowrank_xa.            */
+ * padded rank <= 64 - or <= 128 from 512 tokens on, with 16-byte aligned 16-bit rows -, the two separate
+ * steps otherwise (same bits).  scratch as for lqer_lowrank_xa.                                      */
 int lqer_quantize_act_xa(const lqer_linear_desc_t* desc, const void* x, int dtype, int64_t M,
                          int64_t ldx, const void* a_t, int a_limbs, void* xq_bf16, void* xaq_bf16,
                          void* scratch, size_t scratch_bytes, void* stream);

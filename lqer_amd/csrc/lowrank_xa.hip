@@ -429,14 +429,19 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
 // GEMM reads.  One pass over x instead of two launches and a re-read of the image.  vmcnt counts loads, stores and LDS-DMA
 // together in issue order (MI355X_MICROARCH.md): behind a step's loads lie the previous step's 4 image stores and the next
 // step's 4 + NA requests.
-template <int DT, int NT>
-__global__ __launch_bounds__(256) void k_quant_xa128(const uint8_t* __restrict__ x, int64_t M, int64_t K, int64_t ldx_b, QP q,
-                                                     uint8_t* __restrict__ xq, int64_t Kp, const bf16_t* __restrict__ a_img,
-                                                     int row_groups, int nchunk, int steps_per_chunk, int steps_total,
-                                                     float* __restrict__ part) {
+template <int DT, int NT, int WAVES>  // WAVES = 4: one wave per 32 rows, all rank tiles; 8: two waves per 32 rows, half the rank tiles each
+__global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __restrict__ x, int64_t M, int64_t K, int64_t ldx_b, QP q,
+                                                            uint8_t* __restrict__ xq, int64_t Kp, const bf16_t* __restrict__ a_img,
+                                                            int row_groups, int nchunk, int steps_per_chunk, int steps_total,
+                                                            float* __restrict__ part) {
   static_assert(DT == LQER_F16 || DT == LQER_BF16, "16-bit sources");
+  static_assert(WAVES == 4 || WAVES == 8, "4 or 8 waves");
   constexpr int RP = 32 * NT, AROW = 128, A_SLOT = RP * AROW, SLOT = X_SLOT + A_SLOT;
-  constexpr int NA = RP / 8 / 4;  // A^T pieces (8 rows x 128 B) per wave and step
+  constexpr int XP = 16 / WAVES;                   // activation pieces (8 rows x 128 B of image) a wave quantizes per step
+  constexpr int AP_ALL = RP / 8;                   // A^T pieces (8 rows x 128 B) per step
+  constexpr int AP = (AP_ALL + WAVES - 1) / WAVES; // per wave (a wave without a piece of its own repeats another one: same bytes)
+  constexpr int TG = WAVES / 4;                    // waves per 32-row group
+  constexpr int TW = (NT + TG - 1) / TG;           // rank tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -457,21 +462,23 @@ __global__ __launch_bounds__(256) void k_quant_xa128(const uint8_t* __restrict__
   const u32x4 x_rs = make_rs(x + row0 * ldx_b, (uint32_t)(rows_here * ldx_b));
   const u32x4 q_rs = make_rs(xq + row0 * Kp * 2, (uint32_t)(ROWS * Kp * 2));
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_img, 0, (int)(RP * Kp * 2), 0x00020000);
-  int gx_voff[4], qs_voff[4], kc[4], a_voff[4];
+  int gx_voff[4], qs_voff[4], kc[4], a_voff[4], a_piece[4];
   uint32_t ldw[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int piece = wave * XP + (i < XP ? i : 0);
+    const int row = piece * 8 + (lane >> 3);
     const int cs = (lane & 7) ^ ((row >> 1) & 7);  // the source chunk this lane's LDS position holds (k_xa_partial_lds's swizzle)
     gx_voff[i] = row * (int)ldx_b + cs * 16;
     qs_voff[i] = row * (int)Kp * 2 + cs * 16;
     kc[i] = cs * 8;
-    ldw[i] = lds0 + (wave * 4 + i) * 1024 + lane * 16;
-    a_voff[i] = 0;
+    ldw[i] = lds0 + piece * 1024 + lane * 16;
+    a_voff[i] = 0, a_piece[i] = 0;
   }
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int row = 8 * (wave * NA + i) + (lane >> 3);
+  for (int i = 0; i < AP; ++i) {
+    a_piece[i] = (wave + i * WAVES) % AP_ALL;
+    const int row = 8 * a_piece[i] + (lane >> 3);
     a_voff[i] = row * (int)Kp * 2 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
   }
   // Every step issues the requests of step st + 2 - beyond the chunk with out-of-range offsets (zeros, no traffic; the LDS-DMA
@@ -481,30 +488,39 @@ __global__ __launch_bounds__(256) void k_quant_xa128(const uint8_t* __restrict__
     const int slot = st % 3;
     const int oob = st < s_end ? 0 : 0x40000000;  // (the voffset takes part in the range check)
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + slot * SLOT + X_SLOT + (wave * NA + i) * 1024), 16,
-                                               a_voff[i] | oob, st * AROW, 0, 0);
+    for (int i = 0; i < AP; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + slot * SLOT + X_SLOT + a_piece[i] * 1024), 16, a_voff[i] | oob,
+                                               st * AROW, 0, 0);
     const int so = __builtin_amdgcn_readfirstlane(st * BKB);
-    asm volatile("buffer_load_dwordx4 %0, %4, %8, %9 offen\n\tbuffer_load_dwordx4 %1, %5, %8, %9 offen\n\t"
-                 "buffer_load_dwordx4 %2, %6, %8, %9 offen\n\tbuffer_load_dwordx4 %3, %7, %8, %9 offen"
-                 : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-                 : "v"(gx_voff[0] | oob), "v"(gx_voff[1] | oob), "v"(gx_voff[2] | oob), "v"(gx_voff[3] | oob), "s"(x_rs), "s"(so)
-                 : "memory");
+    if constexpr (XP == 4)
+      asm volatile("buffer_load_dwordx4 %0, %4, %8, %9 offen\n\tbuffer_load_dwordx4 %1, %5, %8, %9 offen\n\t"
+                   "buffer_load_dwordx4 %2, %6, %8, %9 offen\n\tbuffer_load_dwordx4 %3, %7, %8, %9 offen"
+                   : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                   : "v"(gx_voff[0] | oob), "v"(gx_voff[1] | oob), "v"(gx_voff[2] | oob), "v"(gx_voff[3] | oob), "s"(x_rs), "s"(so)
+                   : "memory");
+    else
+      asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen"
+                   : "=&v"(x0), "=&v"(x1)
+                   : "v"(gx_voff[0] | oob), "v"(gx_voff[1] | oob), "s"(x_rs), "s"(so)
+                   : "memory");
   };
-  const int xrow = wave * 32 + r31;
+  // fragment reads: activation rows of this wave's 32-row group, rank tiles th * TW .. of the A^T slab
+  const int rgi = wave & 3, th = wave >> 2;
+  const int xrow = rgi * 32 + r31;
   uint32_t xa[4], aa[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     xa[j] = lds0 + xrow * 128 + (((2 * j + h) ^ ((xrow >> 1) & 7)) << 4);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int n = 32 * t + r31;
+      const int tt = th * TW + t < NT ? th * TW + t : NT - 1;  // (a tile slot beyond the rank: re-reads the last one, never stored)
+      const int n = 32 * tt + r31;
       aa[t][j] = lds0 + X_SLOT + n * 128 + (((2 * j + h) ^ ((n >> 1) & 7)) << 4);
     }
   }
-  f32x16 acc[4];  // (NT used; fixed sizes: an array sized by a template constant and captured by a lambda loses the kernel's host stub)
+  f32x16 acc[4];  // (TW used; fixed sizes: an array sized by a template constant and captured by a lambda loses the kernel's host stub)
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
   typedef __attribute__((ext_vector_type(2))) float f2;
@@ -566,10 +582,15 @@ __global__ __launch_bounds__(256) void k_quant_xa128(const uint8_t* __restrict__
                  :: "v"(ldw[i] + (uint32_t)((st % 3) * SLOT)), "v"(wv), "v"(qs_voff[i]), "s"(q_rs), "s"(so) : "memory");
   };
   auto body = [&](int st, u32x4& x0, u32x4& x1, u32x4& x2, u32x4& x3) {
-    // the step's own requests have landed: behind them lie at most the previous step's 4 image stores (waited for as well)
-    // and the next step's 4 + NA requests
-    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : [n] "n"(4 + NA) : "memory");
-    quant_piece(st, 0, x0), quant_piece(st, 1, x1), quant_piece(st, 2, x2), quant_piece(st, 3, x3);
+    // the step's own requests have landed: behind them lie at most the previous step's XP image stores (waited for as well)
+    // and the next step's XP + AP requests
+    if constexpr (XP == 4) {
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : [n] "n"(XP + AP) : "memory");
+      quant_piece(st, 0, x0), quant_piece(st, 1, x1), quant_piece(st, 2, x2), quant_piece(st, 3, x3);
+    } else {
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x0), "+v"(x1) : [n] "n"(XP + AP) : "memory");
+      quant_piece(st, 0, x0), quant_piece(st, 1, x1);
+    }
     // everybody's words of step st are in the slot (and every wave is past its reads of step st - 1, whose slot is filled next)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     issue(st + 2, x0, x1, x2, x3);
@@ -579,46 +600,54 @@ __global__ __launch_bounds__(256) void k_quant_xa128(const uint8_t* __restrict__
     for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(xr[j]) : "v"(xa[j] + so));
     bf16x8 ar[4][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(ar[t][j]) : "v"(aa[t][j] + so));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < TW; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ar[t][j]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bf16x8 xf = __builtin_bit_cast(bf16x8, xr[j]);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = mfma_32x32x16<false>(xf, ar[t][j], acc[t]);
+      for (int t = 0; t < TW; ++t) acc[t] = mfma_32x32x16<false>(xf, ar[t][j], acc[t]);
     }
   };
-  u32x4 p0, p1, p2, p3, q0, q1, q2, q3;  // the two register sets of source chunks in flight
+  u32x4 p0, p1, p2, p3, q0, q1, q2, q3;  // the two register sets of source chunks in flight (XP of each used)
   issue(s_begin, p0, p1, p2, p3);
   issue(s_begin + 1, q0, q1, q2, q3);
   for (int st = s_begin; st < s_end; st += 2) {
     body(st, p0, p1, p2, p3);
     if (st + 1 < s_end) body(st + 1, q0, q1, q2, q3);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last image stores)
-  const int rg = tile * 4 + wave;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last image stores and the requests past the chunk)
+  const int rg = tile * 4 + rgi;
   if (rg < row_groups) {
     float* dst = part + ((int64_t)c * row_groups + rg) * XA_ROWS * RP;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < TW; ++t) {
+      const int tt = th * TW + t;
+      if (tt < NT) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * h) * RP + 32 * t + r31] = acc[t][e];
+        for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2) + 4 * h) * RP + 32 * tt + r31] = acc[t][e];
+      }
+    }
   }
 }
 
+#ifndef LQER_QXA128_WAVES
+#define LQER_QXA128_WAVES 8
+#endif
 template <int DT, int NT>
 static void launch_q(const void* x, int64_t M, int64_t K, int64_t ldx_b, const QP& q, bf16_t* xq, int64_t Kp, const bf16_t* a_img,
                      int row_groups, int tiles, int nch, int spc, int steps_total, float* part, hipStream_t st) {
+  constexpr int W = LQER_QXA128_WAVES;
   static LdsLimitOnce once;
-  once.set((const void*)k_quant_xa128<DT, NT>, lds_bytes(NT, false));
-  k_quant_xa128<DT, NT><<<(unsigned)(tiles * nch), 256, lds_bytes(NT, false), st>>>((const uint8_t*)x, M, K, ldx_b, q, (uint8_t*)xq, Kp,
-                                                                                   a_img, row_groups, nch, spc, steps_total, part);
+  once.set((const void*)k_quant_xa128<DT, NT, W>, lds_bytes(NT, false));
+  k_quant_xa128<DT, NT, W><<<(unsigned)(tiles * nch), 64 * W, lds_bytes(NT, false), st>>>((const uint8_t*)x, M, K, ldx_b, q, (uint8_t*)xq, Kp,
+                                                                                         a_img, row_groups, nch, spc, steps_total, part);
 }
 
 template <int NT, bool I8>
