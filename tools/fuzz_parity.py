@@ -21,12 +21,12 @@ def one_case(rng):
         M = rng.choice([2048, 2304, 4096])
     K = rng.choice([16, 48, 64, 100, 176, 256, 320, 520, 1000])
     N = rng.choice([16, 40, 160, 256, 300, 1024, 1500]) if kind != "m256" else rng.choice([8192, 16384 + 256])
-    r = rng.choice([0, 8, 16, 32, 48, 64, 128])
+    r = rng.choice([0, 8, 16, 32, 48, 64, 96, 128])
     cfgname = rng.choice(["mxint", "opt", "int", "bout_pass", "a16", "a16", "a16mix"])
     dtype = rng.choice([torch.float16, torch.float16, torch.bfloat16, torch.float32])
     if kind == "m256":
         K = rng.choice([64, 128, 200, 320, 520, 1000])
-        r = rng.choice([0, 16, 32, 64, 128])
+        r = rng.choice([0, 16, 32, 64, 96, 128])
         dtype = torch.float16
     return M, K, N, r, cfgname, dtype
 
