@@ -12,6 +12,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
   rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/$OUT/pass$i -- python3 $R/bench.py --workload $W --layers 1 --steps 2 --warmup 1 \
-      --prewarm-ms 0 --no-cpu-baseline --no-check --no-module "$@" > $R/gpurun_out/$OUT/pass$i.log 2>&1
+      --prewarm-ms 0 --no-cpu-baseline --no-check --no-module --no-two-streams "$@" > $R/gpurun_out/$OUT/pass$i.log 2>&1
 done
 python3 $R/tools/pmc_traffic.py $R/gpurun_out/$OUT $W > $R/gpurun_out/$OUT/summary_$W.json

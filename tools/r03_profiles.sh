@@ -10,7 +10,7 @@ for w in "$@"; do
   extra="--layers 1 --steps 4 --warmup 1"
   [ $w = c2 ] && extra="--steps 50 --warmup 10"
   [ $w = d1 -o $w = d16 ] && extra="--steps 96 --warmup 48"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -- python3 $R/bench.py --workload $w $extra --no-cpu-baseline --no-module \
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -- python3 $R/bench.py --workload $w $extra --no-cpu-baseline --no-module --no-two-streams \
       > $O/bench_under_rocprof_$w.json 2> $O/trace_$w.err
   cp $(find $O/trace_$w -name '*kernel_stats.csv' | head -1) $O/kernel_stats_$w.csv
   rm -rf $O/trace_$w
