@@ -646,7 +646,8 @@ def main():
     # per group (lqer_amd.linear.SharedActivation; same quantizers and GEMM kernels, results as member by member).  The
     # headline `value` stays the conservative one: every Linear quantizes its own input, as the reference's modules do.
     model_shared = None
-    if not args.no_module and layers > 1 and layers_here > 0:
+    # (secondary figures are single-rank only: a rank that fails or owns no layer would leave the others in a collective)
+    if not args.no_module and layers > 1 and layers_here > 0 and world == 1:
         import copy
 
         from lqer_amd.linear import SharedActivation
@@ -689,7 +690,7 @@ def main():
     # run under the other forward's main loop.  A throughput figure for sweeps and serving batches; `value` stays the
     # one-stream figure (a model's Linears form a chain: 8d sums their times)
     two_streams = None
-    if not args.no_two_streams and layers_here > 0 and M > 64 and graph is None:
+    if not args.no_two_streams and layers_here > 0 and M > 64 and graph is None and world == 1:
         try:
             s2 = torch.cuda.Stream(dev)
             ws2 = torch.empty(ws.numel(), dtype=torch.uint8, device=dev)
