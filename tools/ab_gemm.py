@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--bout", type=int, default=1, help="1: B_out MXINT8/16, 0: passthrough, 2: MXINT8, one block per row (pre-pass)")
     ap.add_argument("--xcd-bm", type=int, nargs="*", default=[], help="also time every build with XCD-local tile blocks of this many "
                     "token tiles (lqer_debug_set_xcd_block; 128-row kernel)")
+    ap.add_argument("--no-persist", action="store_true", help="also time every build with the persistent tile loop off (lqer_debug_set_gemm_persistent)")
     ap.add_argument("--blimbs", type=int, default=1, help="bf16 limbs of B (1: MXINT8 values, 2: fp16 values)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -47,6 +48,8 @@ def main():
     b_limbs = op["b_limbs"]
     libs = [(p, load(p)) for p in a.libs]
     base = list(libs)
+    if a.no_persist:
+        libs += [(f"{p} [one workgroup per tile]", L) for p, L in base if hasattr(L, "lqer_debug_set_gemm_persistent")]
     for bm in a.xcd_bm:
         libs += [(f"{p} [xcd block {bm}]", L) for p, L in base if hasattr(L, "lqer_debug_set_xcd_block")]
     bm_of = lambda p: int(p.rsplit("[xcd block ", 1)[1][:-1]) if p.endswith("]") and "[xcd block " in p else 0
@@ -54,9 +57,11 @@ def main():
 
     scr, nscr = op["scr"], op["nscr"]
 
-    def run(L, bm=0):
+    def run(L, bm=0, persist=1):
         if hasattr(L, "lqer_debug_set_xcd_block"):
             L.lqer_debug_set_xcd_block(bm)
+        if hasattr(L, "lqer_debug_set_gemm_persistent"):
+            L.lqer_debug_set_gemm_persistent(persist)
         rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr() if r else None,
                                 bt.data_ptr() if r else None, b_limbs, None, y.data_ptr(), _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
@@ -64,14 +69,14 @@ def main():
     times = {p: [] for p, _ in libs}
     for p, L in libs:
         for _ in range(5):
-            run(L, bm_of(p))
+            run(L, bm_of(p), 0 if p.endswith('[one workgroup per tile]') else 1)
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for p, L in libs:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                run(L, bm_of(p))
+                run(L, bm_of(p), 0 if p.endswith('[one workgroup per tile]') else 1)
             e1.record()
             torch.cuda.synchronize()
             times[p].append(e0.elapsed_time(e1) / a.iters * 1e3)
