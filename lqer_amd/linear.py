@@ -158,6 +158,9 @@ class _LinearBase(nn.Linear):
         # copy.deepcopy / pickle: the per-token-count launch cache holds raw device pointers of THIS module's images
         st = self.__dict__.copy()
         st["_fw_cache"] = {}
+        # the copy's parameters are new tensors with version counters of their own: its first forward adopts them instead of
+        # mistaking the copy for an in-place write (which would quantize the already quantized weight a second time)
+        st["_w_ver"] = None
         return st
 
     # -- derived buffers -------------------------------------------------------------------------
@@ -339,10 +342,12 @@ class _LinearBase(nn.Linear):
 
     @torch.no_grad()
     def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
-        if self._w_ver is not None:  # the dense parameters were written in place since their images were built
-            wv, bv = self._w_ver
-            if self.weight._version != wv or (bv is not None and self.bias._version != bv):
-                self.invalidate_packed(weight_changed=self.weight._version != wv, bias_changed=True)
+        if self._packed is not None:
+            cur = (self.weight._version, None if self.bias is None else self.bias._version)
+            if self._w_ver is None:  # first forward after copy.deepcopy / unpickling: the copied images belong to these parameters
+                self._w_ver = cur
+            elif cur != self._w_ver:  # the dense parameters were written in place since their images were built
+                self.invalidate_packed(weight_changed=cur[0] != self._w_ver[0], bias_changed=True)
         if self._packed is None or self.w_is_quantized is False:
             self._pack()
         K, N = self.in_features, self.out_features

@@ -105,6 +105,40 @@ def test_new_weights_written_in_place_are_requantized(lq):
     assert m.w_is_quantized and torch.equal(m(xd), want)
 
 
+def test_deepcopy_and_pickle_keep_the_quantized_once_weight(lq):
+    """copy.deepcopy / pickle of a module that has run: the copy's parameters are new tensors (fresh version counters) - it must
+    keep the copied images and the weight quantized ONCE (block_fp quantization is not idempotent on these weights), not take
+    the copy for an in-place write and quantize the already quantized weight again."""
+    import copy
+    import io
+
+    from bench import OPT_Q, make_case
+
+    M, K, N, r = 40, 256, 192, 32
+    x, _, A, B, b = make_case(M, K, N, r, seed=5, bias=True)
+    W = _non_idempotent_weight(N, K, seed=2)
+    mod = lq.LinearFlexibleLqer(K, N, bias=True, q_config=OPT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B, "bias": b})
+    mod = mod.to(DEV).half()
+    xd = x.half().to(DEV)
+    y0 = mod(xd).clone()
+    ref = O.lqer_linear_forward(x.half().float(), W.half().float(), b.half().float(), A.half().float(), B.half().float(), OPT_Q)
+    assert float((y0.float().cpu() - ref).norm() / ref.norm()) <= 1e-3
+    cp = copy.deepcopy(mod)
+    assert torch.equal(cp(xd), y0) and torch.equal(cp(xd), y0)
+    assert torch.equal(cp.weight, mod.weight)  # (still the once-quantized values)
+    buf = io.BytesIO()
+    torch.save(mod, buf)
+    buf.seek(0)
+    ld = torch.load(buf, weights_only=False)
+    assert torch.equal(ld(xd), y0)
+    # the copy still notices its OWN in-place writes
+    with torch.no_grad():
+        cp.weight.copy_(torch.zeros_like(cp.weight))
+    y_side = cp(xd)
+    assert not torch.equal(y_side, y0) and torch.equal(mod(xd), y0)
+
+
 def test_bias_is_quantized_exactly_once(lq):
     from bench import OPT_Q, make_case
 
