@@ -692,7 +692,8 @@ def main():
     two_streams = None
     if not args.no_two_streams and layers_here > 0 and M > 64 and graph is None and world == 1:
         try:
-            s2 = torch.cuda.Stream(dev)
+            # (two explicit streams: the legacy default stream this script otherwise launches on serialises with every other stream)
+            s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
             ws2 = torch.empty(ws.numel(), dtype=torch.uint8, device=dev)
             plans2, ys2 = [], []
             for pl in plans:
@@ -706,7 +707,7 @@ def main():
             unit_no, on_b = [0], set()
 
             def step_two():
-                ra, rb = calls_for(stream), calls_for(s2.cuda_stream, plans2)
+                ra, rb = calls_for(s1.cuda_stream), calls_for(s2.cuda_stream, plans2)
                 for i, ((reps, K, N, pa), (_, _, _, pb)) in enumerate(zip(ra, rb)):
                     for u in range(reps):
                         if unit_no[0] % 2:
@@ -717,6 +718,7 @@ def main():
                         if rc:
                             _lib.check(rc, "two-stream step")
 
+            s1.wait_stream(torch.cuda.current_stream(dev))
             s2.wait_stream(torch.cuda.current_stream(dev))
             for _ in range(max(2, args.warmup // 2)):
                 step_two()

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--carve", action="store_true", help="one buffer per stream, carved into image / x A / scratch the way bench.py does")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
@@ -48,6 +49,11 @@ def main():
     bufs = [dict(xq=torch.empty(Mp, Kp, dtype=torch.bfloat16, device=dev), xaq=torch.empty(Mp, rp, dtype=torch.bfloat16, device=dev),
                  scr=torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev), y=torch.empty(M, N, dtype=torch.float16, device=dev))
             for _ in range(S)]
+    if a.carve:
+        for b in bufs:
+            n1, n2 = Mp * Kp * 2, (Mp * rp * 2 + 255) // 256 * 256
+            big = torch.empty(n1 + n2 + max(nscr, 16), dtype=torch.uint8, device=dev)
+            b["big"], b["xq"], b["xaq"], b["scr"] = big, big[:n1], big[n1:n1 + n2], big[n1 + n2:]
 
     def fwd(i):
         b, st = bufs[i], streams[i].cuda_stream
