@@ -148,3 +148,26 @@ def test_module_forward_at_a_prefill_size_captures_in_a_graph(ops):
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(y1, y0)
+
+
+def test_fused_rank128_quantizer_takes_strided_rows_and_unaligned_views(ops):
+    """The 128-row fused quantizer reads its 16-bit source through the row stride it is given: a view into a wider tensor (rows
+    16-byte aligned) equals the dense tensor; a view whose rows are NOT 16-byte aligned takes the two separate kernels - same bits."""
+    import lqer_amd
+    from bench import OPT_Q, make_case
+
+    M, K, N, r = 640, 512, 256, 128
+    x, W, A, B, b = make_case(M, K, N, r, seed=11, bias=True)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=True, q_config=OPT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B, "bias": b})
+    mod = mod.to(DEV).half()
+    xd = x.half().to(DEV)
+    y = mod(xd)
+    wide = torch.zeros(M, K + 64, dtype=torch.float16, device=DEV)
+    wide[:, 8:8 + K] = xd
+    assert torch.equal(mod(wide[:, 8:8 + K]), y)      # rows start 16 bytes into a 1152-byte pitch: aligned, strided
+    wide2 = torch.zeros(M, K + 68, dtype=torch.float16, device=DEV)
+    wide2[:, 3:3 + K] = xd
+    assert torch.equal(mod(wide2[:, 3:3 + K]), y)     # 6 bytes in: not 16-byte aligned -> the separate kernels
+    ref = O.lqer_linear_forward(x.half().float(), W.half().float(), b.half().float(), A.half().float(), B.half().float(), OPT_Q)
+    assert float((y.float().cpu() - ref).norm() / ref.norm()) <= 1e-3
