@@ -446,6 +446,13 @@ class SharedActivation:
         self._cat, self._x, self._cur, self._served = None, None, None, set()
         self._plans = {}
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle (a whole model is copied with its groups): the launch plans and the current round hold raw device
+        # pointers of THIS group's members and of the shared pool - the copy rebuilds them at its first call
+        st = self.__dict__.copy()
+        st.update(_cat=None, _x=None, _cur=None, _served=set(), _plans={}, _ver=-1)
+        return st
+
     @classmethod
     def release_pool(cls):
         """Free the shared image pools of every (device, stream) - they are grow-only and outlive the models that used them."""

@@ -245,6 +245,50 @@ def test_shared_activation_groups_share_one_image_pool(lq):
     assert not SharedActivation._pool
 
 
+def test_deepcopy_of_a_model_with_shared_activation_groups(lq):
+    """A deep copy of a model copies its groups with it (the members point at their group): the copy's group must not keep the
+    original's launch plans - raw device pointers of the ORIGINAL members' images - once the original is gone."""
+    import copy
+    import gc
+
+    from bench import MXINT_Q, make_case
+    from lqer_amd.linear import SharedActivation
+
+    M, K, N, r = 96, 256, 192, 32
+
+    class QKV(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            mods = []
+            for i in range(3):
+                _, W, A, B = make_case(M, K, N, r, seed=20 + i)
+                m = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+                m.load_state_dict({"weight": W, "A": A, "B": B})
+                mods.append(m)
+            self.q, self.k, self.v = mods
+
+        def forward(self, x):
+            return self.q(x), self.k(x), self.v(x)
+
+    net = QKV().to(DEV).half()
+    grp = SharedActivation([net.q, net.k, net.v])
+    assert grp.enabled
+    x = make_case(M, K, N, r, seed=1)[0].half().to(DEV)
+    y0 = [t.clone() for t in net(x)]
+    y0b = [t.clone() for t in net(x)]
+    assert all(torch.equal(a, b) for a, b in zip(y0, y0b))
+    cp = copy.deepcopy(net)
+    assert cp.q._group is not grp and cp.q._group is cp.k._group and cp.q._group.members[0] is cp.q
+    del net, grp
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = torch.full((64 << 20,), 0x7F, dtype=torch.uint8, device=DEV)  # (what the freed images' memory may now hold)
+    y1 = cp(x)
+    assert all(torch.equal(a, b) for a, b in zip(y0, y1))
+    assert cp.q._group._cur is not None  # (served through the copy's own group)
+    del junk
+
+
 @pytest.mark.parametrize("r,members,enabled", [(128, 3, False), (128, 2, True), (80, 3, True)])
 def test_shared_activation_respects_the_side_gemm_rank_limit(lq, r, members, enabled):
     """The concatenated side GEMM takes a padded rank of at most 256: q/k/v of OPT-6.7B at rank 128 (384) cannot share one
