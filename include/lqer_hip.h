@@ -146,6 +146,12 @@ int lqer_linear_sizes(const lqer_linear_desc_t* desc, int64_t m_max, lqer_linear
  * {0,2,4,6,1,3,5,7}.  |w| <= 1e-8 is flushed to code 0.  `scratch` needs N*ceil(K/16) bytes.   */
 int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64_t ldw,
                            const lqer_qfmt_t* fmt, void* w_packed, void* scratch, void* stream);
+/* The same for 2-D tiles (w_quantizer block_size [R, L] with skip_first_dim = false, reference quantizers/utils.py:161-183):
+ * one exponent per tile of `block_rows` weight rows x fmt->block k (block_rows <= 0 or >= N: all rows; 1 = the call above).  The
+ * image layout does not change - a tile's exponent is repeated for each of its rows - so every GEMM route reads it as it is. */
+int lqer_pack_weight_mxint_2d(const void* W, int dtype, int64_t N, int64_t K, int64_t ldw,
+                              const lqer_qfmt_t* fmt, int64_t block_rows, void* w_packed, void* scratch,
+                              void* stream);
 
 /* Test hook: packed panels -> dequantized fp32 [N,K]. */
 int lqer_unpack_weight_mxint(const void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* fmt,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "lqer_quantize_act_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp]),
     "lqer_linear_sizes": (_i, [_dp, _i64, C.POINTER(LinearSizes)]),
     "lqer_pack_weight_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp, _vp]),
+    "lqer_pack_weight_mxint_2d": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _i64, _vp, _vp, _vp]),
     "lqer_unpack_weight_mxint": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),
     "lqer_pack_lowrank": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "lqer_pack_bias": (_i, [_vp, _i, _i64, _qp, _vp, _vp]),

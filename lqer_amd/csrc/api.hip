@@ -294,7 +294,21 @@ int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64
     set_error("w_quantizer: only block_fp weights can be packed");
     return LQER_E_UNSUPPORTED;
   }
-  return pack_weight_dispatch(W, dtype, N, K, ldw, make_qp(*fmt), w_packed, scratch, (hipStream_t)stream);
+  return pack_weight_dispatch(W, dtype, N, K, ldw, make_qp(*fmt), 1, w_packed, scratch, (hipStream_t)stream);
+}
+
+int lqer_pack_weight_mxint_2d(const void* W, int dtype, int64_t N, int64_t K, int64_t ldw, const lqer_qfmt_t* fmt, int64_t block_rows,
+                              void* w_packed, void* scratch, void* stream) {
+  if (!W || !w_packed || !scratch || N <= 0 || K <= 0 || ldw < K) {
+    set_error("pack_weight: bad argument");
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
+  if (fmt->kind != LQER_Q_MXINT) {
+    set_error("w_quantizer: only block_fp weights can be packed");
+    return LQER_E_UNSUPPORTED;
+  }
+  return pack_weight_dispatch(W, dtype, N, K, ldw, make_qp(*fmt), block_rows == 0 ? -1 : block_rows, w_packed, scratch, (hipStream_t)stream);
 }
 
 int lqer_unpack_weight_mxint(const void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* fmt, float* w_f32,

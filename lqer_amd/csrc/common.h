@@ -418,7 +418,7 @@ struct GemmArgs {
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
                       const QuantOut& o, hipStream_t st);
-int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, void* out,
+int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, int64_t block_rows, void* out,
                          void* scratch, hipStream_t st);
 int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, float* out, hipStream_t st);
 int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r, void* a_t,

@@ -31,6 +31,19 @@ __global__ __launch_bounds__(256) void k_w_exps(const void* __restrict__ W, int6
   }
 }
 
+// pass 1b, 2-D tiles (block_size [R, L], reference quantizers/utils.py:161-183): the exponent of a tile is that of its largest
+// element = the largest of its rows' exponents (ceil(log2 .) is monotone; -128 marks all-zero row blocks and loses every max)
+__global__ __launch_bounds__(256) void k_w_exps_rows(int8_t* __restrict__ scratch, int64_t N, int64_t nblk, int64_t R) {
+  const int64_t groups = (N + R - 1) / R, total = groups * nblk;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t gr = idx / nblk, b = idx - gr * nblk;
+    const int64_t r1 = (gr + 1) * R < N ? (gr + 1) * R : N;
+    int e = -128;
+    for (int64_t row = gr * R; row < r1; ++row) e = scratch[row * nblk + b] > e ? scratch[row * nblk + b] : e;
+    for (int64_t row = gr * R; row < r1; ++row) scratch[row * nblk + b] = (int8_t)e;
+  }
+}
+
 // pass 2: one lane per (padded row, 16-k segment)
 template <int DT>
 __global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int64_t N, int64_t K, int64_t ld, QP q,
@@ -119,7 +132,7 @@ __global__ void k_bias_passthrough(const void* __restrict__ b, int64_t N, int64_
 }
 
 template <int DT>
-static int pack_w(const void* W, int64_t N, int64_t K, int64_t ld, const QP& q, uint8_t* out, int8_t* scratch,
+static int pack_w(const void* W, int64_t N, int64_t K, int64_t ld, const QP& q, int64_t block_rows, uint8_t* out, int8_t* scratch,
                   hipStream_t st) {
   const int64_t Np = lqer_padded_n(N), Kp = lqer_padded_k(K);
   const int64_t L = (q.block <= 0 || q.block >= K) ? Kp : q.block;
@@ -129,6 +142,12 @@ static int pack_w(const void* W, int64_t N, int64_t K, int64_t ld, const QP& q, 
     const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     k_w_exps<DT><<<grid, 256, 0, st>>>(W, N, K, ld, q, L, nblk, scratch);
   }
+  if (block_rows != 1) {  // tiles of R rows (R <= 0 or >= N: all rows)
+    const int64_t R = (block_rows <= 0 || block_rows >= N) ? N : block_rows;
+    const int64_t total = ((N + R - 1) / R) * nblk;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    k_w_exps_rows<<<grid, 256, 0, st>>>(scratch, N, nblk, R);
+  }
   {
     const int64_t total = Np * (Kp / 16);
     const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
@@ -137,7 +156,7 @@ static int pack_w(const void* W, int64_t N, int64_t K, int64_t ld, const QP& q, 
   return check_launch("pack_weight");
 }
 
-int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, void* out,
+int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, int64_t block_rows, void* out,
                          void* scratch, hipStream_t st) {
   if (q.mbits < 1 || q.mbits > 3) {
     set_error("packed weights hold 4-bit codes: w_quantizer width must be 2..4, got %d", q.mbits + 1);
@@ -148,9 +167,9 @@ int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t
     return LQER_E_UNSUPPORTED;
   }
   switch (dtype) {
-    case LQER_F32: return pack_w<LQER_F32>(W, N, K, ld, q, (uint8_t*)out, (int8_t*)scratch, st);
-    case LQER_F16: return pack_w<LQER_F16>(W, N, K, ld, q, (uint8_t*)out, (int8_t*)scratch, st);
-    case LQER_BF16: return pack_w<LQER_BF16>(W, N, K, ld, q, (uint8_t*)out, (int8_t*)scratch, st);
+    case LQER_F32: return pack_w<LQER_F32>(W, N, K, ld, q, block_rows, (uint8_t*)out, (int8_t*)scratch, st);
+    case LQER_F16: return pack_w<LQER_F16>(W, N, K, ld, q, block_rows, (uint8_t*)out, (int8_t*)scratch, st);
+    case LQER_BF16: return pack_w<LQER_BF16>(W, N, K, ld, q, block_rows, (uint8_t*)out, (int8_t*)scratch, st);
   }
   set_error("unknown dtype %d", dtype);
   return LQER_E_INVALID;

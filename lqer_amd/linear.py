@@ -310,7 +310,11 @@ class _LinearBase(nn.Linear):
             else:
                 w_img = self._w_single = ops.pack_weight(W, f["w"])
                 # the parameter now carries w_quantizer(W) (|w| <= 1e-8 kept as is, block_fp.py:79-80)
-                wq = ops.quantize_mxint(W, f["w"], want=("deq",))["deq"]
+                if int(getattr(f["w"], "block_rows", 1)) == 1:
+                    wq = ops.quantize_mxint(W, f["w"], want=("deq",))["deq"]
+                else:  # 2-D tiles: read the values back from the image just packed
+                    wq = ops.unpack_weight(w_img, self.out_features, self.in_features, f["w"])
+                    wq = torch.where(W.float().abs() <= 1e-8, W.float(), wq)
                 self.weight.data.copy_(wq.to(W.dtype))
             p = {"w": w_img}
             if self.bias is not None:

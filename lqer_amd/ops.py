@@ -57,8 +57,8 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
     1-D bias), because the reference right-aligns `block_size` to the tensor and `skip_first_dim` picks the blocking
     routine (quantizers/utils.py:42-67, :261-284).  The HIP path implements blocks that run along the last dim within
     one row: [1, L], or a one-entry [L] / [-1] where the reference reads it per row (activations and weights with
-    skip_first_dim = true - the default, block_fp.py:111-118 - and the bias).  Anything else (2-D tiles, e.g. a weight
-    with skip_first_dim = false and block_size [L] = all rows x L) raises instead of being silently read per row."""
+    skip_first_dim = true - the default, block_fp.py:111-118 - and the bias), and for the WEIGHT also 2-D tiles [R, L]
+    (skip_first_dim = false; a lone [L] then means all rows x L).  Anything else raises instead of being silently read per row."""
     if cfg is None:
         raise KeyError("quantizer config missing")
     name = cfg["name"]
@@ -82,16 +82,28 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
         if len(bs) > 1 and any(b != 1 for b in bs[:-1]):
             bs = bs[-1:]  # right-aligned to a 1-D tensor: only the last entry counts
     else:
-        if any(b != 1 for b in bs[:-1]):
-            raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path")
-        if len(bs) < 2 and not skip:
+        block_rows = 1
+        if role == "w" and not skip:
+            # the 2-D weight with skip_first_dim = false (quantizers/utils.py:161-183): [R, L] = tiles of R rows x L k, a lone [L]
+            # is right-aligned to [-1, L] = all rows x L (utils.py:42-67).  One exponent per tile, repeated per row in the image.
+            if len(bs) > 2 and any(b != 1 for b in bs[:-2]):
+                raise NotImplementedError(f"block_size {bs}: more entries than the weight has dims")
+            block_rows = int(bs[-2]) if len(bs) >= 2 else -1
+            if block_rows == 0:
+                raise ValueError(f"block_size {bs}: a block of 0 rows")
+        elif any(b != 1 for b in bs[:-1]):
+            raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path for '{role}'")
+        elif len(bs) < 2 and not skip:
             raise NotImplementedError(
                 f"block_size {bs} with skip_first_dim = false is right-aligned to [-1, {bs[-1]}] (2-D tiles over all rows, "
                 "quantizers/utils.py:42-67): only per-row blocks ([1, L], or [L] with skip_first_dim = true) are implemented")
     ew = int(cfg.get("exponent_width", 8))
     eb = cfg.get("exponent_bias", None)
     eb = 2 ** (ew - 1) - 1 if eb in (None, "none", "None", "NA") else int(eb)
-    return QFmt(_lib.Q_MXINT, int(cfg.get("width", 12)), int(bs[-1]), ew, eb)
+    fmt = QFmt(_lib.Q_MXINT, int(cfg.get("width", 12)), int(bs[-1]), ew, eb)
+    if role != "b" and block_rows != 1:
+        fmt.block_rows = block_rows  # (a Python attribute beside the C fields: only the packing call needs it)
+    return fmt
 
 
 @_on_tensor_device
@@ -147,6 +159,7 @@ def linear_sizes(desc: LinearDesc, m_max: int) -> LinearSizes:
 
 @_on_tensor_device
 def pack_weight(W: torch.Tensor, fmt: QFmt) -> torch.Tensor:
+    """W [N,K] -> packed panels.  A weight format with 2-D tiles carries its row count in `fmt.block_rows` (make_qfmt)."""
     _need_gpu(W)
     N, K = W.shape
     if W.stride(-1) != 1:
@@ -155,10 +168,14 @@ def pack_weight(W: torch.Tensor, fmt: QFmt) -> torch.Tensor:
     Np, Kp = L.lqer_padded_n(N), L.lqer_padded_k(K)
     packed = torch.empty((Np // 16) * (Kp // 64) * 576, dtype=torch.uint8, device=W.device)
     scratch = torch.empty(N * (-(-K // 16)), dtype=torch.int8, device=W.device)
-    check(
-        L.lqer_pack_weight_mxint(W.data_ptr(), dtype_code(W), N, K, W.stride(0), C.byref(fmt), packed.data_ptr(), scratch.data_ptr(), _stream(W.device)),
-        "lqer_pack_weight_mxint",
-    )
+    rows = int(getattr(fmt, "block_rows", 1))
+    if rows == 1:
+        rc = L.lqer_pack_weight_mxint(W.data_ptr(), dtype_code(W), N, K, W.stride(0), C.byref(fmt), packed.data_ptr(), scratch.data_ptr(),
+                                      _stream(W.device))
+    else:
+        rc = L.lqer_pack_weight_mxint_2d(W.data_ptr(), dtype_code(W), N, K, W.stride(0), C.byref(fmt), rows, packed.data_ptr(),
+                                         scratch.data_ptr(), _stream(W.device))
+    check(rc, "lqer_pack_weight_mxint")
     return packed
 
 

@@ -122,6 +122,13 @@ def main():
         g[f"int/w{w}f{f}/x"] = xi.numpy()
         g[f"int/w{w}f{f}/y"] = integer(xi.clone(), w, f, True).numpy()
 
+    # 2-D weight tiles (quantizers/utils.py:161-183; round 3 - drawn after every other vector so that those do not change):
+    # tiles of R rows x L k, ragged in both dims, and a lone [L] with skip_first_dim = false = all rows x L
+    add_q("w4_tile_8x16", 0.02 * torch.randn(40, 80), 4, [8, 16], False)
+    add_q("w4_tile_16x32_ragged", 0.02 * torch.randn(25, 72), 4, [16, 32], False)
+    add_q("w4_tile_allrows_16", 0.02 * torch.randn(20, 64), 4, [16], False)
+    add_q("w4_tile_4xrow", 0.02 * torch.randn(12, 48), 4, [4, -1], False)
+
     # the ceil(log2) rule: for every k, the number of ulps above 2^k that still give k
     thr = []
     for k in range(-126, 128):
@@ -198,6 +205,9 @@ def main():
         ("a16mix", (70, 128), 128, 160, 32, False, a16mix_q, None, False),
         ("intx", (12, 192), 192, 112, 32, True, intx_q, abq, False),
         ("intx70", (2, 35, 128), 128, 160, 16, False, intx5_q, None, True),
+        # 2-D weight tiles (round 3)
+        ("tile8", (7, 176), 176, 160, 32, True, dict(mxint_q, w_quantizer=bfp_cfg(4, [8, 16], False)), abq, False),
+        ("tileall", (70, 128), 128, 96, 16, False, dict(mxint_q, w_quantizer=bfp_cfg(4, [32], False)), abq, False),
     ]
     f = {}
     for name, xs, K, N, r, has_b, qc, abc, use_s in cases:

@@ -124,12 +124,18 @@ def test_make_qfmt_schema():
     assert ops.make_qfmt(dict(name="integer", width=8, frac_width=4), "B_out").kind == _lib.Q_INT  # (round 3: inside the tile kernels)
     # the role decides how a one-entry block_size is right-aligned (quantizers/utils.py:42-67, :261-284): per row for
     # activations / weights with skip_first_dim = true (the quantizer's default) and for the 1-D bias; a 2-D tensor with
-    # skip_first_dim = false reads [L] as tiles of ALL rows x L - not on the HIP path, and never silently per row
+    # skip_first_dim = false reads [L] as tiles of ALL rows x L - for the weight one exponent per tile at pack time (round 3:
+    # `block_rows` rides beside the C fields), for activations not on the HIP path; never silently per row
     w = dict(name="block_fp", width=4, block_size=[128], skip_first_dim=False)
-    with pytest.raises(NotImplementedError):
-        ops.make_qfmt(w, "w")
+    fw = ops.make_qfmt(w, "w")
+    assert fw.block == 128 and fw.block_rows == -1
+    ft = ops.make_qfmt(dict(w, block_size=[8, 32]), "w")
+    assert ft.block == 32 and ft.block_rows == 8
+    assert not hasattr(ops.make_qfmt(dict(w, block_size=[1, 16]), "w"), "block_rows")  # the templates' per-row blocks
     with pytest.raises(NotImplementedError):
         ops.make_qfmt(dict(w, width=8), "x")
+    with pytest.raises(NotImplementedError):
+        ops.make_qfmt(dict(w, width=8, block_size=[8, 16]), "x")
     assert ops.make_qfmt(dict(w, skip_first_dim=True), "w").block == 128
     assert ops.make_qfmt(dict(w, block_size=[1, 128]), "w").block == 128
     assert ops.make_qfmt(dict(name="block_fp", width=8, block_size=[16], skip_first_dim=False), "b").block == 16

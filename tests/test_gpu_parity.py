@@ -39,8 +39,8 @@ def _q_cases(golden_q):
         if x.ndim == 2 and len(block) == 2 and block[0] == 16 and block[1] == 1:
             out.append((name + "^T", x.t().contiguous(), y.t().contiguous(), width, 16))  # column blocks = row blocks of x^T
             continue
-        if any(b != 1 for b in block[:-1]):
-            continue  # 2-D tiles: not on the path
+        if any(b != 1 for b in block[:-1]) or (x.ndim == 2 and len(block) == 1 and not meta[1]):
+            continue  # 2-D tiles (a lone [L] without skip_first_dim = all rows x L): the weight packer's, test_pack_weight_2d_tiles_bit_exact
         out.append((name, x, y, width, block[-1]))
     return out
 
@@ -119,6 +119,22 @@ def test_pack_unpack_weight_bit_exact(ops, golden_q):
             assert torch.equal(packed.cpu(), want), name
 
 
+def test_pack_weight_2d_tiles_bit_exact(ops, golden_q):
+    """Weight tiles of R rows x L k (block_size [R, L], skip_first_dim = false; a lone [L] = all rows x L): the packed image,
+    read back, against the reference's vectors - ragged tiles in both dims included (quantizers/utils.py:161-183)."""
+    for name in ("w4_tile_8x16", "w4_tile_16x32_ragged", "w4_tile_allrows_16", "w4_tile_4xrow"):
+        x = torch.from_numpy(golden_q[f"q/{name}/x"])
+        y = torch.from_numpy(golden_q[f"q/{name}/y"])
+        meta = golden_q[f"q/{name}/meta"].tolist()
+        fmt = ops.make_qfmt(dict(name="block_fp", width=int(meta[0]), exponent_width=8, exponent_bias=None, block_size=meta[2:],
+                                 skip_first_dim=bool(meta[1])), "w")
+        assert getattr(fmt, "block_rows", 1) != 1
+        packed = ops.pack_weight(x.to(DEV), fmt)
+        w = ops.unpack_weight(packed, x.shape[0], x.shape[1], fmt).cpu()
+        ref = torch.where(x.abs() <= 1e-8, torch.zeros_like(y), y)
+        assert torch.equal(w, ref), name
+
+
 def test_pack_lowrank_limbs(ops):
     torch.manual_seed(5)
     K, N, r = 100, 70, 24
@@ -153,7 +169,7 @@ def _module_from_case(g, cfgs, name, dtype=torch.float32):
     return mod.to(DEV).to(dtype), t
 
 
-FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw", "a16", "a16row", "a16mix"]
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw", "a16", "a16row", "a16mix", "tile8", "tileall"]
 
 
 @pytest.mark.parametrize("name", FWD_CASES)

@@ -76,7 +76,7 @@ def test_integer_quantizer(golden_q):
         assert torch.equal(got, torch.from_numpy(golden_q[f"int/{tag}/y"]))
 
 
-FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "int128", "introw", "ragged", "a16", "a16row", "a16mix", "intx", "intx70"]
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "int128", "introw", "ragged", "a16", "a16row", "a16mix", "intx", "intx70", "tile8", "tileall"]
 
 
 @pytest.mark.parametrize("name", FWD_CASES)
