@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 7
+#define LQER_ABI_VERSION 8
 
 /* error codes */
 #define LQER_OK 0

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16

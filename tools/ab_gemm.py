@@ -17,8 +17,8 @@ from lqer_amd import _lib  # noqa: E402
 def load(path):
     L = C.CDLL(os.path.abspath(path))
     for name, (res, args) in _lib.SIGNATURES.items():
-        if name.startswith("lqer_debug_") and not hasattr(L, name):
-            continue  # (an older build without that test hook)
+        if not hasattr(L, name):
+            continue  # (an older build without that entry point / test hook)
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
     return L
