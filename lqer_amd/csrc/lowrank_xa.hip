@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
     const bool any = amax > 0.f;
     const int e = block_exponent(any ? amax : 1.0f, q);
     uint32_t w[4];
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!mxint16_fast_ok(e, q)) == 0, 1)) {
+    if (__builtin_expect(mxint16_fast_ok(e, q), 1)) {  // (per block, like the standalone quantizer: the two routes differ in the sign of a zero)
       const float sc = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
       const float inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
       const float es = 1e-9f * sc, lo = -q.mneg, hi = q.mmax;

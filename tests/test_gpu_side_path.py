@@ -68,6 +68,7 @@ def test_side_path_vs_quantizer_and_oracle(ops, M, K, r, dtype, ablock):
             x[:, c] *= 30.0
     x[min(5, M - 1)] = 0.0            # a zero row: every block takes the zero path
     x[min(9, M - 1), 16:32] = 3e-9    # values inside the reference's pass-through range (fp32 inputs keep them non-zero)
+    x[min(11, M - 1), 32:48] = 1e-37  # a block exponent outside the power-of-two fast path (bf16 / fp32 inputs; 0 in fp16)
     x = x.to(dtype)
     A = O.mxint_quantize(0.01 * torch.randn(K, r, generator=g), width=8, block_size=[16, 1], skip_first_dim=False)
     A = torch.where(A.abs() <= 1e-8, torch.zeros_like(A), A)  # (the reference's pass-through of |a| <= 1e-8 is not on the 8-bit grid)

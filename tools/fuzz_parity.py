@@ -22,7 +22,7 @@ def one_case(rng):
     K = rng.choice([16, 48, 64, 100, 176, 256, 320, 520, 1000])
     N = rng.choice([16, 40, 160, 256, 300, 1024, 1500]) if kind != "m256" else rng.choice([8192, 16384 + 256])
     r = rng.choice([0, 8, 16, 32, 48, 64, 96, 128])
-    cfgname = rng.choice(["mxint", "opt", "int", "bout_pass", "a16", "a16", "a16mix"])
+    cfgname = rng.choice(["mxint", "opt", "int", "bout_pass", "a16", "a16", "a16mix", "tile"])
     dtype = rng.choice([torch.float16, torch.float16, torch.bfloat16, torch.float32])
     if kind == "m256":
         K = rng.choice([64, 128, 200, 320, 520, 1000])
@@ -33,7 +33,8 @@ def one_case(rng):
 
 def run_case(M, K, N, r, cfgname, dtype, dev):
     qc = {"mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q, "bout_pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"}),
-          "a16": A16_Q, "a16mix": dict(A16_Q, B_out_quantizer=MXINT_Q["x_quantizer"])}[cfgname]
+          "a16": A16_Q, "a16mix": dict(A16_Q, B_out_quantizer=MXINT_Q["x_quantizer"]),
+          "tile": dict(MXINT_Q, w_quantizer=dict(MXINT_Q["w_quantizer"], block_size=[(M % 3 + 1) * 4, 16 * (K % 2 + 1)]))}[cfgname]
     bias = cfgname == "opt"
     case = make_case(M, K, N, max(r, 1), seed=M * 7919 + K * 31 + N, bias=bias, quantize_ab=cfgname not in ("int", "a16", "a16mix"))
     x, W, A, B = case[:4]
