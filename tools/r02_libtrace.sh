@@ -10,7 +10,7 @@ import os, sys, runpy
 sys.path.insert(0, "$R")
 from lqer_amd import _lib
 _lib.LIB_PATH = os.path.abspath("$R/$lib")
-sys.argv = ["bench.py", "--workload", "$W", "--layers", "2", "--no-cpu-baseline", "--no-check", "--no-module", "--steps", "20"]
+sys.argv = ["bench.py", "--workload", "$W", "--layers", "2", "--no-cpu-baseline", "--no-check", "--no-module", "--no-two-streams", "--steps", "20"]
 runpy.run_path("$R/bench.py", run_name="__main__")
 PY
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/t_$n -- python3 $O/run_$n.py > $O/bench_$n.json 2> $O/bench_$n.err
