@@ -429,18 +429,22 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
 // GEMM reads.  One pass over x instead of two launches and a re-read of the image.  vmcnt counts loads, stores and LDS-DMA
 // together in issue order (MI355X_MICROARCH.md): behind a step's loads lie the previous step's 4 image stores and the next
 // step's 4 + NA requests.
-template <int DT, int NT, int WAVES>  // WAVES = 4: one wave per 32 rows, all rank tiles; 8: two waves per 32 rows, half the rank tiles each
+template <int DT, int NT, int WAVES, int TROWS = ROWS>  // WAVES waves share TROWS / 32 row groups x NT rank tiles; TROWS = 128 or 64 token rows
 __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __restrict__ x, int64_t M, int64_t K, int64_t ldx_b, QP q,
                                                             uint8_t* __restrict__ xq, int64_t Kp, const bf16_t* __restrict__ a_img,
                                                             int row_groups, int nchunk, int steps_per_chunk, int steps_total,
                                                             float* __restrict__ part) {
   static_assert(DT == LQER_F16 || DT == LQER_BF16, "16-bit sources");
   static_assert(WAVES == 4 || WAVES == 8, "4 or 8 waves");
-  constexpr int RP = 32 * NT, AROW = 128, A_SLOT = RP * AROW, SLOT = X_SLOT + A_SLOT;
-  constexpr int XP = 16 / WAVES;                   // activation pieces (8 rows x 128 B of image) a wave quantizes per step
+  static_assert(TROWS == 128 || TROWS == 64, "128- or 64-row tiles");
+  constexpr int XS = TROWS * BKB;                  // the tile's activation slot
+  constexpr int RP = 32 * NT, AROW = 128, A_SLOT = RP * AROW, SLOT = XS + A_SLOT;
+  constexpr int XP = (TROWS / 8) / WAVES;          // activation pieces (8 rows x 128 B of image) a wave quantizes per step
+  static_assert(XP >= 1, "at most one wave per activation piece");
   constexpr int AP_ALL = RP / 8;                   // A^T pieces (8 rows x 128 B) per step
   constexpr int AP = (AP_ALL + WAVES - 1) / WAVES; // per wave (a wave without a piece of its own repeats another one: same bytes)
-  constexpr int TG = WAVES / 4;                    // waves per 32-row group
+  constexpr int NRG = TROWS / 32;                  // 32-row groups of the tile
+  constexpr int TG = WAVES / NRG;                  // waves per 32-row group
   constexpr int TW = (NT + TG - 1) / TG;           // rank tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
   const int s_begin = c * steps_per_chunk;
   const int s_end = s_begin + steps_per_chunk < steps_total ? s_begin + steps_per_chunk : steps_total;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  const int64_t row0 = (int64_t)tile * ROWS;
-  const int rows_here = (int)(M - row0 < ROWS ? M - row0 : ROWS);  // (>= 1: the grid has ceil(M / 128) tiles)
+  const int64_t row0 = (int64_t)tile * TROWS;
+  const int rows_here = (int)(M - row0 < TROWS ? M - row0 : TROWS);  // (>= 1: the grid has ceil(M / TROWS) tiles)
   auto make_rs = [](const uint8_t* base, uint32_t range) {
     const unsigned long long b64 = (unsigned long long)base;
     return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64),
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
   };
   // rows of the tile beyond M read as zeros through the range check; the image has its padded rows
   const u32x4 x_rs = make_rs(x + row0 * ldx_b, (uint32_t)(rows_here * ldx_b));
-  const u32x4 q_rs = make_rs(xq + row0 * Kp * 2, (uint32_t)(ROWS * Kp * 2));
+  const u32x4 q_rs = make_rs(xq + row0 * Kp * 2, (uint32_t)(TROWS * Kp * 2));
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_img, 0, (int)(RP * Kp * 2), 0x00020000);
   int gx_voff[4], qs_voff[4], kc[4], a_voff[4], a_piece[4];
   uint32_t ldw[4];
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
     const int oob = st < s_end ? 0 : 0x40000000;  // (the voffset takes part in the range check)
 #pragma unroll
     for (int i = 0; i < AP; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + slot * SLOT + X_SLOT + a_piece[i] * 1024), 16, a_voff[i] | oob,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + slot * SLOT + XS + a_piece[i] * 1024), 16, a_voff[i] | oob,
                                                st * AROW, 0, 0);
     const int so = __builtin_amdgcn_readfirstlane(st * BKB);
     if constexpr (XP == 4)
@@ -498,14 +502,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
                    : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
                    : "v"(gx_voff[0] | oob), "v"(gx_voff[1] | oob), "v"(gx_voff[2] | oob), "v"(gx_voff[3] | oob), "s"(x_rs), "s"(so)
                    : "memory");
-    else
+    else if constexpr (XP == 2)
       asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen"
                    : "=&v"(x0), "=&v"(x1)
                    : "v"(gx_voff[0] | oob), "v"(gx_voff[1] | oob), "s"(x_rs), "s"(so)
                    : "memory");
+    else
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(x0) : "v"(gx_voff[0] | oob), "s"(x_rs), "s"(so) : "memory");
   };
   // fragment reads: activation rows of this wave's 32-row group, rank tiles th * TW .. of the A^T slab
-  const int rgi = wave & 3, th = wave >> 2;
+  const int rgi = wave % NRG, th = wave / NRG;
   const int xrow = rgi * 32 + r31;
   uint32_t xa[4], aa[4][4];
 #pragma unroll
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
     for (int t = 0; t < 4; ++t) {
       const int tt = th * TW + t < NT ? th * TW + t : NT - 1;  // (a tile slot beyond the rank: re-reads the last one, never stored)
       const int n = 32 * tt + r31;
-      aa[t][j] = lds0 + X_SLOT + n * 128 + (((2 * j + h) ^ ((n >> 1) & 7)) << 4);
+      aa[t][j] = lds0 + XS + n * 128 + (((2 * j + h) ^ ((n >> 1) & 7)) << 4);
     }
   }
   f32x16 acc[4];  // (TW used; fixed sizes: an array sized by a template constant and captured by a lambda loses the kernel's host stub)
@@ -587,9 +593,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
     if constexpr (XP == 4) {
       asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : [n] "n"(XP + AP) : "memory");
       quant_piece(st, 0, x0), quant_piece(st, 1, x1), quant_piece(st, 2, x2), quant_piece(st, 3, x3);
-    } else {
+    } else if constexpr (XP == 2) {
       asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x0), "+v"(x1) : [n] "n"(XP + AP) : "memory");
       quant_piece(st, 0, x0), quant_piece(st, 1, x1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(x0) : [n] "n"(XP + AP) : "memory");
+      quant_piece(st, 0, x0);
     }
     // everybody's words of step st are in the slot (and every wave is past its reads of step st - 1, whose slot is filled next)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -623,7 +632,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
     if (st + 1 < s_end) body(st + 1, q0, q1, q2, q3);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last image stores and the requests past the chunk)
-  const int rg = tile * 4 + rgi;
+  const int rg = tile * NRG + rgi;
   if (rg < row_groups) {
     float* dst = part + ((int64_t)c * row_groups + rg) * XA_ROWS * RP;
 #pragma unroll
@@ -640,14 +649,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
 #ifndef LQER_QXA128_WAVES
 #define LQER_QXA128_WAVES 8
 #endif
+#ifndef LQER_QXA128_ROWS
+#define LQER_QXA128_ROWS 64  // 64-row tiles x twice the K per chunk: half the partial tiles to write and to reduce (-1.3 .. -1.7 us per
+#endif                      // rank-96 / 128 forward at K = 4096 against 128-row tiles; +-0 at K = 16384)
+constexpr int qx_rows = LQER_QXA128_ROWS;  // token rows per workgroup of the fused quantizer (its K chunks double at 64)
 template <int DT, int NT>
 static void launch_q(const void* x, int64_t M, int64_t K, int64_t ldx_b, const QP& q, bf16_t* xq, int64_t Kp, const bf16_t* a_img,
                      int row_groups, int tiles, int nch, int spc, int steps_total, float* part, hipStream_t st) {
-  constexpr int W = LQER_QXA128_WAVES;
+  constexpr int W = LQER_QXA128_WAVES, R = LQER_QXA128_ROWS;
+  constexpr int lds = 3 * (R * BKB + 32 * NT * 128);
   static LdsLimitOnce once;
-  once.set((const void*)k_quant_xa128<DT, NT, W>, lds_bytes(NT, false));
-  k_quant_xa128<DT, NT, W><<<(unsigned)(tiles * nch), 64 * W, lds_bytes(NT, false), st>>>((const uint8_t*)x, M, K, ldx_b, q, (uint8_t*)xq, Kp,
-                                                                                         a_img, row_groups, nch, spc, steps_total, part);
+  once.set((const void*)k_quant_xa128<DT, NT, W, R>, lds);
+  k_quant_xa128<DT, NT, W, R><<<(unsigned)(tiles * nch), 64 * W, lds, st>>>((const uint8_t*)x, M, K, ldx_b, q, (uint8_t*)xq, Kp, a_img,
+                                                                           row_groups, nch, spc, steps_total, part);
 }
 
 template <int NT, bool I8>
@@ -980,7 +994,7 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
         xal::ROWS * ldx_b >= 0x40000000)
       return LQER_E_UNSUPPORTED;
     const XaPlan base = xa_plan(M, Kp);
-    const int steps_total = (int)(Kp * 2 / xal::BKB), tiles = (int)((M + xal::ROWS - 1) / xal::ROWS);
+    const int steps_total = (int)(Kp * 2 / xal::BKB), tiles = (int)((M + xal::qx_rows - 1) / xal::qx_rows);
     int nch = LQER_XAL_WGS / tiles;
     nch = nch < 1 ? 1 : (nch > base.nchunk ? base.nchunk : nch);
     nch = nch < steps_total ? nch : steps_total;

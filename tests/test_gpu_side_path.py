@@ -105,8 +105,8 @@ def test_side_path_vs_quantizer_and_oracle(ops, M, K, r, dtype, ablock):
     ref = O.mxint_quantize(torch.from_numpy(xq64).float() @ A, width=8, block_size=[1, ablock], skip_first_dim=True).numpy()
     print(f"xAq entries differing from the oracle's summation order: {(got != ref).mean():.4%}")
     assert (got != ref).mean() <= 0.03
-    # (2b) the fused routes against the two separate steps (standalone quantizer, then lqer_lowrank_xa on its image): where
-    # both walk the same K chunks in the same order - the 128-row kernels of rank 65..128 - the bits are the same
+    # (2b) the two separate steps (standalone quantizer, then lqer_lowrank_xa on its image - the route of unaligned inputs) walk
+    # other K chunks than the fused 64-row kernel: another fp32 summation order, the same envelope
     if rp > 64 and M >= 512:
         img = torch.zeros(Mp, Kp, dtype=torch.bfloat16, device=DEV)
         img[:M] = ref_img[:M]
@@ -114,7 +114,8 @@ def test_side_path_vs_quantizer_and_oracle(ops, M, K, r, dtype, ablock):
         _lib.check(L.lqer_lowrank_xa(C.byref(desc), img.data_ptr(), M, a_t.data_ptr(), a_limbs, xaq3.data_ptr(), scr.data_ptr(), nscr,
                                      None), "lowrank_xa")
         torch.cuda.synchronize()
-        assert torch.equal(xaq3[:M, :r].view(torch.int16), xaq[:M, :r].view(torch.int16))
+        assert _envelope_check(s64, xaq3[:M, :r].float().cpu().numpy(), Lb, 7, max(16.0, math.sqrt(K))) == 0
+        assert (xaq3[:M, :r] != xaq[:M, :r]).float().mean() <= 0.03
         assert float(xq[:M, K:].float().abs().max()) == 0.0 if Kp > K else True  # (the padded k of the image are zeros)
     # (3) run-to-run bit stability (fixed-order combine), fresh output buffers
     xq2, xaq2 = torch.zeros_like(xq), torch.zeros_like(xaq)
