@@ -987,7 +987,11 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
   if (rp % La != 0 || La % 4 != 0 || (G & (G - 1)) != 0 || G > 64) return LQER_E_UNSUPPORTED;
   if (M == 0) return LQER_OK;
 #ifndef LQER_NO_QXA128
+#ifdef LQER_QXA128_ALL  // experiment: every rank through the tile kernel (rank 32: one rank tile, three of four waves per row group idle in the MFMA part)
+  if (rp % 32 == 0 && M >= 512 && a_limbs == 1 && dtype != LQER_F32 && K % 8 == 0 && (uintptr_t)x % 16 == 0 && (ldx * 2) % 16 == 0) {
+#else
   if (rp > 64) {
+#endif
     // rank 65..128: 128-row tiles, both MFMA operands through LDS (xal::k_quant_xa128), the plan of the LDS-staged side GEMM
     const int64_t ldx_b = ldx * 2;
     if (rp % 32 != 0 || a_limbs != 1 || M < 512 || dtype == LQER_F32 || K % 8 != 0 || (uintptr_t)x % 16 != 0 || ldx_b % 16 != 0 ||
@@ -1005,8 +1009,15 @@ int quant_xa_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int6
     const size_t need = (size_t)nch * plan.row_groups * XA_ROWS * rp * sizeof(float);
     if (!scratch || scratch_bytes < need) return LQER_E_UNSUPPORTED;
     const int nt = rp / 32;
+#ifdef LQER_QXA128_ALL
+#define QX128(DT) (nt == 1 ? xal::launch_q<DT, 1>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st) \
+                 : nt == 2 ? xal::launch_q<DT, 2>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st) \
+                 : nt == 3 ? xal::launch_q<DT, 3>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st) \
+                           : xal::launch_q<DT, 4>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st))
+#else
 #define QX128(DT) (nt == 3 ? xal::launch_q<DT, 3>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st) \
                            : xal::launch_q<DT, 4>(x, M, K, ldx_b, qx, xq, Kp, a_t, plan.row_groups, tiles, nch, spc, steps_total, scratch, st))
+#endif
     if (dtype == LQER_F16) QX128(LQER_F16); else QX128(LQER_BF16);
 #undef QX128
     if (!xaq) return check_launch("quantize_act_xa");
