@@ -336,6 +336,11 @@ def main():
         return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # LQER_BENCH_REHEARSE=1: every rank on cuda:0 with gloo carrying the collectives (RCCL refuses two ranks on one device) -
+    # the N > 1 code path with real kernels on a one-GPU box; the figures of such a run mean nothing
+    rehearse = os.environ.get("LQER_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -344,7 +349,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import ctypes as C
 
