@@ -53,3 +53,48 @@ def test_forwards_on_two_streams_equal_the_forwards_alone(lq, cfg, M, K, N, r):
     for i in (0, 1):
         for y in outs[i]:
             assert torch.equal(y.view(torch.int16), ref[i].view(torch.int16))
+
+
+def test_forwards_from_two_host_threads(lq):
+    """Two Python threads, each with its own stream and module copy, call the C ABI at the same time (ctypes drops the GIL for the
+    call): the library keeps no per-call global state (thread-local error string, once-flags, an atomic launch counter), so both
+    threads get the bits of the forwards run alone - tile route and one-launch decode route."""
+    import copy
+    import threading
+
+    from bench import MXINT_Q, make_weights
+
+    K, N, r = 1024, 1024, 32
+    g = torch.Generator().manual_seed(99)
+    W, A, B = make_weights(g, K, N, r, quantize_ab=True)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).half()
+    xs = {M: torch.randn(M, K, generator=g).half().to(DEV) for M in (600, 3)}
+    ref = {M: mod(x).clone() for M, x in xs.items()}
+    mods = [mod, copy.deepcopy(mod)]
+    mods[1](xs[3])
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream(DEV)
+            with torch.cuda.stream(s):
+                for it in range(40):
+                    M = 600 if (it + i) % 2 else 3
+                    y = mods[i](xs[M])
+                    if it % 8 == 7:
+                        s.synchronize()
+                        if not torch.equal(y, ref[M]):
+                            errors.append((i, it, M))
+            s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
