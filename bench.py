@@ -736,16 +736,7 @@ def main():
                 # both queues produce the bits of the one-stream run (units of a plan that share one image set)
                 if any(pi == i for pi, _ in on_b):  # (every image set of a plan holds the same values)
                     assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), "two-stream outputs differ"
-            def run_two(n):
-                # (the second queue starts one quantizer late: launched together, the two queues fall into lockstep - both GEMMs
-                # compete for the CUs at once and every quantizer trickles beside a GEMM, NOTEBOOK 8.8 - instead of running each
-                # quantizer under the other queue's GEMM)
-                if os.environ.get("LQER_BENCH_TWO_OFFSET", "1") == "1":
-                    qxa(*calls_for(s2.cuda_stream, plans2)[0][3][0][1])
-                for _ in range(n):
-                    step_two()
-
-            el_two = sweep.max_over_ranks(timed_region(run_two, args.steps), dev)
+            el_two = sweep.max_over_ranks(timed_region(lambda n: [step_two() for _ in range(n)], args.steps), dev)
             two_streams = {"ms_per_step": round(el_two / args.steps * 1e3, 4), "vs_one_stream": round(elapsed / el_two, 4)}
             del ws2, ys2
         except Exception as e:  # (a secondary figure must not cost the bench line)
