@@ -154,65 +154,52 @@ __global__ __launch_bounds__(256) void k_qmm_bimage_j(const void* __restrict__ y
 }
 
 // ---- y [b][k][j], k contiguous (the transposed view of a [j][k] tensor) -> img [b][S2p][Kp] -------------------------------
-// One thread = 16 consecutive j x 8 consecutive k: 16 loads of 16 B; the block of 16 along j of each of its 8 k is entirely in
-// its registers.  Consecutive threads take consecutive pieces of 8 k: the loads of a j row are contiguous.
+// A 64 (j) x 64 (k) tile per workgroup: four threads read 128 B of a j row, the fp32 values cross an LDS tile, thread (j block of
+// 16, k) quantizes its block with the packed routine, the bf16 values cross a second tile and leave as 32-byte pieces of the
+// image's rows.  (Round 2's kernel kept 16 x 8 values per thread - one wave per SIMD, 1,400 instructions per thread, a branch
+// around a slow path per element: 18-20 us for a [32, 2048, 128] operand against 10 us.)
 template <int DT>
 __global__ __launch_bounds__(256) void k_qmm_bimage_k(const void* __restrict__ y, int64_t K, int64_t S2, int64_t y_bs, int64_t y_js, QP q,
-                                                      bf16_t* __restrict__ img, int64_t S2p, int64_t Kp, bool vec) {
-  const int64_t kp8 = Kp / 8;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (j block, piece of 8 k)
-  const int64_t b = blockIdx.z;
-  if (idx >= (S2p / 16) * kp8) return;
-  const int64_t jb = idx / kp8 * 16, k = (idx - idx / kp8 * kp8) * 8;
-  float v[16][8];
+                                                       bf16_t* __restrict__ img, int64_t S2p, int64_t Kp, bool vec) {
+  __shared__ float tf[64][64 + 1];
+  __shared__ bf16_t tb[64][64 + 2];
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.z, j0 = (int64_t)blockIdx.y * 64, k0 = (int64_t)blockIdx.x * 64;
+  {
+    const int jl = tid >> 2, kc = (tid & 3) * 16;
+    const int64_t j = j0 + jl, k = k0 + kc;
+    float v[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int64_t j = jb + r;
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    if (j < S2 && k < K) load16<DT>(y, b * y_bs + j * y_js + k, K - k, vec, v);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) v[r][c] = 0.f;
-    if (j < S2 && k < K) {
-      const int64_t off = b * y_bs + j * y_js + k;
-      if (vec && k + 8 <= K) {
-        if constexpr (DT == LQER_F32) {
-          const float4 a = ((const float4*)((const float*)y + off))[0], c4 = ((const float4*)((const float*)y + off))[1];
-          v[r][0] = a.x, v[r][1] = a.y, v[r][2] = a.z, v[r][3] = a.w, v[r][4] = c4.x, v[r][5] = c4.y, v[r][6] = c4.z, v[r][7] = c4.w;
-        } else {
-          const uint4 t = *(const uint4*)((const bf16_t*)y + off);
-          const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+    for (int i = 0; i < 16; ++i) tf[jl][kc + i] = v[i];
+  }
+  __syncthreads();
+  {
+    const int jb = tid >> 6, kl = tid & 63;  // block of 16 consecutive j at one k: consecutive lanes = consecutive k (no bank conflict)
+    float v[16];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if constexpr (DT == LQER_F16) {
-              typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-              const h2 h = __builtin_bit_cast(h2, w[c]);
-              v[r][2 * c] = (float)h[0], v[r][2 * c + 1] = (float)h[1];
-            } else {
-              v[r][2 * c] = __uint_as_float(w[c] << 16), v[r][2 * c + 1] = __uint_as_float(w[c] & 0xffff0000u);
-            }
-          }
-        }
-      } else {
+    for (int r = 0; r < 16; ++r) v[r] = tf[16 * jb + r][kl];
+    uint32_t w[8];
+    quant16_bf16<DT != LQER_F16>(v, q, w);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[r][c] = k + c < K ? load_elem<DT>(y, off + c) : 0.f;
-      }
+    for (int i = 0; i < 8; ++i) {
+      tb[16 * jb + 2 * i][kl] = (bf16_t)(w[i] & 0xffff);
+      tb[16 * jb + 2 * i + 1][kl] = (bf16_t)(w[i] >> 16);
     }
   }
-  // per k: the block of 16 along j
+  __syncthreads();
+  {
+    const int jl = tid >> 2, kc = (tid & 3) * 16;
+    if (j0 + jl < S2p && k0 + kc < Kp) {
+      bf16_t* dst = img + (b * S2p + j0 + jl) * Kp + k0 + kc;
+      uint32_t w[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float amax = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(v[r][c]));
-    const bool any = amax > 0.f;
-    const int e = any ? block_exponent(amax, q) : 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r][c] = any ? ldexpf(mxint_mantissa(v[r][c], e, q), e - q.mbits) : 0.f;
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    uint32_t w[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) w[c] = exact_bf16_bits(v[r][2 * c]) | (exact_bf16_bits(v[r][2 * c + 1]) << 16);
-    *(uint4*)(img + (b * S2p + jb + r) * Kp + k) = make_uint4(w[0], w[1], w[2], w[3]);
+      for (int i = 0; i < 8; ++i) w[i] = (uint32_t)tb[jl][kc + 2 * i] | ((uint32_t)tb[jl][kc + 2 * i + 1] << 16);
+      ((uint4*)dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      ((uint4*)dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
   }
 }
 
@@ -661,8 +648,7 @@ static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, in
     const dim3 grid((unsigned)(S2p / 64), (unsigned)(Kp / 64), (unsigned)batch);
     qmm::k_qmm_bimage_j<DT><<<grid, 256, 0, st>>>(y, K, S2, y_bs, y_ks, qy, img, S2p, Kp, al16(y, y_bs, y_ks));
   } else {
-    const int64_t items = (S2p / 16) * (Kp / 8);
-    const dim3 grid((unsigned)((items + 255) / 256), 1, (unsigned)batch);
+    const dim3 grid((unsigned)(Kp / 64), (unsigned)(S2p / 64), (unsigned)batch);
     qmm::k_qmm_bimage_k<DT><<<grid, 256, 0, st>>>(y, K, S2, y_bs, y_js, qy, img, S2p, Kp, al16(y, y_bs, y_js));
   }
   if (Kp <= qmm::XR_MAXK && S2p / qmm::BN >= 2 * qmm::XR_JT) {  // short contraction, many column tiles: x tile resident in LDS
