@@ -709,6 +709,125 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
   commit();
 }
 
+// The same pre-pass with the B^T fragments through LDS, for rank 64 (the W4A8 INT configurations).  Counters of k_bout_amax<4, 4>
+// at C4 (tools/r03_sidepmc.sh): the texture addresser is busy 62 % of the kernel, the MFMA pipe 30 % - every wave fetches its own
+// copy of the B^T run, 32 lanes x 128-byte rows per request.  Here the four waves of a workgroup take four different groups of
+// 128 token rows over the SAME run of column tiles: a stage of AMX_SB (tile, limb) batches - 4 KB each, contiguous in the B^T
+// image - is read once per workgroup with one 16-byte request per thread and batch (16 lanes per 256-byte line), swizzled into
+// LDS (two stage buffers, one barrier per stage), and every wave reads its fragments from there.  Same maxima (max is
+// order-independent), same commit.
+constexpr int AMX_SB = 4;
+__global__ __launch_bounds__(256) void k_bout_amax_lds(GemmArgs g, int tiles_n32, int seg_tiles) {
+  constexpr int RG = 4, NKS = 4;
+  __shared__ __attribute__((aligned(16))) unsigned char sbuf[2][AMX_SB][4096];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int64_t groups = ((g.M + 31) / 32 + RG - 1) / RG;
+  const int nseg = (tiles_n32 + seg_tiles - 1) / seg_tiles;
+  const int wgr = (int)(blockIdx.x / nseg), sg = (int)(blockIdx.x - (int64_t)wgr * nseg);
+  const int64_t tg_raw = (int64_t)wgr * 4 + wave;
+  const bool live = tg_raw < groups;               // (a wave past the last row group still stages and meets the barriers)
+  const int tg = (int)(live ? tg_raw : groups - 1);
+  const int Mp = (g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
+  bf16x8 xa[RG][NKS];
+  int rowv[RG];
+#pragma unroll
+  for (int u = 0; u < RG; ++u) {
+    const int row = (tg * RG + u) * 32 + l31;
+    rowv[u] = live && row < Mp ? row : -1;
+    const int rc = row < Mp ? row : Mp - 1;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) xa[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)rc * g.xaq_ld + ks * 16 + 8 * lh);
+  }
+  const int t_begin = sg * seg_tiles;
+  const int t_end = t_begin + seg_tiles < tiles_n32 ? t_begin + seg_tiles : tiles_n32;
+  int cur_blk = (t_begin * 32) / g.bout_L;
+  float cur[RG];
+#pragma unroll
+  for (int u = 0; u < RG; ++u) cur[u] = 0.f;
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
+      const float m = pair32_max(cur[u]);
+      if (lh == 0 && rowv[u] >= 0)
+        atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(m));
+    }
+  };
+  const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int nb = (t_end - t_begin) * g.b_limbs;  // batches (tile, limb), limb fastest
+  const int nst = (nb + AMX_SB - 1) / AMX_SB;
+  const int64_t limb_stride = (int64_t)g.Np * g.rp;
+  // staging: thread t moves 16-byte chunk t of a batch's 4 KB (row t / 8 of the tile, chunk t % 8 of its 128 B) to the swizzled slot
+  const int srow = tid >> 3, sch = tid & 7;
+  const int sdst = srow * 128 + ((sch ^ (srow & 7)) << 4);
+  u32x4 st[AMX_SB];
+  auto gload = [&](int s) {
+#pragma unroll
+    for (int u = 0; u < AMX_SB; ++u) {
+      const int i = s * AMX_SB + u, ii = i < nb ? i : nb - 1;  // (past the end: the last batch again, never consumed)
+      const int tn = t_begin + ii / g.b_limbs, l = ii - (ii / g.b_limbs) * g.b_limbs;
+      st[u] = *(const u32x4*)(g.bt + l * limb_stride + (int64_t)tn * 32 * g.rp + tid * 8);
+    }
+  };
+  auto lwrite = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < AMX_SB; ++u) *(u32x4*)(&sbuf[buf][u][sdst]) = st[u];
+  };
+  int fo[NKS];  // fragment offsets inside a batch: row l31, chunk 2 ks + lh
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) fo[ks] = l31 * 128 + (((2 * ks + lh) ^ (l31 & 7)) << 4);
+  f32x16 acc[RG];
+  int tn = t_begin, l = 0;
+  gload(0);
+  lwrite(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    if (s + 1 < nst) gload(s + 1);
+    const int buf = s & 1;
+#pragma unroll
+    for (int u2 = 0; u2 < AMX_SB; ++u2) {
+      if (s * AMX_SB + u2 < nb) {
+        bf16x8 fr[NKS];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) fr[ks] = *(const bf16x8*)(&sbuf[buf][u2][fo[ks]]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          if (l == 0 && ks == 0) {
+#pragma unroll
+            for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[0], xa[u][0], zero, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int u = 0; u < RG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks], xa[u][ks], acc[u], 0, 0, 0);
+          }
+        }
+        if (++l == g.b_limbs) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int blk = (tn * 32 + 16 * b) / g.bout_L;  // wave-uniform
+            if (blk != cur_blk) {
+              commit();
+              cur_blk = blk;
+#pragma unroll
+              for (int u = 0; u < RG; ++u) cur[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < RG; ++u) {
+              float m = cur[u];
+#pragma unroll
+              for (int k = 0; k < 8; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[u][8 * b + k])), fabsf(acc[u][8 * b + k + 1]));
+              cur[u] = m;
+            }
+          }
+          l = 0, ++tn;
+        }
+      }
+    }
+    if (s + 1 < nst) lwrite(buf ^ 1);  // (everybody left that buffer before the previous barrier)
+    __syncthreads();
+  }
+  commit();
+}
+
 template <int DT>
 static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st) {
   const unsigned grid = (unsigned)(g.tiles_m * g.tiles_n);
@@ -841,6 +960,16 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
       const int64_t waves = groups * ((tiles_n32 + seg_tiles - 1) / seg_tiles);
       const unsigned grid = (unsigned)((waves + 3) / 4);
 #define LQER_AMAX(RGv, NKSv) k_bout_amax<RGv, NKSv><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles)
+#ifndef LQER_AMAX_NO_LDS
+      if (nks == 4 && g.rp == 64) {  // rank 64: the B^T run through LDS, four row groups per workgroup
+        const int64_t wgroups = (groups + 3) / 4;
+        int ns = (int)((LQER_AMAX_WAVES / 4) / wgroups);
+        ns = ns < 1 ? 1 : (ns > tiles_n32 ? tiles_n32 : ns);
+        const int st_l = (tiles_n32 + ns - 1) / ns;
+        const int64_t wgs = wgroups * ((tiles_n32 + st_l - 1) / st_l);
+        k_bout_amax_lds<<<(unsigned)wgs, 256, 0, st>>>(g, tiles_n32, st_l);
+      } else
+#endif
       switch (nks) {
         case 1: LQER_AMAX(4, 1); break;
         case 2: LQER_AMAX(4, 2); break;

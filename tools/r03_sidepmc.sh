@@ -14,7 +14,7 @@ for set in "TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
   i=$((i+1))
   # (a counter set the hardware cannot collect at once makes rocprofv3 abort and the child hang: bounded)
   timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/$OUT/pass$i -- python3 $R/bench.py --workload $W --layers 1 --steps 2 --warmup 1 \
-      --prewarm-ms 0 --no-cpu-baseline --no-check --no-module > $R/gpurun_out/$OUT/pass$i.log 2>&1
+      --prewarm-ms 0 --no-cpu-baseline --no-check --no-module --no-two-streams > $R/gpurun_out/$OUT/pass$i.log 2>&1
   echo "pass $i rc=$?"
 done
 python3 $R/tools/pmc_traffic.py $R/gpurun_out/$OUT $W > $R/gpurun_out/$OUT/summary_$W.json
