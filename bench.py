@@ -429,7 +429,11 @@ def main():
     launch_no = [0]
     # bracket every n-th launch of the dominant kernel with HIP events: at least 8 samples inside the timed region
     # whatever --steps is (the driver's 20-step C2 run: every 2nd launch), at most every 10th (a pair costs ~12 us of gaps)
-    EV_EVERY = max(1, min(10, args.steps * sum(m[4] for m in mods) // 8))
+    EV_TOTAL = args.steps * sum(m[4] for m in mods)  # timed launches of the dominant kernel
+    EV_EVERY = max(1, min(10, EV_TOTAL // 8))
+    # (short regions - the driver's 20-step C2 run: exactly 8 samples, evenly spread, instead of every 2nd launch = 10)
+    ev_sample = (lambda i: i % EV_EVERY == 0) if EV_EVERY >= 10 or EV_TOTAL < 8 else \
+        (lambda i: i == 0 or (i * 8) // EV_TOTAL != ((i - 1) * 8) // EV_TOTAL)
 
     # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
     plans = []
@@ -520,7 +524,7 @@ def main():
         for reps, K, N, per_unit in rows:
             for u in range(reps):
                 fa, qa, ga = per_unit[u % len(per_unit)]
-                ev = timed and launch_no[0] % EV_EVERY == 0  # counts timed launches only: the first one is always sampled
+                ev = timed and ev_sample(launch_no[0])  # counts timed launches only: the first one is always sampled
                 if timed:
                     launch_no[0] += 1
                 if one_launch:
