@@ -15,7 +15,7 @@
  *  - the caller owns every buffer (incl. workspace); the library never allocates, frees or
  *    retains pointers, and is re-entrant (its only process-wide state are std::once_flag-guarded, idempotent kernel
  *    attribute settings, one atomic call counter - the tag of the one-launch decode route, see lqer_linear_forward - and
- *    the thread-local error text);
+ *    the thread-local error text; kernel-selection knobs for tests travel in the descriptor: lqer_linear_desc_t.tuning);
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  *    stream) and performs no host synchronisation, so calls may be captured in a hipGraph;
  *  - return value 0 = success, <0 = error (LQER_E_*); lqer_last_error() gives the text of the
@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 8
+#define LQER_ABI_VERSION 9
 
 /* error codes */
 #define LQER_OK 0
@@ -96,7 +96,21 @@ typedef struct lqer_linear_desc {
   lqer_qfmt_t b_fmt;     /* linear.py:152   b_quantizer                        */
   lqer_qfmt_t a_out_fmt; /* linear.py:154   A_out_quantizer                    */
   lqer_qfmt_t b_out_fmt; /* linear.py:155   B_out_quantizer                    */
+  int32_t tuning;        /* 0 = the library decides everything (what every caller wants).  LQER_TUNE_* bits: per-CALL kernel
+                            selection knobs for tests and measurements - they change which kernel variant runs, never a result
+                            bit.  Carried by the descriptor, not by process-wide state: two threads never see each other's. */
 } lqer_linear_desc_t;
+
+/* lqer_linear_desc_t.tuning (all variants give the same bits) */
+#define LQER_TUNE_TILE_ROWS_128 0x1   /* 128-row kernel family (LQER_ROUTE_TILE128): always 128-row tiles                     */
+#define LQER_TUNE_TILE_ROWS_64 0x2    /* ... always 64-row tiles (two workgroups per CU); default: 64 rows when the 128-row grid
+                                         covers at most half of the CUs                                                        */
+#define LQER_TUNE_XCD_BLOCK(t) (((t) & 0x3f) << 4) /* XCD-local tile BLOCKS of `t` token tiles x (tiles / 8 / t) weight tiles in the
+                                         128-row kernel instead of rows of weight tiles; applied only where the tile grid divides
+                                         (16 x 16 tiles: 8, 4 or 16); measured +-0 (the weight stream through every XCD's L2 is
+                                         served by the Infinity Cache)                                                        */
+#define LQER_TUNE_DECODE_NO_POLL 0x10000 /* one-launch decode route: no wait for the producers' tiles - every weight-streaming
+                                         workgroup computes the partial tiles of x A itself (the bounded wait's fall-back)     */
 
 /* Sizes (bytes) of the derived, caller-allocated device buffers of one Linear. */
 typedef struct lqer_linear_sizes {
@@ -195,20 +209,6 @@ int lqer_linear_forward(const lqer_linear_desc_t* desc, const void* x, int dtype
  * capture as well: a replayed graph node carries the captured counter but gets a fresh dispatch id, and never accepts the
  * previous replay's tiles.  The wait for the tiles is bounded; a workgroup that does not see them computes them itself
  * (same bits). */
-
-/* test hook: poll sweeps of that wait before the fall-back (0 = every workgroup computes the tiles itself; < 0 = default) */
-int lqer_debug_set_decode_spin(int sweeps);
-
-/* test hook: tile height of the 128-row kernel family (LQER_ROUTE_TILE128): 0 = chosen per launch (64-row tiles when the
- * 128-row grid covers at most half of the CUs), 128 = always 128 rows, 64 = always 64 rows (two workgroups per CU).  All
- * give the same bits. */
-int lqer_debug_set_tile_rows(int rows);
-
-/* experiment hook (round 3): XCD-local tile BLOCKS in the 128-row kernel - an XCD's tiles form a block of `token_tiles` token
- * tiles x (tiles / 8 / token_tiles) weight tiles instead of rows of weight tiles; applied only where the tile grid divides
- * (e.g. 16 x 16 tiles: 8, 4 or 16), 0 = off.  Same bits, same time (the weight stream through every XCD's L2 is served by
- * the Infinity Cache and is not what the main loop waits for): kept for measurement (tools/ab_gemm.py --xcd-bm). */
-int lqer_debug_set_xcd_block(int token_tiles);
 
 /* The same, split for callers that share one quantized activation between several Linears
  * (q/k/v, gate/up) and for per-stage timing.  xq = output of lqer_quantize_act_mxint.         */

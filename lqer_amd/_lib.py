@@ -11,11 +11,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
 ROUTE_SMALLM, ROUTE_TILE128, ROUTE_TILE256, ROUTE_TILE256_I8 = 0, 1, 2, 3
+TUNE_TILE_ROWS_128, TUNE_TILE_ROWS_64, TUNE_DECODE_NO_POLL = 0x1, 0x2, 0x10000
+
+
+def tune_xcd_block(t: int) -> int:
+    return (t & 0x3F) << 4
+
 
 
 class QFmt(C.Structure):
@@ -33,6 +39,7 @@ class LinearDesc(C.Structure):
         ("b_fmt", QFmt),
         ("a_out_fmt", QFmt),
         ("b_out_fmt", QFmt),
+        ("tuning", C.c_int32),  # LQER_TUNE_* (0 = defaults): per-call kernel-variant knobs of tests / measurements
     ]
 
 
@@ -69,9 +76,6 @@ SIGNATURES = {
     "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "lqer_decode_partials": (_i, [_dp, _i64]),
-    "lqer_debug_set_decode_spin": (_i, [_i]),
-    "lqer_debug_set_tile_rows": (_i, [_i]),
-    "lqer_debug_set_xcd_block": (_i, [_i]),
     "lqer_gemm_route": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),

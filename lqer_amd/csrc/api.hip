@@ -104,7 +104,9 @@ static bool i8_formats_ok(const lqer_linear_desc_t* d) {
 // (M a multiple of the row padding: the tile kernels read whole row tiles; M <= 64: the small-M kernel and the side
 // GEMM never read past row M - 1 - unless B_out blocks other than 16 send a decode-size call to the tile kernel)
 static bool f16_image_is_input(const lqer_linear_desc_t* d, const void* x, int64_t M, int64_t ldx) {
-  const bool smallm = M <= 64 && !(d->rank > 0 && d->b_out_fmt.kind == LQER_Q_MXINT && d->b_out_fmt.block != 16);
+  // (asked of the dispatcher itself, so the two can not drift: an integer B_out, or B_out blocks other than 16, send a
+  // decode-size call to the tile kernel, whose buffer range covers whole row tiles)
+  const bool smallm = M <= 64 && x_is_f16(d) && lqer_gemm_route(d, M, LQER_F16) == LQER_ROUTE_SMALLM;
   return x_is_f16(d) && ldx == d->in_features && d->in_features % LQER_K_ALIGN == 0 && (M % LQER_M_ALIGN == 0 || smallm) &&
          ((uintptr_t)x & 15) == 0;
 }
@@ -442,6 +444,7 @@ static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, Ge
   g.Kp = (int)lqer_padded_k(d->in_features) * xl;  // limbs side by side along k, weight image repeated to match
   g.rp = (int)lqer_padded_r(d->rank) * al;
   g.w_mbits = d->w_fmt.width - 1;
+  g.tuning = d->tuning;
   if (lowrank) g.bout = make_qp(d->b_out_fmt);
   if (x_is_i8(d)) {
     if (!i8_formats_ok(d)) return LQER_E_UNSUPPORTED;

@@ -168,7 +168,7 @@ __device__ __forceinline__ bool mxint16_fast_ok(int e, const QP& q) {
 // calls (power-of-two factors built from exponent bits, round-to-nearest-even by the 1.5 * 2^23 trick, as in
 // mxint16_bf16_fast below) when mxint16_fast_ok(e, q); the |x| <= tiny case is the caller's.
 __device__ __forceinline__ float mxint_value(float x, int e, const QP& q) {
-  if (mxint16_fast_ok(e, q)) {
+  if (mxint16_fast_ok(e, q) && q.mmax <= 4194304.0f) {  // (the magic-number rounding is exact up to 2^22)
     const float s = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23), inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
     const float r = __builtin_fmaf(fabsf(x) + q.eps, s, 12582912.0f) - 12582912.0f;
     return copysignf(fminf(r, q.mmax + (x < 0.0f ? q.mneg - q.mmax : 0.0f)) * inv, x);
@@ -212,11 +212,14 @@ __device__ __forceinline__ void mxint16_bf16_fast(const float (&v)[16], int e, c
 // integer (quantizers/integer.py:37-40; the QP carries eps = 0, tiny = -1, the two's-complement negative clamp, e = 0):
 //   q = clamp(rne(v 2^frac), lo, hi) 2^-frac.
 // Same arithmetic as mxint16_bf16_fast (fma on the signed value, 1.5 * 2^23 rounding, v_med3 clamp): the results of
-// mxint_mantissa + ldexpf element by element; exponents whose scale factors are not normal floats take that route.
+// mxint_mantissa + ldexpf element by element; exponents whose scale factors are not normal floats, and clamps beyond 2^22
+// (where the magic-number rounding stops being exact), take that route.
 template <int N>
 __device__ __forceinline__ void mxint_requant_fast(float (&v)[N], int e, const QP& q) {
   typedef __attribute__((ext_vector_type(2))) float f2;
-  if (mxint16_fast_ok(e, q)) {
+  // (the 1.5 * 2^23 rounding is exact for |v s| <= 2^22 only: formats with a clamp beyond that - B_out widths 24 - take the
+  // element routine)
+  if (mxint16_fast_ok(e, q) && q.mmax <= 4194304.0f && q.mneg <= 4194304.0f) {
     const float s = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
     const float inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
     const float es = q.eps * s, hi = q.mmax, lo = -q.mneg, tiny = q.tiny;
@@ -414,6 +417,7 @@ struct GemmArgs {
   const uint8_t* w8;
   const float* xscale;  // [Mp] row scales 2^(e - mbits) of the int8 activation image
   int i8_shift;         // some weight group carries a non-zero shift (blocks of 128 with differing exponents)
+  int tuning;           // lqer_linear_desc_t.tuning of the call (LQER_TUNE_*: kernel-variant knobs of tests, same bits)
 };
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,

@@ -570,19 +570,12 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
 }
 
 static std::atomic<uint32_t> g_nonce{1};  // the call's granule tag: any value the granule area does not hold yet
-static std::atomic<int> g_spin{LQER_QD1_SPIN};
 
 }  // namespace d1
 
 #ifdef LQER_D1_STAMPS
 extern "C" int lqer_debug_set_d1_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(d1::g_d1_stamps), &p, sizeof(p)); }
 #endif
-
-// test hook: poll sweeps before the fall-back (0: every consumer workgroup computes the partial tiles itself)
-extern "C" int lqer_debug_set_decode_spin(int sweeps) {
-  d1::g_spin.store(sweeps < 0 ? LQER_QD1_SPIN : sweeps, std::memory_order_relaxed);
-  return 0;
-}
 
 size_t decode1_lds_bytes(int M, int64_t Kp) {
   return (size_t)M * ((Kp * 2 + 255) / 256 * 256) + d1::RED_BYTES + d1::XAQ_BYTES + d1::PSLAB_BYTES + d1::PRED_BYTES + d1::FLAG_BYTES;
@@ -605,7 +598,7 @@ int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, c
   const uint32_t n = d1::g_nonce.fetch_add(1, std::memory_order_relaxed);
   a.nonce = n * 0x9E3779B1u ^ 0xA5C35A3Cu;
   a.np = (int)((g.Kp + d1::SLAB_K - 1) / d1::SLAB_K);
-  a.spin = d1::g_spin.load(std::memory_order_relaxed);
+  a.spin = (g.tuning & LQER_TUNE_DECODE_NO_POLL) ? 0 : LQER_QD1_SPIN;  // (tests: every consumer computes the tiles itself)
   const unsigned grid = (unsigned)(a.np + g.Np / 16);
 #define D1_LAUNCH(DT, BO)                                                                     \
   do {                                                                                        \

@@ -25,7 +25,6 @@
 //  * the two waves of a SIMD run half a k-step apart (LOAD / COMPUTE ping-pong, see the main loop).
 //  * tiles are numbered so that each of the 8 XCDs works on a contiguous run of tiles (same token
 //    rows -> the activation slab stays in that XCD's L2).
-#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -881,9 +880,6 @@ extern "C" int lqer_debug_set_stamp_buffer(void* p) {
 }
 #endif
 
-static std::atomic<int> g_xcd_bm{0};  // experiment hook (lqer_debug_set_xcd_block): token tiles per XCD-local tile block, 0 = rows of tiles
-static std::atomic<int> g_tile_rows{0};  // test hook (lqer_debug_set_tile_rows): 0 = per launch, 128 = never 64-row tiles, 64 = always
-
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
   if (bout.kind != LQER_Q_MXINT || bout.block == 16) return 0;
   const int64_t Np = lqer_padded_n(N);
@@ -1010,7 +1006,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   {
     constexpr int CUS = 256;
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;
-    const int pin = g_tile_rows.load(std::memory_order_relaxed);
+    const int pin = (g.tuning & LQER_TUNE_TILE_ROWS_128) ? 128 : ((g.tuning & LQER_TUNE_TILE_ROWS_64) ? 64 : 0);  // (tests)
     if ((pin != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) || (pin == 64 && g.M > 64)) {
       g.tiles_m = (g.M + 63) / 64;
       g.tiles_m_rows = 64;
@@ -1018,7 +1014,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   }
 #endif
   {
-    const int bm = g_xcd_bm.load(std::memory_order_relaxed), nt = g.tiles_m * g.tiles_n;
+    const int bm = (g.tuning >> 4) & 0x3f, nt = g.tiles_m * g.tiles_n;  // LQER_TUNE_XCD_BLOCK (measurements)
     g.xcd_bm = 0;
     if (bm > 0 && nt % 8 == 0 && (nt / 8) % bm == 0 && g.tiles_m % bm == 0 && 8 % (g.tiles_m / bm) == 0 &&
         g.tiles_n % (8 / (g.tiles_m / bm)) == 0 && (nt / 8) / bm == g.tiles_n / (8 / (g.tiles_m / bm)))
@@ -1031,16 +1027,6 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   }
   set_error("unknown dtype %d", dtype);
   return LQER_E_INVALID;
-}
-
-extern "C" int lqer_debug_set_xcd_block(int bm) {
-  g_xcd_bm.store(bm > 0 ? bm : 0, std::memory_order_relaxed);
-  return 0;
-}
-
-extern "C" int lqer_debug_set_tile_rows(int rows) {
-  g_tile_rows.store(rows == 128 ? 128 : (rows == 64 ? 64 : 0), std::memory_order_relaxed);
-  return 0;
 }
 
 }  // namespace lqer

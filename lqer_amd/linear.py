@@ -56,6 +56,7 @@ class _LinearBase(nn.Linear):
         self._x_i8 = False         # per-token 8-bit activations on the int8 MFMA route (decided when the images are built)
         self.i8_a_f16 = True       # int8 route: fp16 A as one fp16 image for the side GEMM (False: the bf16 limb pair)
         self.a8_native = True      # False: keep them on the bf16 route
+        self.tuning = 0            # lqer_linear_desc_t.tuning (_lib.TUNE_*): per-call kernel-variant knobs of tests, same bits
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
 
@@ -90,7 +91,7 @@ class _LinearBase(nn.Linear):
 
         return LinearDesc(self.in_features, self.out_features, self.rank, int(self.bias is not None),
                           eff("x", _SIG_BITS[dt]), f["w"], f.get("b", none), eff("A_out", 24 if dt == torch.float32 else 16),
-                          f.get("B_out", none))
+                          f.get("B_out", none), int(getattr(self, "tuning", 0)))
 
     def _limbs(self):
         """(activation limbs, x A limbs) of the packed images - 1, 1 unless x / A_out are pass-through."""
@@ -294,6 +295,7 @@ class _LinearBase(nn.Linear):
         self._packed = self._replicate(p)
         self._packed_only = True
         self.w_is_quantized = True
+        self._w_ver = None
 
     @torch.no_grad()
     def _pack(self) -> None:
@@ -312,7 +314,7 @@ class _LinearBase(nn.Linear):
                 # the parameter now carries w_quantizer(W) (|w| <= 1e-8 kept as is, block_fp.py:79-80)
                 if int(getattr(f["w"], "block_rows", 1)) == 1:
                     wq = ops.quantize_mxint(W, f["w"], want=("deq",))["deq"]
-                else:  # 2-D tiles: read the values back from the image just packed
+                else:  # 2-D tiles: read the values back from the image just packed (what ops.quantize_mxint does for them)
                     wq = ops.unpack_weight(w_img, self.out_features, self.in_features, f["w"])
                     wq = torch.where(W.float().abs() <= 1e-8, W.float(), wq)
                 self.weight.data.copy_(wq.to(W.dtype))
@@ -346,12 +348,16 @@ class _LinearBase(nn.Linear):
 
     @torch.no_grad()
     def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
-        if self._packed is not None:
+        if self._packed is not None and not self._packed_only:
+            # (images of a packed checkpoint are the only copy of the operands: its dense parameters are never consulted)
             cur = (self.weight._version, None if self.bias is None else self.bias._version)
             if self._w_ver is None:  # first forward after copy.deepcopy / unpickling: the copied images belong to these parameters
                 self._w_ver = cur
             elif cur != self._w_ver:  # the dense parameters were written in place since their images were built
-                self.invalidate_packed(weight_changed=cur[0] != self._w_ver[0], bias_changed=True)
+                # (a bias that was NOT written already holds b_quantizer(bias): it must not be quantized a second time)
+                keep_bias = self._bias_q if cur[1] == self._w_ver[1] else None
+                self.invalidate_packed(weight_changed=cur[0] != self._w_ver[0], bias_changed=cur[1] != self._w_ver[1])
+                self._bias_q = keep_bias
         if self._packed is None or self.w_is_quantized is False:
             self._pack()
         K, N = self.in_features, self.out_features
@@ -369,7 +375,7 @@ class _LinearBase(nn.Linear):
             return y.reshape(*x.shape[:-1], N)
         # per token count and dtype, built once: descriptor, workspace size and the constant part of the argument list
         # (decode-size forwards are host-bound: the ctypes marshalling of 16 arguments is not free)
-        key = (M, x2.dtype)
+        key = (M, x2.dtype, self.tuning)
         ent = self._fw_cache.get(key)
         if ent is None:
             desc = self._desc()

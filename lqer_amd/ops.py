@@ -108,8 +108,16 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
 
 @_on_tensor_device
 def quantize_mxint(x: torch.Tensor, fmt: QFmt, want=("deq", "codes", "exps")) -> Dict[str, torch.Tensor]:
-    """MXINT quantizer over the last dim of x (any leading dims).  Returns the requested images."""
+    """MXINT quantizer over the last dim of x (any leading dims).  Returns the requested images.  A WEIGHT format with 2-D
+    tiles (`fmt.block_rows` != 1, make_qfmt role "w") is honoured too: the values then come from the packed image of
+    lqer_pack_weight_mxint_2d (one exponent per tile), |x| <= 1e-8 kept as is (block_fp.py:79-80) - `deq` of a 2-D tensor only."""
     _need_gpu(x)
+    if int(getattr(fmt, "block_rows", 1)) != 1:
+        if tuple(want) != ("deq",) or x.dim() != 2:
+            raise NotImplementedError("quantize_mxint with 2-D weight tiles (block_rows != 1) returns `deq` of a 2-D tensor only")
+        xf = x.float()
+        deq = unpack_weight(pack_weight(x, fmt), x.shape[0], x.shape[1], fmt)
+        return {"deq": torch.where(xf.abs() <= 1e-8, xf, deq)}
     cols = x.shape[-1]
     x2 = x.reshape(-1, cols)
     if x2.stride(-1) != 1:

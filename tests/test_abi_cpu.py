@@ -48,7 +48,8 @@ def test_abi_constants_and_padding(lib):
     assert lib.lqer_padded_k(4096) == 4096 and lib.lqer_padded_k(4097) == 4160 and lib.lqer_padded_k(1) == 64
     assert lib.lqer_padded_n(11008) == 11008 and lib.lqer_padded_n(50) == 256
     assert lib.lqer_padded_m(1) == 256 and lib.lqer_padded_r(32) == 32 and lib.lqer_padded_r(33) == 48
-    assert C.sizeof(_lib.QFmt) == 20 and C.sizeof(_lib.LinearDesc) == 16 + 5 * 20
+    assert C.sizeof(_lib.QFmt) == 20 and C.sizeof(_lib.LinearDesc) == 16 + 5 * 20 + 4  # (+ tuning, ABI 9)
+    assert _lib.LinearDesc(1, 1, 0, 0).tuning == 0  # positional construction without the knob field: defaults
 
 
 def test_sizes_and_argument_errors_without_gpu(lib):

@@ -96,16 +96,13 @@ def test_consumer_fallback_computes_the_same_bits(ops):
     from bench import MXINT_Q
     from lqer_amd import _lib
 
-    L = _lib.lib()
     mod, x, W, A, B, _ = _module(2048, 1024, 32, False, MXINT_Q, torch.float16)
     xd = x[:6].half().to(DEV)
     y = mod(xd)
-    try:
-        assert L.lqer_debug_set_decode_spin(0) == 0
-        y_fb = mod(xd)
-        torch.cuda.synchronize()
-    finally:
-        L.lqer_debug_set_decode_spin(-1)
+    mod.tuning = _lib.TUNE_DECODE_NO_POLL  # (per call, in the descriptor)
+    y_fb = mod(xd)
+    torch.cuda.synchronize()
+    mod.tuning = 0
     assert torch.equal(y_fb, y)
 
 

@@ -137,3 +137,40 @@ def test_integer_fallback_forward_vs_reference_vectors(ops, golden_fwd, name, dt
         ref = O.lqer_linear_forward(h(x), h(W), h(t("bias")) if has_b else None, h(A), h(B), qc)
         assert float((y - ref).norm() / ref.norm()) <= 1e-3
     assert y.shape == t("y").shape
+
+
+@pytest.mark.parametrize("M", [1, 7, 64])
+def test_decode_size_passthrough_fp16_x_with_integer_b_out(ops, M):
+    """pass-through fp16 activations + an integer B_out at M <= 64.  The integer B_out sends the call to the TILE
+    kernel (not the small-M one), whose buffer range covers whole row tiles - so the caller's [M, K] tensor must NOT be handed
+    over as the activation image (the library copies it into its padded workspace image instead).  Results vs the oracle."""
+    import ctypes as C
+
+    import lqer_amd
+    from bench import _bfp, make_case
+    from lqer_amd import _lib
+
+    K, N, r = 256, 512, 32
+    qc = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=dict(name="passthrough"),
+              w_quantizer=_bfp(4, [1, 128], False), b_quantizer=dict(name="passthrough"),
+              A_out_quantizer=dict(name="passthrough"), B_out_quantizer=dict(name="integer", width=12, frac_width=8))
+    x, W, A, B = make_case(M, K, N, r, seed=5, quantize_ab=False)
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).half()
+    xh = x.half()
+    y = mod(xh.to(DEV)).float().cpu()
+    assert mod._x_f16  # the fp16 MFMA route
+    desc = mod._desc()
+    assert _lib.lib().lqer_gemm_route(C.byref(desc), M, _lib.F16) == _lib.ROUTE_TILE128  # not the small-M kernel
+    h = lambda t: t.half().float()
+    ref = O.lqer_linear_forward(h(x), h(W), None, h(A), h(B), qc)
+    assert float((y - ref).norm() / ref.norm()) <= 1e-3
+    # the split API refuses xq == x for this descriptor at this token count (it would read past row M - 1)
+    L = _lib.lib()
+    p = mod._packed
+    xd = xh.to(DEV)
+    ws = ops.workspace(xd.device, ops.linear_sizes(desc, M).workspace)
+    rc = L.lqer_quantize_act_xa(C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], xd.data_ptr(),
+                                ws.data_ptr(), ws.data_ptr() + (1 << 16), 1 << 16, None)
+    assert rc == -1, rc

@@ -133,6 +133,10 @@ def test_pack_weight_2d_tiles_bit_exact(ops, golden_q):
         w = ops.unpack_weight(packed, x.shape[0], x.shape[1], fmt).cpu()
         ref = torch.where(x.abs() <= 1e-8, torch.zeros_like(y), y)
         assert torch.equal(w, ref), name
+        # the standalone quantizer honours the tile rows as well (it used to quantize per row silently)
+        assert torch.equal(ops.quantize_mxint(x.to(DEV), fmt, want=("deq",))["deq"].cpu(), y), name
+        with pytest.raises(NotImplementedError):
+            ops.quantize_mxint(x.to(DEV), fmt, want=("deq", "codes"))
 
 
 def test_pack_lowrank_limbs(ops):
@@ -463,8 +467,8 @@ def test_forward_captured_in_a_graph(ops, M):
     assert torch.equal(static_y, eager2)
 
 
-@pytest.mark.parametrize("with_scale", [False, True])
-def test_gpu_approximator_reconstruction_error(ops, with_scale):
+@pytest.mark.parametrize("with_scale,w_block", [(False, [1, 16]), (True, [1, 16]), (False, [8, 16]), (True, [16])])
+def test_gpu_approximator_reconstruction_error(ops, with_scale, w_block):
     """lqer_amd.approximate.lqer_factors (HIP quantizers + rocSOLVER SVD) against the oracle's restatement of the
     reference approximators: the factors are not unique, the error they leave is - |E^T - A B| must agree, and it
     must beat the rank-0 error by the margin the oracle sees."""
@@ -474,7 +478,8 @@ def test_gpu_approximator_reconstruction_error(ops, with_scale):
     N, K, r = 192, 160, 16
     W = 0.02 * torch.randn(N, K)
     W[:, 5] *= 20
-    w_cfg = dict(name="block_fp", width=4, exponent_width=8, exponent_bias=None, block_size=[1, 16], skip_first_dim=False)
+    # (w_block [8, 16] / [16] with skip_first_dim = false: 2-D weight tiles - the factors must correct the error of THAT quantizer)
+    w_cfg = dict(name="block_fp", width=4, exponent_width=8, exponent_bias=None, block_size=w_block, skip_first_dim=False)
     ab_cfg = dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[16, 1], skip_first_dim=False)
     scale = (0.5 + torch.rand(K)) if with_scale else None
     A, B = lqer_factors(W.to(DEV), w_cfg, r, ab_cfg, ab_cfg, scale.to(DEV) if with_scale else None)

@@ -59,14 +59,10 @@ def test_64_row_tiles_equal_128_row_tiles_and_the_oracle(lq, M, K, N, r, bias, b
     mod.load_state_dict(sd)
     mod = mod.to(DEV).to(dtype)
     xd = x.to(dtype).to(DEV)
-    L = _lib.lib()
-    try:
-        assert L.lqer_debug_set_tile_rows(128) == 0
-        y128 = mod(xd).clone()
-        assert L.lqer_debug_set_tile_rows(0) == 0
-        y64 = mod(xd).clone()
-    finally:
-        L.lqer_debug_set_tile_rows(0)
+    mod.tuning = _lib.TUNE_TILE_ROWS_128  # (per call, in the descriptor: no process-wide switch)
+    y128 = mod(xd).clone()
+    mod.tuning = 0
+    y64 = mod(xd).clone()
     assert torch.equal(y64, y128)
     h = lambda t: None if t is None else t.to(dtype).float()
     ref = O.lqer_linear_forward(h(x), h(W), h(bvec), h(A) if r > 0 else None, h(B) if r > 0 else None, qc)
@@ -87,15 +83,10 @@ def test_forced_64_row_tiles_and_xcd_blocks_give_the_same_bits(lq):
     mod.load_state_dict({"weight": W, "A": A, "B": B})
     mod = mod.to(DEV).half()
     xd = x.half().to(DEV)
-    L = _lib.lib()
     y0 = mod(xd).clone()
-    try:
-        L.lqer_debug_set_tile_rows(64)
-        assert torch.equal(mod(xd), y0)
-        L.lqer_debug_set_tile_rows(0)
-        for bm in (8, 4, 16, 3):  # (3 does not divide the grid: ignored)
-            L.lqer_debug_set_xcd_block(bm)
-            assert torch.equal(mod(xd), y0), bm
-    finally:
-        L.lqer_debug_set_tile_rows(0)
-        L.lqer_debug_set_xcd_block(0)
+    mod.tuning = _lib.TUNE_TILE_ROWS_64
+    assert torch.equal(mod(xd), y0)
+    for bm in (8, 4, 16, 3):  # (3 does not divide the grid: ignored)
+        mod.tuning = _lib.tune_xcd_block(bm)
+        assert torch.equal(mod(xd), y0), bm
+    mod.tuning = 0

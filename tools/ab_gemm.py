@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--bout", type=int, default=1, help="1: B_out MXINT8/16, 0: passthrough, 2: MXINT8, one block per row (pre-pass)")
     ap.add_argument("--xcd-bm", type=int, nargs="*", default=[], help="also time every build with XCD-local tile blocks of this many "
-                    "token tiles (lqer_debug_set_xcd_block; 128-row kernel)")
+                    "token tiles (LQER_TUNE_XCD_BLOCK; 128-row kernel)")
     ap.add_argument("--no-persist", action="store_true", help="also time every build with the persistent tile loop off (lqer_debug_set_gemm_persistent)")
     ap.add_argument("--blimbs", type=int, default=1, help="bf16 limbs of B (1: MXINT8 values, 2: fp16 values)")
     a = ap.parse_args()
@@ -51,15 +51,14 @@ def main():
     if a.no_persist:
         libs += [(f"{p} [one workgroup per tile]", L) for p, L in base if hasattr(L, "lqer_debug_set_gemm_persistent")]
     for bm in a.xcd_bm:
-        libs += [(f"{p} [xcd block {bm}]", L) for p, L in base if hasattr(L, "lqer_debug_set_xcd_block")]
+        libs += [(f"{p} [xcd block {bm}]", L) for p, L in base]
     bm_of = lambda p: int(p.rsplit("[xcd block ", 1)[1][:-1]) if p.endswith("]") and "[xcd block " in p else 0
     st = torch.cuda.current_stream().cuda_stream
 
     scr, nscr = op["scr"], op["nscr"]
 
     def run(L, bm=0, persist=1):
-        if hasattr(L, "lqer_debug_set_xcd_block"):
-            L.lqer_debug_set_xcd_block(bm)
+        desc.tuning = _lib.tune_xcd_block(bm)  # per call, in the descriptor (lqer_linear_desc_t.tuning)
         if hasattr(L, "lqer_debug_set_gemm_persistent"):
             L.lqer_debug_set_gemm_persistent(persist)
         rc = L.lqer_linear_gemm(C.byref(desc), xq.data_ptr(), M, wp.data_ptr(), xaq.data_ptr() if r else None,

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--r", type=int, default=32)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--iters", type=int, default=40)
-    ap.add_argument("--also-128", action="store_true", help="time every build a second time with the 128-row tiles pinned (lqer_debug_set_tile_rows)")
+    ap.add_argument("--also-128", action="store_true", help="time every build a second time with the 128-row tiles pinned (LQER_TUNE_TILE_ROWS_128)")
     ap.add_argument("--also-64", action="store_true", help="time every build once more with 64-row tiles forced (two workgroups per CU at large M)")
     ap.add_argument("--spin0", action="store_true", help="also time every build with the in-launch hand-offs' poll bound at 0 (every workgroup sums its own rows)")
     ap.add_argument("--gap", type=int, default=0, help="tiny unrelated kernels launched between the quantizer and the GEMM (boundary-effect probe)")
@@ -49,9 +49,8 @@ def main():
     dummy = torch.zeros(64, device=dev)
 
     def run(L, pin=0):
-        if hasattr(L, "lqer_debug_set_tile_rows"):
-            L.lqer_debug_set_tile_rows(pin if pin > 0 else 0)
-        L.lqer_debug_set_decode_spin(0 if pin == -1 else -1)
+        # per-call knobs ride in the descriptor (lqer_linear_desc_t.tuning, ABI 9; older builds read a prefix of the struct)
+        desc.tuning = {128: _lib.TUNE_TILE_ROWS_128, 64: _lib.TUNE_TILE_ROWS_64, -1: _lib.TUNE_DECODE_NO_POLL}.get(pin, 0)
         # (a build whose GEMM sums the partial tiles of x A itself - lqer_decode_partials - gets no xaq: two launches)
         xa = None if L.lqer_decode_partials(C.byref(desc), M) else xaq.data_ptr()
         rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xa,
