@@ -1,0 +1,593 @@
+"""One workload on this rank's GPU: setup (token batch, packed operands, launch plans), the timed regions, and the record
+bench.py prints.  Everything that is timed goes through the C ABI (lqer_quantize_act_xa + lqer_linear_gemm, or
+lqer_linear_forward for the one-launch decode route); the CPU oracle is touched only after the timed regions (parity of the
+buffers just written) and in the cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+import time
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import roofline as RL
+from .cpu_baseline import cpu_baseline
+from .hipevents import HipEvent
+from .workloads import MXINT_Q, UNQUANTIZED_AB, WORKLOADS, check_rows, flops, make_weights, make_x
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@dataclass
+class Ctx:
+    """Process-wide facts of a bench run: this rank, the job, its device, the process group (or None)."""
+    rank: int
+    world: int
+    dev: torch.device
+    dist: object  # torch.distributed or None
+
+
+@dataclass
+class Opts:
+    workload: str
+    steps: Optional[int] = None
+    warmup: Optional[int] = None
+    layers: int = 0              # override of the model's decoder-layer count (0 = the model's)
+    sweep: str = "auto"          # auto | weak | strong
+    shard: str = "none"          # none | n (column-parallel single Linear)
+    check: bool = True
+    module: bool = True          # secondary figures through the nn.Module (and shared inputs for model workloads)
+    two_streams: bool = True
+    cpu_base: bool = True
+    prewarm_ms: float = 300.0
+    graph: int = 0
+    rotate: Optional[int] = None
+    shared_weights: bool = False
+    uninstrumented: bool = True  # a second timed region without event pairs
+
+
+def timed_region(ctx: Ctx, fn, steps):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides (driver contract)."""
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(steps)
+    torch.cuda.synchronize()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
+    """Runs the workload; returns the record on rank 0 (None elsewhere)."""
+    import lqer_amd
+    from lqer_amd import _lib, ops, sweep
+
+    rank, world, dev, dist = ctx.rank, ctx.world, ctx.dev, ctx.dist
+    desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS[o.workload]
+    if o.layers > 0:
+        layers = o.layers
+        desc_txt += f" [--layers {layers}]"
+    big = M >= 8192
+    steps = o.steps if o.steps is not None else (4 if big else (400 if M <= 64 else 50))
+    # (decode sizes: a 50-step region is 0.4 ms, of which the first launch's latency and the closing synchronize are ~10 %)
+    warmup = o.warmup if o.warmup is not None else (1 if big else 10)
+    shard_n = o.shard == "n"
+    strong = shard_n or (o.sweep == "strong") or (o.sweep == "auto" and layers > 1)
+    if shard_n and (layers > 1 or len(shapes) > 1):
+        sys.exit("--shard n is the column-parallel split of ONE Linear (c2 / d1 / d16): model sweeps split by layer")
+    if strong and not shard_n and layers == 1 and world > 1:
+        sys.exit("--sweep strong needs a model workload (c3/c4/c5): a single Linear has no layers to split")
+    my_layers = range(layers) if shard_n else (sweep.layer_partition(layers, world)[rank] if strong else range(layers))
+    layers_here = len(my_layers)
+    quantize_ab = not any(qc is c for c in UNQUANTIZED_AB)
+
+    # ---- the token batch: generated on rank 0, broadcast once per distinct K (RCCL over xGMI), outside the timed region
+    xs, broadcast_ms = {}, 0.0
+    for K in sorted({K for K, _, _ in shapes}):
+        if rank == 0:
+            xd = make_x(M, K, seed=0)[0].half().to(dev)
+        else:
+            xd = torch.empty(M, K, dtype=torch.float16, device=dev)
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            sweep.broadcast_activation(xd, src=0)
+            torch.cuda.synchronize()
+            broadcast_ms += (time.perf_counter() - t0) * 1e3
+        xs[K] = xd
+
+    # ---- this rank's units: one module per distinct projection shape, weights from a per-rank seed; a model sweep re-runs
+    # each shape `count x layers owned` times per step (layers differ in values, not in cost).  --shard n: every rank
+    # builds the SAME Linear from one seed and keeps its columns [n0, n1) of W, B and the bias.
+    mods = []
+    col_ranges = {}
+    for i, (K, N, cnt) in enumerate(shapes):
+        g = torch.Generator().manual_seed(sweep.unit_seed(0 if shard_n else rank, i))
+        wts = make_weights(g, K, N, r, bias=has_bias, quantize_ab=quantize_ab)
+        n0, n1 = 0, N
+        if shard_n:
+            bo = qc.get("B_out_quantizer", qc["x_quantizer"])
+            if bo.get("name") == "block_fp" and bo["block_size"][-1] != 16:
+                sys.exit("--shard n: B_out blocks must be 16 columns (a block that spans several ranks' columns would need a reduction)")
+            col_ranges[N] = sweep.column_partition(N, world)
+            n0, n1 = col_ranges[N][rank]
+        Nl = n1 - n0
+        if Nl == 0:
+            mods.append((None, xs[K], K, 0, 0, torch.empty(M, 0, dtype=torch.float16, device=dev), wts, N))
+            continue
+        mod = lqer_amd.LinearFlexibleLqer(K, Nl, bias=has_bias, q_config=qc, l_config={"rank": r})
+        sd = {"weight": wts[0][n0:n1], "A": wts[1], "B": wts[2][:, n0:n1].contiguous()}
+        if has_bias:
+            sd["bias"] = wts[3][n0:n1]
+        mod.load_state_dict(sd)
+        mod = mod.to(dev).half()
+        y = mod(xs[K])  # packs the operands (one-time, like the reference's first forward)
+        mods.append((mod, xs[K], K, Nl, cnt * layers_here, y, wts, N))
+    torch.cuda.synchronize()
+    live = [m for m in mods if m[0] is not None]
+    if not live:
+        layers_here = 0
+
+    # decode sizes: a model walks ~3.6 GB of DISTINCT weights per token, so one 9.4 MB image re-run from the Infinity Cache
+    # says little - R copies of the Linear (own packed images; same values, same output buffer) are walked round robin
+    rotate = o.rotate if o.rotate is not None else (48 if (M <= 64 and len(shapes) == 1 and layers == 1 and not shard_n) else 0)
+    if rotate and not (M <= 64 and len(live) == 1):
+        sys.exit("--rotate is for the single-Linear decode workloads")
+    rot_mods = list(live)
+    if rotate > 1:
+        import copy
+
+        rot_mods += [(copy.deepcopy(live[0][0]),) + live[0][1:] for _ in range(rotate - 1)]
+        for m in rot_mods[1:]:
+            m[0](m[1])  # (its launch cache)
+        torch.cuda.synchronize()
+
+    L = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    gemm_events = []
+    launch_no = [0]
+    # bracket every n-th launch of the dominant kernel with HIP events: at least 8 samples inside the timed region
+    # whatever --steps is (the driver's 20-step C2 run: 8 evenly spread), at most every 10th (a pair costs ~12 us of gaps)
+    EV_TOTAL = steps * sum(m[4] for m in live)  # timed launches of the dominant kernel
+    EV_EVERY = max(1, min(10, EV_TOTAL // 8))
+    ev_on = [True]
+    ev_sample = (lambda i: i % EV_EVERY == 0) if EV_EVERY >= 10 or EV_TOTAL < 8 else \
+        (lambda i: i == 0 or (i * 8) // EV_TOTAL != ((i - 1) * 8) // EV_TOTAL)
+
+    # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
+    plans = []
+    distinct = layers > 1 and not o.shared_weights and rotate <= 1
+    distinct_keep = []  # (the cloned images stay alive for the run)
+    ws = ops.workspace(dev, max([ops.linear_sizes(mod._desc(), M).workspace for mod, *_ in live] + [256]))  # one buffer for all
+    for mod, xd, K, N, reps, y, _, _ in rot_mods:
+        desc = mod._desc()
+        if mod._x_i8 and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) != _lib.ROUTE_TILE256_I8:
+            desc = mod._desc(plain=True)  # token counts the int8 tile kernel does not serve: the bf16 kernels, same buffers
+        p = mod._packed
+        Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
+        xl, al = ops.desc_limbs(desc)  # bf16 limbs of the activation / x A images (1, 1 unless pass-through)
+        xq = ws.data_ptr()
+        xaq = xq + ((Mp * Kp * 2 * xl + 255) // 256) * 256
+        if mod._x_f16 and K % 64 == 0 and (M % 256 == 0 or M <= 64):
+            xq = xd.data_ptr()  # fp16 route: a dense, aligned fp16 tensor is its own activation image (include/lqer_hip.h)
+        rp = L.lqer_padded_r(r)
+        xscr = xaq + ((Mp * rp * 2 * al + 255) // 256) * 256
+        nscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M)
+        gscr = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+        if L.lqer_decode_partials(C.byref(desc), M):
+            xaq, gscr = None, nscr  # decode route: the GEMM reduces the partial tiles of x A left in the scratch itself
+        a_t, a_limbs = p["a_t"].data_ptr(), p["a_limbs"]
+        if mod._x_i8 and "a_t_f16" in p and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) == _lib.ROUTE_TILE256_I8:
+            a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # the int8 route's side GEMM: A as one fp16 image (as the module passes it)
+        # model sweeps: every Linear of the model owns its packed operands (same values, distinct addresses - layers differ
+        # in values, not in cost, but a weight that is re-read from the Infinity Cache 32 times is not what a model does)
+        copies = []
+        if distinct and reps > 1:
+            a_key = "a_t_f16" if a_limbs == -1 else "a_t"
+            for _ in range(reps - 1):
+                cw, ca, cb = p["w"].clone(), p[a_key].clone(), p["b_t"].clone()
+                cbias = p["bias"].clone() if p.get("bias") is not None else None
+                distinct_keep.append((cw, ca, cb, cbias))
+                copies.append((cw.data_ptr(), ca.data_ptr(), cb.data_ptr(), ops._ptr(cbias)))
+        plans.append(dict(desc=desc, dref=C.byref(desc), x=xd.data_ptr(), a_t=a_t, a_limbs=a_limbs, xq=xq, xaq=xaq, copies=copies,
+                          ws=ws.data_ptr(), ws_bytes=ws.numel(),
+                          xscr=xscr, nscr=nscr, w=p["w"].data_ptr(),
+                          b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),
+                          gscr=gscr, K=K, N=N, reps=reps, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16)))
+
+    # M <= 8 with block_fp activations in blocks of 16: lqer_linear_forward issues ONE launch
+    one_launch = (M <= 8 and r > 0 and bool(plans) and
+                  all(L.lqer_decode_partials(pl["dref"], M) and pl["a_limbs"] == 1 for pl in plans))
+
+    # the C-ABI calls of a step with their arguments bound once per stream (the launch stream, or the capture stream of
+    # --graph): at decode sizes the Python that assembles 16 arguments per call costs as much as the kernel it launches
+    fwd, qxa, gemm = L.lqer_linear_forward, L.lqer_quantize_act_xa, L.lqer_linear_gemm
+    bound = {}
+    # event pairs for the sampled launches, created ahead of the timed region (creating one costs more host time than a
+    # decode-size kernel runs)
+    ev_flags = int(os.environ.get("LQER_BENCH_EVENT_FLAGS", "0x20000000"), 0)
+    new_pair = lambda: (HipEvent(ev_flags), HipEvent(ev_flags))
+    ev_pool = [new_pair() for _ in range(64)]
+
+    def calls_for(st, pls=None):
+        pls = plans if pls is None else pls
+        if (st, id(pls)) not in bound:
+            rows = []
+            for pl in pls:
+                K, N = pl["K"], pl["N"]
+                fa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["w"], pl["a_t"], pl["b_t"], pl["a_limbs"], pl["b_limbs"], pl["bias"],
+                      pl["y"], N, pl["ws"], pl["ws_bytes"], st)
+                qa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"], pl["xq"], pl["xaq"], pl["xscr"], pl["nscr"], st)
+                ga = (pl["dref"], pl["xq"], M, pl["w"], pl["xaq"], pl["b_t"], pl["b_limbs"], pl["bias"], pl["y"], _lib.F16, N,
+                      pl["xscr"], pl["gscr"], st)
+                per_unit = [(fa, qa, ga)]
+                for cw, ca, cb, cbias in pl["copies"]:  # the other Linears of this shape: own weight / A / B / bias images
+                    per_unit.append(((pl["dref"], pl["x"], _lib.F16, M, K, cw, ca, cb, pl["a_limbs"], pl["b_limbs"], cbias,
+                                      pl["y"], N, pl["ws"], pl["ws_bytes"], st),
+                                     (pl["dref"], pl["x"], _lib.F16, M, K, ca, pl["a_limbs"], pl["xq"], pl["xaq"], pl["xscr"],
+                                      pl["nscr"], st),
+                                     (pl["dref"], pl["xq"], M, cw, pl["xaq"], cb, pl["b_limbs"], cbias, pl["y"], _lib.F16, N,
+                                      pl["xscr"], pl["gscr"], st)))
+                rows.append((pl["reps"], K, N, per_unit))
+            bound[(st, id(pls))] = rows
+        return bound[(st, id(pls))]
+
+    rot_no = [0]
+    resident = [False]  # True: every step re-runs plan 0 (the weight stays in the Infinity Cache)
+
+    def step(timed: bool, stream=stream):
+        rows = calls_for(stream)
+        if rotate > 1:
+            rows = rows[:1] if resident[0] else rows[rot_no[0] % rotate: rot_no[0] % rotate + 1]
+            rot_no[0] += 1
+        for reps, K, N, per_unit in rows:
+            for u in range(reps):
+                fa, qa, ga = per_unit[u % len(per_unit)]
+                ev = timed and ev_on[0] and ev_sample(launch_no[0])  # counts timed launches only: the first one is always sampled
+                if timed:
+                    launch_no[0] += 1
+                if one_launch:
+                    # up to 8 tokens the whole forward is ONE launch (csrc/decode1.hip) behind lqer_linear_forward - the entry
+                    # point of INTEGRATION.md; the events bracket that launch
+                    if ev:
+                        e0, e1 = ev_pool.pop() if ev_pool else new_pair()
+                        e0.record(stream)
+                    rc = fwd(*fa)
+                    if rc:
+                        _lib.check(rc, "linear_forward")
+                    if ev:
+                        e1.record(stream)
+                        gemm_events.append((e0, e1, K, N))
+                    continue
+                # the two calls of lqer_linear_forward, issued separately so that the dominant kernel can be
+                # bracketed with HIP events on the launch stream
+                rc = qxa(*qa)
+                if rc:
+                    _lib.check(rc, "quantize_act_xa")
+                if ev:
+                    e0, e1 = ev_pool.pop() if ev_pool else new_pair()
+                    e0.record(stream)
+                rc = gemm(*ga)
+                if rc:
+                    _lib.check(rc, "linear_gemm")
+                if ev:
+                    e1.record(stream)
+                    gemm_events.append((e0, e1, K, N))
+
+    mrot_no = [0]
+
+    def step_module():
+        if rotate > 1:
+            mod, xd = rot_mods[mrot_no[0] % rotate][:2]
+            mrot_no[0] += 1
+            return mod(xd)
+        for mod, xd, K, N, reps, _, _, _ in live:
+            for _ in range(reps):
+                mod(xd)
+
+    # Device clock ramp (setup, like the packing above): after idling the GPU needs tens of milliseconds of load to
+    # reach the clocks it then holds - a 60-step run (5 ms) would measure the ramp, not the kernels (C2: 850 vs 970
+    # TFLOP/s-equiv on the same box).  Untimed; the W warm-up steps and the K timed steps follow unchanged.
+    if layers_here > 0:
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < o.prewarm_ms * 1e-3:
+            for _ in range(1 if big else 20):
+                step(False)
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        step(False)
+    torch.cuda.synchronize()
+    graph = None
+    if o.graph:
+        # launch-bound steps (decode sizes: three ~3 us kernels): capture one step in a hipGraph and replay it.  The
+        # kernels cannot be bracketed with events inside a graph, so the roofline sample is taken from ungraphed
+        # launches after the timed region.
+        if steps % o.graph:
+            sys.exit("--steps must be a multiple of --graph")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(o.graph):
+                step(False, torch.cuda.current_stream(dev).cuda_stream)
+        graph.replay()
+        torch.cuda.synchronize()
+
+    def run_abi(n):
+        if graph is not None:
+            for _ in range(n // o.graph):
+                graph.replay()
+        else:
+            for _ in range(n):
+                step(True)
+
+    elapsed_rank = timed_region(ctx, run_abi, steps)
+    if graph is not None:
+        for _ in range(min(steps, 4 * EV_EVERY)):
+            step(True)
+        torch.cuda.synchronize()
+    elapsed = sweep.max_over_ranks(elapsed_rank, dev)
+
+    # the same K steps once more WITHOUT the event pairs (the instrumented region above is what the contract asks
+    # `value` and the roofline sample to share; this one says what the instrumentation costs)
+    uninstrumented = None
+    if o.uninstrumented and graph is None:
+        ev_on[0] = False
+        el_u = sweep.max_over_ranks(timed_region(ctx, run_abi, steps), dev)
+        ev_on[0] = True
+        uninstrumented = el_u
+
+    # decode workloads: the same steps once more on ONE resident weight (what rounds 1-2 reported: an upper bound)
+    resident_fig = None
+    if rotate > 1 and graph is None:
+        rot_events, gemm_events = gemm_events, []
+        resident[0] = True
+        for _ in range(warmup):
+            step(False)
+        el_res = sweep.max_over_ranks(timed_region(ctx, run_abi, steps), dev)
+        resident[0] = False
+        res_events, gemm_events = gemm_events, rot_events
+        resident_fig = {"ms_per_step": round(el_res / steps * 1e3, 4), "events": res_events}
+
+    # second timed region: the same K steps through the drop-in module (torch.empty, descriptor cache, ctypes marshalling
+    # included) - the boundary the reference's callers use
+    module = None
+    if o.module and live:
+        for _ in range(max(1, warmup // 2)):
+            step_module()
+        el_mod = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_module() for _ in range(n)], steps), dev)
+        module = {"ms_per_step": round(el_mod / steps * 1e3, 4), "vs_c_abi": round(el_mod / elapsed, 4)}
+        if M <= 64 and graph is None:
+            # decode sizes are host-bound through the module (torch.empty + ctypes per call ~8 us on a ~8 us kernel): the way a
+            # serving loop runs them is ONE captured graph per token step - here G module forwards (one per rotated weight)
+            # captured by lqer_amd.graph.GraphedCallable and replayed; the one-launch decode route is capturable
+            from lqer_amd.graph import GraphedCallable
+
+            G = max(rotate, 1) * max(1, 48 // max(rotate, 1))
+            while steps % G:
+                G -= 1
+            gm = GraphedCallable(lambda: [step_module() for _ in range(G)][-1], warmup=2)
+            gm()
+            el_g = sweep.max_over_ranks(timed_region(ctx, lambda n: [gm() for _ in range(n // G)], steps), dev)
+            module.update(graph_ms_per_step=round(el_g / steps * 1e3, 4), graph_vs_c_abi=round(el_g / elapsed, 4),
+                          graph_forwards_per_replay=G)
+
+    # third timed region (model workloads): the same Linears the way the model runs them - q/k/v and
+    # gate/up receive ONE tensor, so its activation image and one side GEMM over the members' concatenated A are made once
+    # per group (lqer_amd.linear.SharedActivation; same quantizers and GEMM kernels, results as member by member).  The
+    # headline `value` stays the conservative one: every Linear quantizes its own input, as the reference's modules do.
+    model_shared = None
+    # (secondary figures are single-rank only: a rank that fails or owns no layer would leave the others in a collective)
+    if o.module and layers > 1 and layers_here > 0 and world == 1:
+        model_shared = _shared_inputs_region(ctx, live, layers_here, warmup, steps, elapsed)
+
+    # secondary figure: the forwards of this workload are INDEPENDENT units - issued alternately on two HIP streams
+    # (own activation / x A images, scratch and output per stream) the second queue's quantizer, side GEMM and store phases
+    # run under the other forward's main loop.  A throughput figure for sweeps and serving batches; `value` stays the
+    # one-stream figure (a model's Linears form a chain: 8d sums their times)
+    two_streams = None
+    if o.two_streams and layers_here > 0 and M > 64 and graph is None and world == 1:
+        two_streams = _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm, M, warmup, steps, elapsed)
+
+    # ---- gather (outside the timed regions): per-rank elapsed time, a checksum of the first unit's output
+    ysum = float(live[0][5].float().sum().item()) if live else 0.0
+    gathered = sweep.gather_rows([elapsed_rank * 1e3 / steps, ysum, float(layers_here)], dev)
+
+    if shard_n:  # `value` of a column-parallel Linear: the UNSHARDED Linear's multiplies over the slowest rank's time
+        flops_all = float(sum(flops(M, K, N, r) * cnt * layers for K, N, cnt in shapes))
+    else:
+        flops_rank = sum(flops(M, K, N, r) * reps for _, _, K, N, reps, _, _, _ in live)
+        flops_all = sweep.sum_over_ranks(float(flops_rank), dev)
+    ms_per_step = elapsed / steps * 1e3
+    value = flops_all * steps / elapsed / 1e12
+
+    # ---- column-parallel: assemble y from every rank's columns (all-gather, outside the timed regions) for the check
+    y_full = {}
+    if shard_n:
+        for mod, xd, K, Nl, reps, y, wts, N in mods:
+            y_full[N] = sweep.all_gather_columns(y, col_ranges[N], N)
+
+    # ---- parity of what was just timed: row slices of every unit's output buffer against the CPU oracle (rank 0)
+    parity = None
+    parity_rows = None
+    if o.check and rank == 0:
+        from oracle import lqer_oracle as O  # the checker - after the timed regions, never inside them
+
+        idx = check_rows(M, every=len(mods) == 1)
+        parity_rows = int(len(idx))
+        worst = 0.0
+        h = lambda t: None if t is None else t.half().float()
+        for mod, xd, K, Nl, reps, y, wts, N in mods:
+            if not shard_n and mod is None:
+                continue
+            ref = O.lqer_linear_forward(xd[idx.to(dev)].float().cpu(), h(wts[0]), h(wts[3]) if has_bias else None, h(wts[1]), h(wts[2]), qc)
+            got = (y_full[N] if shard_n else y)[idx.to(dev)].float().cpu()
+            worst = max(worst, float((got - ref).norm() / ref.norm()))
+        parity = worst
+        print(f"# [{o.workload}] parity vs CPU oracle ({len(idx)} rows x {len(mods)} shapes): rel-L2 {parity:.3e}", file=sys.stderr)
+
+    if rank != 0:
+        return None
+
+    # ---- roofline of the dominant kernel (benchlib/roofline.py) from the event samples taken inside the timed region
+    cal_x = (live[0][1], live[0][2]) if live else None
+    ev_overhead_ms = RL.event_pair_overhead_ms(L, _lib, ops, dev, stream, cal_x, new_pair, M) if live else 0.0
+    routes = sorted({pl["route"] for pl in plans})
+    int8 = routes == [_lib.ROUTE_TILE256_I8]  # every GEMM of the step ran the int8 MFMA main loop
+    rl = RL.mfma_roofline(gemm_events, ev_overhead_ms, M, r, routes, int8, one_launch, _lib, o.workload, ev_flags)
+    if M <= 64:
+        rl = RL.hbm_roofline(gemm_events, ev_overhead_ms, M, r, has_bias, routes, one_launch, _lib, o.workload, ev_flags, rotate,
+                             ms_per_step, resident_fig)
+    f16x = bool(live) and live[0][0]._x_f16
+    out = {
+        "metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv",
+        "value": round(value, 2),
+        "unit": "TFLOP/s-equiv",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        # the arithmetic type of the main loop's MFMA operands
+        "dtype": "int8" if (M > 64 and int8) else ("f16" if f16x else "bf16"),
+        "data": "synthetic",
+        "config": {"workload": desc_txt + (f" [{rotate} distinct packed weights walked round robin: {rotate * 9.4:.0f} MB > the 256 MB "
+                                            "Infinity Cache]" if rotate > 1 else ""), "tokens_per_step": M, "rank": r,
+                   "formats": "x %s, W MXINT4/%s, A_out,B_out as x, y fp16" % (
+                       "MXINT8/%s" % qc["x_quantizer"]["block_size"][-1] if qc["x_quantizer"]["name"] == "block_fp"
+                       else ("fp16 pass-through (fp16 MFMA main loop)" if f16x else "fp16 pass-through (2 bf16 limbs)"),
+                       qc["w_quantizer"]["block_size"][-1]),
+                   "boundary": ("C ABI (lqer_linear_forward per Linear: one launch)" if one_launch else
+                                "C ABI (lqer_quantize_act_xa + lqer_linear_gemm per Linear, pre-built plans)") +
+                               "; the nn.Module figure is in `module`",
+                   "sharding": ("ONE Linear column-parallel: rank g owns W[n0:n1], B[:, n0:n1] (cuts at multiples of 16 - exact, no "
+                                "reduction), y[:, n0:n1] all-gathered outside the timed region" if shard_n else
+                                ("decoder layers split over the ranks, ceil(L/G) consecutive layers each (infer_device_map.py:29-37)"
+                                 if strong else "every rank runs its own Linear unit(s) of the workload")) +
+                               "; x broadcast from rank 0 and per-rank results gathered outside the timed region, no data-path collective",
+                   "layers_per_rank": [int(row[2]) for row in gathered],
+                   "column_shard": {str(N): [list(c) for c in rg] for N, rg in col_ranges.items()} if shard_n else None,
+                   "weights": ("one packed image set per Linear of the model: %.2f GB walked per step on rank 0" % (
+                       sum(sum(t.numel() * t.element_size() for t in c if t is not None) for c in distinct_keep) / 1e9
+                       + sum(m[0]._packed["w"].numel() for m in live) / 1e9) if distinct else
+                       ("one packed image set per projection shape, re-run for every layer" if layers > 1 else "one Linear"))},
+        "tokens_per_s": round(M * steps / elapsed * (1 if strong else world), 1),
+        "launch": ("hipGraph replay, %d steps per graph" % o.graph) if graph is not None else "direct launches",
+        "prewarm_ms": o.prewarm_ms,
+        "broadcast_ms": round(broadcast_ms, 3),
+        "roofline": rl,
+        # the same K steps without the roofline's event pairs (what the instrumentation inside the timed region costs)
+        "uninstrumented": None if uninstrumented is None else {
+            "ms_per_step": round(uninstrumented / steps * 1e3, 4), "value": round(flops_all * steps / uninstrumented / 1e12, 2)},
+        "module": module,
+        # (model workloads) q/k/v and gate/up sharing one quantized input, as the model runs them; `value` does not use it
+        "model_shared_inputs": model_shared if model_shared is None or "error" in model_shared else dict(
+            model_shared, value=round(flops_all / (model_shared["ms_per_step"] * 1e-3) / 1e12, 2)),
+        # independent forwards alternating on two HIP streams (throughput of sweeps / serving batches; not `value`)
+        "two_streams": two_streams if two_streams is None or "error" in two_streams else dict(
+            two_streams, value=round(flops_all / (two_streams["ms_per_step"] * 1e-3) / 1e12, 2)),
+        "parity_rel_l2": None if parity is None else float(f"{parity:.3e}"),
+        "parity_rows": parity_rows,
+        "rank_ms_per_step": [round(row[0], 4) for row in gathered],
+        "rank_checksums": [round(row[1], 3) for row in gathered],
+    }
+    if world == 1 and o.cpu_base:
+        K0, N0, _ = shapes[0]
+        out["cpu_baseline"] = cpu_baseline(M, K0, N0, r, qc)
+    if parity is not None:
+        assert parity <= 1e-3, f"[{o.workload}] parity of the timed outputs vs the CPU oracle: rel-L2 {parity:.3e} > 1e-3"
+    return out
+
+
+def _shared_inputs_region(ctx, live, layers_here, warmup, steps, elapsed):
+    import copy
+
+    from lqer_amd import sweep
+    from lqer_amd.linear import SharedActivation
+
+    try:
+        units = []  # per shape: (group members, solo module or None, solo calls per layer, x)
+        for mod, xd, K, N, reps, _, _, _ in live:
+            cnt = reps // layers_here
+            gsz = 3 if (cnt >= 3 and K == N) else (2 if cnt == 2 else 0)
+            solo_n = cnt - gsz
+            copies = [copy.deepcopy(mod) for _ in range(max(gsz - 1, 0) + (1 if solo_n else 0))]
+            solo = copies.pop() if solo_n else None
+            members = []
+            if gsz:
+                grp = SharedActivation([mod] + copies)
+                members = grp.members if grp.enabled else []
+                if not grp.enabled:
+                    solo, solo_n = mod, cnt
+            units.append((members, solo, solo_n, xd))
+        if not any(members for members, _, _, _ in units):
+            return None
+
+        def step_shared():
+            for _ in range(layers_here):
+                for members, solo, solo_n, xd in units:
+                    for m in members:
+                        m(xd)
+                    for _ in range(solo_n):
+                        solo(xd)
+
+        for _ in range(max(1, warmup // 2)):
+            step_shared()
+        el_sh = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_shared() for _ in range(n)], steps), ctx.dev)
+        return {"ms_per_step": round(el_sh / steps * 1e3, 4), "vs_c_abi": round(el_sh / elapsed, 4),
+                "groups_per_layer": [len(members) for members, _, _, _ in units if members]}
+    except Exception as e:  # (a secondary figure must not cost the bench line)
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
+def _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm, M, warmup, steps, elapsed):
+    from lqer_amd import _lib, sweep
+
+    dev = ctx.dev
+    try:
+        # (two explicit streams: the legacy default stream this script otherwise launches on serialises with every other stream)
+        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ws2 = torch.empty(ws.numel(), dtype=torch.uint8, device=dev)
+        plans2, ys2 = [], []
+        for pl in plans:
+            q = dict(pl)
+            for k in ("xq", "xaq", "xscr", "ws"):
+                if q[k] is not None and ws.data_ptr() <= q[k] < ws.data_ptr() + ws.numel():
+                    q[k] = q[k] - ws.data_ptr() + ws2.data_ptr()
+            ys2.append(torch.empty(M, q["N"], dtype=torch.float16, device=dev))
+            q["y"] = ys2[-1].data_ptr()
+            plans2.append(q)
+        unit_no, on_b = [0], set()
+
+        def step_two():
+            ra, rb = calls_for(s1.cuda_stream), calls_for(s2.cuda_stream, plans2)
+            for i, ((reps, K, N, pa), (_, _, _, pb)) in enumerate(zip(ra, rb)):
+                for u in range(reps):
+                    if unit_no[0] % 2:
+                        on_b.add((i, u % len(pa)))
+                    _, qa, ga = (pa if unit_no[0] % 2 == 0 else pb)[u % len(pa)]
+                    unit_no[0] += 1
+                    rc = qxa(*qa) or gemm(*ga)
+                    if rc:
+                        _lib.check(rc, "two-stream step")
+
+        s1.wait_stream(torch.cuda.current_stream(dev))
+        s2.wait_stream(torch.cuda.current_stream(dev))
+        for _ in range(max(2, warmup // 2)):
+            step_two()
+        torch.cuda.synchronize()
+        for i, ((mod, xd, K, N, reps, y, _, _), y2) in enumerate(zip(live, ys2)):
+            # both queues produce the bits of the one-stream run (units of a plan that share one image set)
+            if any(pi == i for pi, _ in on_b):  # (every image set of a plan holds the same values)
+                assert torch.equal(y.view(torch.int16), y2.view(torch.int16)), "two-stream outputs differ"
+        el_two = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_two() for _ in range(n)], steps), dev)
+        return {"ms_per_step": round(el_two / steps * 1e3, 4), "vs_one_stream": round(elapsed / el_two, 4)}
+    except Exception as e:  # (a secondary figure must not cost the bench line)
+        return {"error": f"{type(e).__name__}: {e}"[:200]}

@@ -94,3 +94,34 @@ def sum_over_ranks(value: float, device: torch.device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def column_partition(n_out: int, world: int, granule: int = 16) -> List[Tuple[int, int]]:
+    """Column-parallel split of ONE Linear (SURVEY.md §8e "single-Linear scaling"): rank g owns the output columns
+    [n0, n1), cut at multiples of `granule` (16: a B_out block and a packed weight panel are 16 columns, and W's blocks run
+    along K - so every rank's y[:, n0:n1] is exactly the unsharded result, no reduction).  ceil(blocks / G) consecutive
+    blocks per rank, like the layer rule; trailing ranks may own fewer or no columns."""
+    if n_out < 0 or world <= 0 or granule <= 0:
+        raise ValueError("n_out >= 0, world > 0 and granule > 0 required")
+    blocks = -(-n_out // granule)
+    per = math.ceil(blocks / world) if blocks else 0
+    return [(min(n_out, g * per * granule), min(n_out, (g + 1) * per * granule)) for g in range(world)]
+
+
+def all_gather_columns(y_local: torch.Tensor, ranges: Sequence[Tuple[int, int]], n_out: int) -> torch.Tensor:
+    """Assemble y [M, n_out] from every rank's column slice y[:, n0:n1] (all-gather over RCCL / gloo, OUTSIDE any timed
+    region; slices are padded to the widest one for the collective).  Identity without a process group."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return y_local
+    M = y_local.shape[0]
+    width = max(n1 - n0 for n0, n1 in ranges)
+    buf = torch.zeros(M, width, dtype=y_local.dtype, device=y_local.device)
+    buf[:, : y_local.shape[1]] = y_local
+    parts = [torch.empty_like(buf) for _ in ranges]
+    dist.all_gather(parts, buf)
+    out = torch.empty(M, n_out, dtype=y_local.dtype, device=y_local.device)
+    for (n0, n1), p in zip(ranges, parts):
+        out[:, n0:n1] = p[:, : n1 - n0]
+    return out

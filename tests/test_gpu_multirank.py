@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("workload,extra,scaling,layers", [("c3", ["--layers", "3"], "strong", [2, 1]), ("c2", [], "weak", [1, 1])])
+@pytest.mark.parametrize("workload,extra,scaling,layers", [("c3", ["--layers", "3"], "strong", [2, 1]), ("c2", [], "weak", [1, 1]),
+                                                           ("c2", ["--shard", "n"], "strong", [1, 1])])
 def test_two_ranks_on_one_gpu(workload, extra, scaling, layers):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -34,3 +35,33 @@ def test_two_ranks_on_one_gpu(workload, extra, scaling, layers):
     assert len(d["rank_ms_per_step"]) == 2 and all(t > 0 for t in d["rank_ms_per_step"])
     assert d["parity_rel_l2"] is not None and d["parity_rel_l2"] <= 1e-3
     assert d["value"] > 0 and d["two_streams"] is None and d["model_shared_inputs"] is None  # (secondary regions: single rank only)
+    if "--shard" in extra:  # column-parallel single Linear: rank g owns the columns [n0, n1); the all-gathered y meets the oracle
+        assert d["config"]["column_shard"] == {"4096": [[0, 2048], [2048, 4096]]}
+
+
+def test_column_parallel_linear_is_bit_identical_to_the_unsharded_forward():
+    """SURVEY.md §8e, optional row: a Linear split column-parallel at multiples of 16 needs no reduction - W's blocks run along
+    K, B_out blocks are 16 columns - so every shard's y[:, n0:n1] carries the BITS of the unsharded forward.  Three uneven
+    shards (lqer_amd.sweep.column_partition, 16-column granules) on one GPU, bias included."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import lqer_amd
+    from bench import OPT_Q, make_case
+    from lqer_amd import sweep
+
+    dev = "cuda:0"
+    M, K, N, r = 300, 512, 1000, 32
+    x, W, A, B, b = make_case(M, K, N, r, seed=21, bias=True)
+
+    def build(n0, n1):
+        mod = lqer_amd.LinearFlexibleLqer(K, n1 - n0, bias=True, q_config=OPT_Q, l_config={"rank": r})
+        mod.load_state_dict({"weight": W[n0:n1], "A": A, "B": B[:, n0:n1].contiguous(), "bias": b[n0:n1]})
+        return mod.to(dev).half()
+
+    xd = x.half().to(dev)
+    full = build(0, N)(xd)
+    ranges = sweep.column_partition(N, 3)
+    assert ranges == [(0, 336), (336, 672), (672, 1000)] and all(n0 % 16 == 0 for n0, _ in ranges)
+    for n0, n1 in ranges:
+        assert torch.equal(build(n0, n1)(xd), full[:, n0:n1]), (n0, n1)
+    # (OPT_Q's bias blocks are 16 wide: a shard boundary at a multiple of 16 keeps them whole as well)

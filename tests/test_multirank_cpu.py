@@ -210,3 +210,63 @@ def test_bench_launcher_relays_the_childs_exit_code():
                           "--sweep", "strong"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_column_partition_rule():
+    """Column-parallel split of one Linear: cuts at multiples of 16, ceil(blocks / G) blocks per rank, trailing
+    ranks may own fewer or no columns, the ranges tile [0, N) exactly."""
+    assert sweep.column_partition(4096, 2) == [(0, 2048), (2048, 4096)]
+    assert sweep.column_partition(4096, 8) == [(512 * g, 512 * (g + 1)) for g in range(8)]
+    assert sweep.column_partition(11008, 8) == [(1376 * g, 1376 * (g + 1)) for g in range(8)]
+    assert sweep.column_partition(1000, 3) == [(0, 336), (336, 672), (672, 1000)]  # 63 blocks -> 21 per rank, last one ragged
+    assert sweep.column_partition(40, 4) == [(0, 16), (16, 32), (32, 40), (40, 40)]  # the last rank owns nothing
+    for N, G in ((4096, 3), (11008, 5), (50, 8), (16, 2)):
+        rg = sweep.column_partition(N, G)
+        assert rg[0][0] == 0 and rg[-1][1] == N and all(a[1] == b[0] for a, b in zip(rg, rg[1:]))
+        assert all(n0 % 16 == 0 for n0, n1 in rg if n1 > n0)  # (every non-empty shard starts on a 16-column granule)
+    with pytest.raises(ValueError):
+        sweep.column_partition(16, 0)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        M, N = 5, 40
+        ranges = sweep.column_partition(N, world)
+        full = torch.arange(M * N, dtype=torch.float32).reshape(M, N)
+        n0, n1 = ranges[rank]
+        got = sweep.all_gather_columns(full[:, n0:n1].contiguous(), ranges, N)
+        q.put((rank, bool(torch.equal(got, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_columns_two_ranks_uneven():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]  # 40 columns over 2 ranks: 32 + 8, padded to the widest slice for the collective
+
+
+def test_dry_run_column_shard_line():
+    """`bench.py --gpus 2 --shard n --dry-run-cpu`: the launcher, the column split and the JSON line of the column-parallel run."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--shard", "n", "--dry-run-cpu"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["column_shard"] == {"4096": [0, 2048]}
