@@ -160,6 +160,16 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     ev_on = [True]
     ev_sample = (lambda i: i % EV_EVERY == 0) if EV_EVERY >= 10 or EV_TOTAL < 8 else \
         (lambda i: i == 0 or (i * 8) // EV_TOTAL != ((i - 1) * 8) // EV_TOTAL)
+    # several projection shapes: every shape gets its own samples (>= 4 where it has that many timed launches; per_shape of the
+    # roofline object) - the global rule above could leave a rare shape without one
+    shape_total = {(m[2], m[3]): steps * m[4] for m in live}
+    shape_seen = {k: 0 for k in shape_total}
+
+    def ev_sample_shape(K, N):
+        tot, i = shape_total[(K, N)], shape_seen[(K, N)]
+        shape_seen[(K, N)] = i + 1
+        every = max(1, min(10, tot // 4))
+        return i % every == 0
 
     # per-module launch constants (descriptor, workspace carving), built once: decode-size steps are host-bound
     plans = []
@@ -250,7 +260,8 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         for reps, K, N, per_unit in rows:
             for u in range(reps):
                 fa, qa, ga = per_unit[u % len(per_unit)]
-                ev = timed and ev_on[0] and ev_sample(launch_no[0])  # counts timed launches only: the first one is always sampled
+                # (counts timed launches only: the first one is always sampled)
+                ev = timed and ev_on[0] and (ev_sample(launch_no[0]) if len(shape_total) == 1 else ev_sample_shape(K, N))
                 if timed:
                     launch_no[0] += 1
                 if one_launch:
@@ -394,6 +405,11 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     if o.two_streams and layers_here > 0 and M > 64 and graph is None and world == 1:
         two_streams = _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm, M, warmup, steps, elapsed)
 
+    # decode workloads (M <= 8): the Linears a model hands the SAME token to - q/k/v - as ONE launch (lqer_linear_forward_group)
+    group_fig = None
+    if one_launch and layers == 1 and len(live) == 1 and world == 1 and graph is None and not shard_n:
+        group_fig = _decode_group_region(ctx, live[0], M, r, has_bias, rotate, warmup, steps, ev_flags)
+
     # ---- gather (outside the timed regions): per-rank elapsed time, a checksum of the first unit's output
     ysum = float(live[0][5].float().sum().item()) if live else 0.0
     gathered = sweep.gather_rows([elapsed_rank * 1e3 / steps, ysum, float(layers_here)], dev)
@@ -487,6 +503,9 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         "uninstrumented": None if uninstrumented is None else {
             "ms_per_step": round(uninstrumented / steps * 1e3, 4), "value": round(flops_all * steps / uninstrumented / 1e12, 2)},
         "module": module,
+        # (decode) three Linears that share their input - q/k/v - as one launch: per-Linear time, the launch against HBM, and the
+        # same through the eager nn.Modules behind a SharedActivation
+        "group": group_fig,
         # (model workloads) q/k/v and gate/up sharing one quantized input, as the model runs them; `value` does not use it
         "model_shared_inputs": model_shared if model_shared is None or "error" in model_shared else dict(
             model_shared, value=round(flops_all / (model_shared["ms_per_step"] * 1e-3) / 1e12, 2)),
@@ -591,3 +610,103 @@ def _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm, M, warmup, s
         return {"ms_per_step": round(el_two / steps * 1e3, 4), "vs_one_stream": round(elapsed / el_two, 4)}
     except Exception as e:  # (a secondary figure must not cost the bench line)
         return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
+def _decode_group_region(ctx, unit, M, r, has_bias, rotate, warmup, steps, ev_flags, n_members=3):
+    """q/k/v at decode sizes: `n_members` Linears of the workload's shape (own packed images each) that are handed the same
+    tokens, run as ONE launch through lqer_linear_forward_group; `rotate // n_members` such groups are walked round robin so
+    that the weights stream from HBM.  Reports per-Linear step time, the launch's HIP-event time against the HBM peak
+    (algorithmic bytes: every member's packed W, B^T, bias and y, the concatenated A^T, x) and the same groups through the
+    eager nn.Modules (SharedActivation: one launch + two cached outputs per token step)."""
+    import copy
+
+    from lqer_amd import _lib, ops, sweep
+    from lqer_amd.linear import SharedActivation
+
+    from .workloads import HBM_PEAK_GBS
+
+    dev = ctx.dev
+    try:
+        mod, xd, K, N = unit[0], unit[1], unit[2], unit[3]
+        L = _lib.lib()
+        n_groups = max(1, (rotate or n_members) // n_members)
+        groups = []
+        for _ in range(n_groups):
+            members = [copy.deepcopy(mod) for _ in range(n_members)]
+            grp = SharedActivation(members)
+            if not grp.enabled:
+                return {"error": "the workload's Linears do not form a SharedActivation group"}
+            outs = [m(xd) for m in members]  # packs, builds the group plan
+            groups.append((grp, members))
+        torch.cuda.synchronize()
+        dtc = ops.dtype_code(xd)
+        plans = [g._dplans.get((M, dtc)) for g, _ in groups]
+        if any(p is None for p in plans):
+            return {"error": "lqer_linear_forward_group refused the group"}
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ws = ops.workspace(dev, max(p["ws"] for p in plans))
+        ybuf = torch.empty(n_members, M, N, dtype=torch.float16, device=dev)
+        calls = []
+        for p in plans:
+            for i in range(n_members):
+                p["tab"][i].y = ybuf[i].data_ptr()
+            calls.append((p["tab"], p["n"], xd.data_ptr(), dtc, M, K, p["a_t"], 1, ws.data_ptr(), ws.numel(), stream))
+        fwd = L.lqer_linear_forward_group
+        no, events = [0], []
+        new_pair = lambda: (HipEvent(ev_flags), HipEvent(ev_flags))
+        pool = [new_pair() for _ in range(40)]
+
+        def step_abi(timed):
+            args = calls[no[0] % n_groups]
+            ev = timed and no[0] % 10 == 0 and pool
+            no[0] += 1
+            if ev:
+                e0, e1 = pool.pop()
+                e0.record(stream)
+            rc = fwd(*args)
+            if rc:
+                _lib.check(rc, "linear_forward_group")
+            if ev:
+                e1.record(stream)
+                events.append((e0, e1))
+
+        for _ in range(warmup):
+            step_abi(False)
+        el = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_abi(True) for _ in range(n)], steps), dev)
+        mno = [0]
+
+        def step_mod():
+            _, members = groups[mno[0] % n_groups]
+            mno[0] += 1
+            for m in members:
+                m(xd)
+
+        for _ in range(max(1, warmup // 2)):
+            step_mod()
+        el_m = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_mod() for _ in range(n)], steps), dev)
+        # the pair overhead, as for the headline sample
+        cal = []
+        for _ in range(16):
+            fwd(*calls[0])
+            c0, c1 = new_pair()
+            c0.record(stream), c1.record(stream)
+            cal.append((c0, c1))
+        torch.cuda.synchronize()
+        ovh = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2]
+        tot_ms = sum(max(e0.elapsed_time(e1) - ovh, 1e-6) for e0, e1 in events)
+        nl = max(len(events), 1)
+        Kp, Np, rp = -(-K // 64) * 64, -(-N // 256) * 256, -(-r // 16) * 16
+        by = n_members * (Np * Kp * 0.5625 + Np * rp * 2 + M * N * 2 + (Np * 4 if has_bias else 0)) + M * K * 2 + n_members * rp * Kp * 2
+        gbs = by / (tot_ms / nl * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        for g, members in groups:
+            for m in members:
+                m._group = None
+        return {"members": n_members, "groups_walked": n_groups, "weights_mb_walked": round(n_groups * n_members * Np * Kp * 0.5625 / 1e6, 1),
+                "ms_per_step": round(el / steps * 1e3, 4), "ms_per_linear": round(el / steps / n_members * 1e3, 4),
+                "kernel": "k_decode1 (one launch for the group)", "avg_launch_us": round(tot_ms / nl * 1e3, 2), "launches": nl,
+                "algorithmic_bytes_per_launch": int(by), "achieved": round(gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "event_pair_overhead_us": round(ovh * 1e3, 2),
+                "module": {"ms_per_step": round(el_m / steps * 1e3, 4), "ms_per_linear": round(el_m / steps / n_members * 1e3, 4),
+                           "vs_c_abi": round(el_m / el, 4)}}
+    except Exception as e:  # (a secondary figure must not cost the bench line)
+        return {"error": f"{type(e).__name__}: {e}"[:300]}

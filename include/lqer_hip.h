@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 9
+#define LQER_ABI_VERSION 10
 
 /* error codes */
 #define LQER_OK 0
@@ -258,6 +258,33 @@ int lqer_decode_partials(const lqer_linear_desc_t* desc, int64_t M);
 int lqer_linear_gemm_ld(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M, const void* w_packed,
                         const void* xaq_bf16, int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q,
                         void* y, int dtype, int64_t ldy, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- decode: Linears that are handed the SAME tokens in ONE launch ---------------------------------------------------
+ * q/k/v and gate/up receive one tensor (reference models/llama_decoder.py:222-224, :104; opt_decoder.py q/k/v).  At decode
+ * sizes a forward is a chain of latencies around a 9 MB weight stream; a group's members run as ONE launch of the one-launch
+ * decode route (see lqer_linear_forward above): the producers multiply x with the concatenation of the members' A, every
+ * member's weight-streaming workgroups pick their rank columns out of the shared tiles.  Per member the arithmetic is that of
+ * its own lqer_linear_forward: the same bits.
+ *   members[i]: the member's descriptor, packed operands (as for lqer_linear_forward) and output y_i [M, N_i] (row stride ldy);
+ *   a_t_cat:    A^T of the members concatenated along the rank: bf16 [sum of padded ranks][padded K] - lqer_pack_lowrank of
+ *               [A_0 | A_1 | ...] (each A_i zero-padded to its padded rank); a_limbs must be 1 (8-bit MXINT values);
+ *   workspace:  >= lqer_group_workspace_bytes(K, sum of padded ranks), 16-byte aligned.
+ * Served: 2..4 members with equal in_features and equal x / A_out / B_out formats, each with lqer_decode_partials(desc, M) == 1,
+ * M <= 8, 16-byte aligned rows of x, sum of padded ranks <= 128.  Anything else returns LQER_E_UNSUPPORTED WITHOUT launching:
+ * the caller then runs the members one by one. */
+typedef struct lqer_group_member {
+  const lqer_linear_desc_t* desc;
+  const void* w_packed;
+  const void* b_t;
+  int32_t b_limbs;
+  const float* bias_q;
+  void* y;
+  int64_t ldy;
+} lqer_group_member_t;
+size_t lqer_group_workspace_bytes(int64_t K, int64_t rank_padded_sum);
+int lqer_linear_forward_group(const lqer_group_member_t* members, int n_members, const void* x, int dtype, int64_t M,
+                              int64_t ldx, const void* a_t_cat, int a_limbs, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* ---- pass-through activations ("A16": x_quantizer = passthrough, reference quantizers/passthrough.py:1, every
  * experiments/configs/template/ *-int.toml) ------------------------------------------------------------------

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
@@ -41,6 +41,12 @@ class LinearDesc(C.Structure):
         ("b_out_fmt", QFmt),
         ("tuning", C.c_int32),  # LQER_TUNE_* (0 = defaults): per-call kernel-variant knobs of tests / measurements
     ]
+
+
+class GroupMember(C.Structure):
+    """lqer_group_member_t: one Linear of a one-launch decode group (lqer_linear_forward_group)."""
+    _fields_ = [("desc", C.POINTER(LinearDesc)), ("w_packed", C.c_void_p), ("b_t", C.c_void_p), ("b_limbs", C.c_int32),
+                ("bias_q", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64)]
 
 
 class LinearSizes(C.Structure):
@@ -76,6 +82,8 @@ SIGNATURES = {
     "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "lqer_decode_partials": (_i, [_dp, _i64]),
+    "lqer_group_workspace_bytes": (_sz, [_i64, _i64]),
+    "lqer_linear_forward_group": (_i, [C.POINTER(GroupMember), _i, _vp, _i, _i64, _i64, _vp, _i, _vp, _sz, _vp]),
     "lqer_gemm_route": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),

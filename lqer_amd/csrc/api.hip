@@ -572,7 +572,8 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
       g.b_limbs = b_limbs;
       g.aout = make_qp(d->a_out_fmt);
       const int bout = d->b_out_fmt.kind == LQER_Q_PASSTHROUGH ? 0 : 1;  // (decode_partials_ok: pass-through or blocks of 16)
-      rc = decode1_dispatch(g, dtype, x, ldx, d->in_features, make_qp(d->x_fmt), (const bf16_t*)a_t, bout, xa_scratch, nscr,
+      const DecodeMember one{g.wp, g.bt, g.bias, g.y, g.ldy, g.N, g.Np, g.rp, g.b_limbs};
+      rc = decode1_dispatch(g, dtype, x, ldx, d->in_features, make_qp(d->x_fmt), (const bf16_t*)a_t, bout, &one, 1, xa_scratch, nscr,
                             (hipStream_t)stream);
       if (rc != LQER_E_UNSUPPORTED) return rc;
     }
@@ -587,6 +588,59 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   if (rc) return rc;
   return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch,
                           lqer_linear_gemm_scratch_bytes(d, M), stream);
+}
+
+size_t lqer_group_workspace_bytes(int64_t K, int64_t rank_padded_sum) {
+  return (K > 0 && rank_padded_sum > 0) ? (decode1_scratch_bytes(lqer_padded_k(K), (int)rank_padded_sum) + 255) / 256 * 256 : 0;
+}
+
+int lqer_linear_forward_group(const lqer_group_member_t* members, int n_members, const void* x, int dtype, int64_t M, int64_t ldx,
+                              const void* a_t_cat, int a_limbs, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!members || n_members < 1 || !x || !a_t_cat || !workspace || M < 0) {
+    set_error("linear_forward_group: bad argument");
+    return LQER_E_INVALID;
+  }
+  if (M == 0) return LQER_OK;
+  const lqer_linear_desc_t* d0 = members[0].desc;
+  const int esz = dtype == LQER_F32 ? 4 : 2;
+  auto same = [](const lqer_qfmt_t& a, const lqer_qfmt_t& b) {
+    return a.kind == b.kind && a.width == b.width && a.block == b.block && a.exp_width == b.exp_width && a.exp_bias == b.exp_bias;
+  };
+  // the one-launch route's conditions (lqer_linear_forward), for every member; anything else: the caller's member-by-member loop
+  bool ok = n_members >= 2 && n_members <= 4 && M <= 8 && a_limbs == 1 && d0 && !x_is_f16(d0) && ((uintptr_t)x & 15) == 0 &&
+            (ldx * esz) % 16 == 0 && ((uintptr_t)workspace & 15) == 0;
+  DecodeMember mem[4];
+  int64_t rp_all = 0;
+  for (int i = 0; ok && i < n_members; ++i) {
+    const lqer_group_member_t& m = members[i];
+    const lqer_linear_desc_t* d = m.desc;
+    ok = d && m.w_packed && m.b_t && m.y && decode_partials_ok(d, M) && d->in_features == d0->in_features && same(d->x_fmt, d0->x_fmt) &&
+         same(d->a_out_fmt, d0->a_out_fmt) && same(d->b_out_fmt, d0->b_out_fmt) && m.b_limbs >= 1 && m.b_limbs <= 3 &&
+         m.ldy >= d->out_features && ldx >= d->in_features;
+    if (!ok) break;
+    mem[i] = DecodeMember{(const uint8_t*)m.w_packed, (const bf16_t*)m.b_t, d->has_bias ? m.bias_q : nullptr, m.y, m.ldy, d->out_features,
+                          (int)lqer_padded_n(d->out_features), (int)lqer_padded_r(d->rank), m.b_limbs};
+    rp_all += lqer_padded_r(d->rank);
+  }
+  if (!ok || rp_all > 128) {
+    set_error("linear_forward_group: outside the one-launch decode route (2..4 members with equal K and x / A_out / B_out formats, "
+              "lqer_decode_partials, M <= 8, one limb of A, aligned x): run the members one by one");
+    return LQER_E_UNSUPPORTED;
+  }
+  if (workspace_bytes < lqer_group_workspace_bytes(d0->in_features, rp_all)) {
+    set_error("linear_forward_group: workspace %zu B < %zu B", workspace_bytes, lqer_group_workspace_bytes(d0->in_features, rp_all));
+    return LQER_E_WORKSPACE;
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  int rc = gemm_shape_args(d0, M, dtype, g);  // the shared part: M, Kp, formats
+  if (rc) return rc;
+  g.aout = make_qp(d0->a_out_fmt);
+  const int bout = d0->b_out_fmt.kind == LQER_Q_PASSTHROUGH ? 0 : 1;  // (decode_partials_ok: pass-through or blocks of 16)
+  rc = decode1_dispatch(g, dtype, x, ldx, d0->in_features, make_qp(d0->x_fmt), (const bf16_t*)a_t_cat, bout, mem, n_members, workspace,
+                        workspace_bytes, (hipStream_t)stream);
+  if (rc == LQER_E_UNSUPPORTED) set_error("linear_forward_group: shape outside the one-launch decode kernel (K too long for its LDS image)");
+  return rc;
 }
 
 int lqer_desc_limbs(const lqer_linear_desc_t* d, int* act, int* xa) {

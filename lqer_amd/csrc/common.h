@@ -369,8 +369,18 @@ __host__ inline const float* i8_row_scales(const void* xq8, int64_t M, int64_t K
 }
 // Weight image: per (n tile of 256 rows, step of 128 k) one block of I8_WBLOCK bytes - 256 rows x 64 B of
 // two's-complement nibbles, then 256 shift bytes -, then the row scales fp32 [Np] (gemm_w4a8_i8.hip has the details).
+// ... and one MODE byte per n tile (256-byte padded): how the tile's per-(row, group) exponents are carried (I8_MODE_*).
+constexpr int I8_MODE_NONE = 0;      // every group of every row has the row's exponent: plain accumulation
+constexpr int I8_MODE_FOLD = 1;      // shift bytes s = e[n,g] - emin[n]: the group sums are folded with v_lshl_add_u32
+constexpr int I8_MODE_PRESHIFT = 2;  // shift bytes q = emax[n] - e[n,g] <= 4: the int8 lane is cw << (4 - q), no folds
+constexpr int I8_MODE_PRESHIFT1 = 3; // the same with q <= 1 everywhere in the tile: the sign fill is the sign bit itself (7 instead of 11
+                                     // vector instructions per 8 weights)
+__host__ __device__ inline size_t i8_weight_mode_offset(int64_t Np, int64_t nk8) {
+  return (size_t)(Np / 256) * nk8 * I8_WBLOCK + (size_t)Np * sizeof(float);
+}
 __host__ inline size_t i8_weight_image_bytes(int64_t N, int64_t K) {
-  return (size_t)(lqer_padded_n(N) / 256) * (padded_k8(K) / I8_BK) * I8_WBLOCK + (size_t)lqer_padded_n(N) * sizeof(float);
+  const int64_t Np = lqer_padded_n(N);
+  return i8_weight_mode_offset(Np, padded_k8(K) / I8_BK) + (size_t)((Np / 256 + 255) / 256 * 256);
 }
 
 // ---- cross-file declarations ----------------------------------------------------------------------
@@ -454,8 +464,16 @@ int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStr
 
 // decode1.hip: the whole forward of M <= 8 tokens in one launch (LQER_E_UNSUPPORTED without launching when outside its shapes)
 size_t decode1_scratch_bytes(int64_t Kp, int rp);
-int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, const QP& qx, const bf16_t* a_t, int bout, void* scratch,
-                     size_t scratch_bytes, hipStream_t st);
+struct DecodeMember {  // one Linear of a one-launch decode forward (a group shares the tokens and the launch)
+  const uint8_t* wp;
+  const bf16_t* bt;
+  const float* bias;
+  void* y;
+  int64_t ldy;
+  int N, Np, rp, b_limbs;
+};
+int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, const QP& qx, const bf16_t* a_t, int bout,
+                     const DecodeMember* mem, int nmem, void* scratch, size_t scratch_bytes, hipStream_t st);
 
 size_t qmatmul_workspace_bytes(int64_t batch, int64_t K, int64_t S2);  // matmul_q.hip
 int qmatmul_dispatch(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs,

@@ -18,6 +18,11 @@
 // granule round trip 1.2, tail 1.8), so the tail is written for instruction COUNT: branch-free exponent rule, power-of-two
 // scaling by exponent bits instead of ldexpf, DPP / v_permlane*_swap maxima instead of LDS shuffles, the workgroup's
 // "all granules seen" vote carried by a barrier that is there anyway, bias and B fragments requested before the wait.
+// GROUPS (lqer_linear_forward_group): Linears that are handed the SAME tokens - q/k/v, gate/up (reference llama_decoder.py:222-224,
+// :104) - run as ONE launch: the producers multiply x with the concatenation of the members' A (rank tiles in chunks of four), the
+// consumer workgroups of all members stream their own packed rows (the members' images stay where they are: a table of up
+// to four members rides in the kernel arguments) and pick the rank columns of their member out of the shared granules.  Per
+// member the arithmetic is that of its own launch: same bits.
 // No workgroup ever waits for a consumer, producers wait for nobody, and the poll is bounded: if a granule has not arrived
 // after QD1_SPIN sweeps (it has, in practice, long before a consumer asks - producers are the first blocks of the grid and
 // finish in ~2 us) the consumer workgroup computes every partial tile itself with the producers' own routine (same bits)
@@ -72,14 +77,28 @@ __device__ unsigned long long* g_d1_stamps = nullptr;  // diagnostic build: s_me
 // the intrinsic, and the kernel descriptor then requests the two system SGPRs)
 extern "C" __device__ unsigned long long lqer_dispatch_id() __asm("llvm.amdgcn.dispatch.id");
 
+constexpr int MAXMEM = 4;  // Linears of one launch (q/k/v, gate/up)
+struct Member {        // one Linear of the launch: its own packed operands and output
+  const uint8_t* wp;   // packed panels
+  const bf16_t* bt;    // [limbs][Np][rp]
+  const float* bias;   // [Np] or null
+  void* y;
+  int64_t ldy;
+  int N, Np, rp, b_limbs;
+  int r_off;           // its first column in the concatenated x A (granules, A^T image)
+  int cb0;             // its first consumer workgroup (consumer ids run member-major)
+};
 struct Args {
-  GemmArgs g;          // the consumer side: wp, bt, bias, y, ldy, M, N, Np, Kp, rp, b_limbs, aout, bout
+  GemmArgs g;          // formats and shapes shared by the members: M, Kp, aout, bout (per-member fields: `mem`)
+  Member mem[MAXMEM];
+  int nmem;
+  int rp_all;          // padded ranks summed over the members: row pitch of the granules and rows of the A^T image
   const void* x;       // [M, K] tokens, row stride ldx
   int64_t ldx;
   int K;
   QP qx;
-  const bf16_t* a_t;   // A^T bf16 image [rp][Kp] (one limb)
-  uint32_t* gran;      // granules [np][MAXM][rp] x {value, tag}
+  const bf16_t* a_t;   // A^T bf16 image [rp_all][Kp] (one limb; the members' images concatenated along the rank)
+  uint32_t* gran;      // granules [np][MAXM][rp_all] x {value, tag}
   uint32_t nonce;      // host part of the granule tag (a per-call counter); the kernel mixes in its dispatch id and queue
   int np;              // producers = ceil(Kp / 256)
   int spin;            // poll sweeps before a consumer computes the tiles itself
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  const int M = g.M, Kp = g.Kp, rp = g.rp;
+  const int M = g.M, Kp = g.Kp, rp_all = a.rp_all;
   // The granule tag of THIS launch: the host's per-call counter, the dispatch id (x odd constant: consecutive launches of one
   // queue never share a tag; a replayed graph node gets a fresh one although its kernel arguments are frozen) and the queue's
   // address (two queues that take turns on one workspace).  Scalar: the same in every lane and workgroup of the launch.
@@ -204,8 +223,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   float* const pred = (float*)(pslab + PSLAB_BYTES);
   volatile uint32_t* const miss_flag = (volatile uint32_t*)((unsigned char*)pred + PRED_BYTES);  // (not inside pred: produce() writes there)
   if (tid == 0) *miss_flag = 0u;  // (ordered before its use by the barriers below)
-  const auto gran_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, a.np * MAXM * rp * 8, 0x00020000);
-  const int nt16 = rp / 16;
+  const auto gran_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, a.np * MAXM * rp_all * 8, 0x00020000);
+  const int nt16_all = rp_all / 16;
 
   // ---- the partial tile of x A of slab p, published as granules (the producers' whole job; a consumer's fall-back)
   auto produce = [&](int p) {
@@ -213,18 +232,23 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
     // partial tile is a dependent chain - loads, quantize, MFMA, combine, publish - whose length the consumers wait for at
     // their very end, so it is kept short: three hand-overs through LDS instead of seven, only the live rank tiles.
     // Their A^T fragments come first: they do not depend on x, and their L2 / HBM latency then passes under the quantizer.
+    // More than four rank tiles (a group's concatenated A): chunks of four against the same quantized slab.
     constexpr int PW = 4, PS = SLAB_K / 32 / PW;  // multiplying waves, k-slices of 32 per wave
     bf16x8 af[PS][MAXNT];
     const int64_t kw = (int64_t)p * SLAB_K + 32 * PS * wave;
-    if (wave < PW) {
+    auto load_af = [&](int t0) {
+      if (wave < PW) {
 #pragma unroll
-      for (int sl = 0; sl < PS; ++sl)
+        for (int sl = 0; sl < PS; ++sl)
 #pragma unroll
-        for (int t = 0; t < MAXNT; ++t) {
-          af[sl][t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (t < nt16 && kw + 32 * sl < Kp) af[sl][t] = *(const bf16x8*)(a.a_t + (int64_t)(16 * t + l15) * Kp + kw + 32 * sl + 8 * lq);
-        }
-    }
+          for (int t = 0; t < MAXNT; ++t) {
+            af[sl][t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (t0 + t < nt16_all && kw + 32 * sl < Kp)
+              af[sl][t] = *(const bf16x8*)(a.a_t + (int64_t)(16 * (t0 + t) + l15) * Kp + kw + 32 * sl + 8 * lq);
+          }
+      }
+    };
+    load_af(0);
     // quantize the slab: threads 0..127 take block (row t >> 4, segment t & 15); rows >= M and k >= K are zeros
     if (tid < MAXM * 16) {
       const int row = tid >> 4, seg = tid & 15;
@@ -240,45 +264,49 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
       *(uint4*)(pslab + img_off(row, 2 * seg + 1, SLAB_K * 2)) = make_uint4(w[4], w[5], w[6], w[7]);
     }
     __syncthreads();
-    // A operand = tokens (row l15 & 7: rows 8..15 duplicate 0..7 and are never published), B operand = A^T (lane: rank
-    // entry 16 t + l15, k + 8 lq)
-    f32x4 acc[MAXNT];
+    for (int t0 = 0; t0 < nt16_all; t0 += MAXNT) {
+      if (t0 > 0) load_af(t0);
+      const int nt16 = nt16_all - t0 < MAXNT ? nt16_all - t0 : MAXNT;  // live rank tiles of this chunk
+      // A operand = tokens (row l15 & 7: rows 8..15 duplicate 0..7 and are never published), B operand = A^T (lane: rank
+      // entry 16 t + l15, k + 8 lq)
+      f32x4 acc[MAXNT];
 #pragma unroll
-    for (int t = 0; t < MAXNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (wave < PW) {
+      for (int t = 0; t < MAXNT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (wave < PW) {
 #pragma unroll
-      for (int sl = 0; sl < PS; ++sl)
-        if (kw + 32 * sl < Kp) {
-          const bf16x8 xf = *(const bf16x8*)(pslab + img_off(l15 & 7, 4 * (PS * wave + sl) + lq, SLAB_K * 2));
+        for (int sl = 0; sl < PS; ++sl)
+          if (kw + 32 * sl < Kp) {
+            const bf16x8 xf = *(const bf16x8*)(pslab + img_off(l15 & 7, 4 * (PS * wave + sl) + lq, SLAB_K * 2));
 #pragma unroll
-          for (int t = 0; t < MAXNT; ++t)
-            if (t < nt16) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, af[sl][t], acc[t], 0, 0, 0);
-        }
-    }
-    if (wave > 0 && wave < PW) {
-#pragma unroll
-      for (int t = 0; t < MAXNT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (t < nt16) pred[(((wave - 1) * MAXNT + t) * 4 + j) * 64 + lane] = acc[t][j];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-      for (int t = 0; t < MAXNT; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = 4 * lq + j;  // lane holds token rows 4 lq + j, rank entry 16 t + l15
-          if (t < nt16 && row < M) {
-            float sum = acc[t][j];
-#pragma unroll
-            for (int w2 = 0; w2 < PW - 1; ++w2) sum += pred[((w2 * MAXNT + t) * 4 + j) * 64 + lane];
-            const u32x2_t gv = {__float_as_uint(sum), tag};
-            __builtin_amdgcn_raw_buffer_store_b64(gv, gran_rsrc, (((p * MAXM + row) * rp) + 16 * t + l15) * 8, 0, 16);  // sc1
+            for (int t = 0; t < MAXNT; ++t)
+              if (t < nt16) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, af[sl][t], acc[t], 0, 0, 0);
           }
-        }
+      }
+      if (wave > 0 && wave < PW) {
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (t < nt16) pred[(((wave - 1) * MAXNT + t) * 4 + j) * 64 + lane] = acc[t][j];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 4 * lq + j;  // lane holds token rows 4 lq + j, rank entry 16 (t0 + t) + l15
+            if (t < nt16 && row < M) {
+              float sum = acc[t][j];
+#pragma unroll
+              for (int w2 = 0; w2 < PW - 1; ++w2) sum += pred[((w2 * MAXNT + t) * 4 + j) * 64 + lane];
+              const u32x2_t gv = {__float_as_uint(sum), tag};
+              __builtin_amdgcn_raw_buffer_store_b64(gv, gran_rsrc, (((p * MAXM + row) * rp_all) + 16 * (t0 + t) + l15) * 8, 0, 16);  // sc1
+            }
+          }
+      }
+      __syncthreads();  // pslab / pred may be reused (next chunk, fall-back loop)
     }
-    __syncthreads();  // pslab / pred may be reused (fall-back loop)
   };
 
   D1_STAMP(0);
@@ -289,16 +317,23 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   }
 
   // ================================================== consumer =========================================================
-  const int cb = (int)blockIdx.x - a.np;
+  // which Linear of the launch this workgroup belongs to (consumer ids run member-major; scalar index into the argument table)
+  const int cb_all = (int)blockIdx.x - a.np;
+  int mi = 0;
+  for (int i = 1; i < a.nmem; ++i) mi = cb_all >= a.mem[i].cb0 ? i : mi;
+  mi = __builtin_amdgcn_readfirstlane(mi);
+  const Member& mb = a.mem[mi];
+  const int rp = mb.rp, r_off = mb.r_off;
+  const int cb = cb_all - mb.cb0;
   const int row = l15, q = lq;  // weight row / token within the tile; k group (gemm_smallm.hip's names)
   const int n0 = cb * 16;
   const int nk = Kp / 64;
-  const uint8_t* prow = g.wp + (int64_t)cb * nk * LQER_PANEL_BYTES;
+  const uint8_t* prow = mb.wp + (int64_t)cb * nk * LQER_PANEL_BYTES;
   const int codes_off = row * 32 + (q & 1) * 16;
   const int exps_off = 512 + row * 4;
   const bool hi = (q >> 1) != 0;
   const int sh0 = 8 * (q >> 1), sh1 = 16 + 8 * (q >> 1);
-  const bool lowrank = g.bt != nullptr && rp > 0;
+  const bool lowrank = mb.bt != nullptr && rp > 0;
 
   // weight panels through a buffer descriptor: a request past the end is dropped by the range check,
   // so no load sits under a branch and the compiler's vmcnt counts stay exact
@@ -387,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int p = p0 + 4 * u;
-      const uint32_t off = (it < items && p < a.np) ? (uint32_t)((((p * MAXM + g_r) * rp) + 4 * g_c4) * 8) : 0x7ffffff0u;  // (past the range: zeros)
+      const uint32_t off = (it < items && p < a.np) ? (uint32_t)((((p * MAXM + g_r) * rp_all) + r_off + 4 * g_c4) * 8) : 0x7ffffff0u;  // (past the range: zeros)
       b.v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, (int)off, 0, 16);       // sc1: past this CU's L1
       b.v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, (int)(off + 16u), 0, 16);
     }
@@ -427,11 +462,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   // wave 0 requests the first side-path fragment of B now: its latency passes under the granule round trip (requested at
   // the top of the kernel it would sit under a branch in front of the weight stream and cost a register for the whole loop)
   bf16x8 sp_b = zero8;
-  if (lowrank && wave == 0 && g.b_limbs > 0 && 8 * q < rp) sp_b = *(const bf16x8*)(g.bt + (int64_t)(n0 + row) * rp + 8 * q);
+  if (lowrank && wave == 0 && mb.b_limbs > 0 && 8 * q < rp) sp_b = *(const bf16x8*)(mb.bt + (int64_t)(n0 + row) * rp + 8 * q);
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};  // (the bias image is padded to Np: columns n0 + 4 q .. + 3 exist)
-  if (wave == 0 && g.bias) {
+  if (wave == 0 && mb.bias) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias4[j] = g.bias[n0 + 4 * q + j];
+    for (int j = 0; j < 4; ++j) bias4[j] = mb.bias[n0 + 4 * q + j];
   }
   if (wave == 0) {
 #pragma unroll
@@ -461,7 +496,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
               if (!ok[u]) {
-                const int off = ((((p0 + 4 * u) * MAXM + g_r) * rp) + 4 * g_c4) * 8;
+                const int off = ((((p0 + 4 * u) * MAXM + g_r) * rp_all) + r_off + 4 * g_c4) * 8;
                 gb.v0[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off, 0, 16);
                 gb.v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, off + 16, 0, 16);
               }
@@ -534,13 +569,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   if (lowrank) {
     bf16x8 sp_x = zero8;
     if (8 * q < rp && row < M) sp_x = *(const bf16x8*)(xaq_l + row * rp + 8 * q);
-    if (g.b_limbs > 0) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_b, sp_x, s, 0, 0, 0);  // prefetched
-    for (int l = 0; l < g.b_limbs; ++l)
+    if (mb.b_limbs > 0) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_b, sp_x, s, 0, 0, 0);  // prefetched
+    for (int l = 0; l < mb.b_limbs; ++l)
       for (int ks = (l == 0 ? 1 : 0); ks * 32 < rp; ++ks) {
         const int j0 = ks * 32 + 8 * q;
         bf16x8 bb = zero8, xv = zero8;
         if (j0 < rp) {
-          bb = *(const bf16x8*)(g.bt + ((int64_t)l * g.Np + n0 + row) * rp + j0);
+          bb = *(const bf16x8*)(mb.bt + ((int64_t)l * mb.Np + n0 + row) * rp + j0);
           if (row < M) xv = *(const bf16x8*)(xaq_l + row * rp + j0);
         }
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, xv, s, 0, 0, 0);
@@ -564,7 +599,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
     float out[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j] = (s[j] + bias4[j]) + acc[j];
-    store_row4<DT>(g.y, (int64_t)row * g.ldy + nq, nq, g.N, out);
+    store_row4<DT>(mb.y, (int64_t)row * mb.ldy + nq, nq, mb.N, out);
   }
   D1_STAMP(5);
 }
@@ -583,14 +618,28 @@ size_t decode1_lds_bytes(int M, int64_t Kp) {
 
 size_t decode1_scratch_bytes(int64_t Kp, int rp) { return (size_t)((Kp + d1::SLAB_K - 1) / d1::SLAB_K) * d1::MAXM * rp * 8; }
 
-// g: filled like for the small-M kernel (xq / xaq / xa_part unused).  Returns LQER_E_UNSUPPORTED when the shape is outside.
+// g: the shared part, filled like for the small-M kernel (M, Kp, aout, bout, tuning; xq / xaq / xa_part and the per-Linear fields
+// unused) - mem[0 .. nmem-1]: the Linears of the launch (one, or a group that is handed the same tokens), a_t: the
+// concatenation of their A^T images along the rank.  Returns LQER_E_UNSUPPORTED when the shape is outside.
 int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, const QP& qx, const bf16_t* a_t, int bout,
-                     void* scratch, size_t scratch_bytes, hipStream_t st) {
-  if (g.M < 1 || g.M > d1::MAXM || g.rp > 16 * d1::MAXNT || bout > 1 || K % 16 != 0) return LQER_E_UNSUPPORTED;
-  const size_t lds = decode1_lds_bytes(g.M, g.Kp);
-  if (lds > 150 * 1024 || scratch_bytes < decode1_scratch_bytes(g.Kp, g.rp) || ((uintptr_t)scratch & 15)) return LQER_E_UNSUPPORTED;
+                     const DecodeMember* mem, int nmem, void* scratch, size_t scratch_bytes, hipStream_t st) {
+  if (g.M < 1 || g.M > d1::MAXM || nmem < 1 || nmem > d1::MAXMEM || bout > 1 || K % 16 != 0) return LQER_E_UNSUPPORTED;
   d1::Args a;
+  int rp_all = 0, cbs = 0;
+  for (int i = 0; i < nmem; ++i) {
+    if (mem[i].rp <= 0 || mem[i].rp > 16 * d1::MAXNT || mem[i].rp % 16 || mem[i].Np % 16 || !mem[i].bt || mem[i].b_limbs < 1 ||
+        mem[i].b_limbs > 3)
+      return LQER_E_UNSUPPORTED;
+    a.mem[i] = d1::Member{mem[i].wp, mem[i].bt, mem[i].bias, mem[i].y, mem[i].ldy, mem[i].N, mem[i].Np, mem[i].rp, mem[i].b_limbs, rp_all, cbs};
+    rp_all += mem[i].rp;
+    cbs += mem[i].Np / 16;
+  }
+  for (int i = nmem; i < d1::MAXMEM; ++i) a.mem[i] = d1::Member{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0x7fffffff};
+  if (rp_all > 128) return LQER_E_UNSUPPORTED;
+  const size_t lds = decode1_lds_bytes(g.M, g.Kp);
+  if (lds > 150 * 1024 || scratch_bytes < decode1_scratch_bytes(g.Kp, rp_all) || ((uintptr_t)scratch & 15)) return LQER_E_UNSUPPORTED;
   a.g = g;
+  a.nmem = nmem, a.rp_all = rp_all;
   a.x = x, a.ldx = ldx, a.K = K, a.qx = qx, a.a_t = a_t;
   a.gran = (uint32_t*)scratch;
   // the call's tag: a counter spread over all 32 bits (odd multiplier: a bijection, so two calls never share a tag before
@@ -599,7 +648,7 @@ int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, c
   a.nonce = n * 0x9E3779B1u ^ 0xA5C35A3Cu;
   a.np = (int)((g.Kp + d1::SLAB_K - 1) / d1::SLAB_K);
   a.spin = (g.tuning & LQER_TUNE_DECODE_NO_POLL) ? 0 : LQER_QD1_SPIN;  // (tests: every consumer computes the tiles itself)
-  const unsigned grid = (unsigned)(a.np + g.Np / 16);
+  const unsigned grid = (unsigned)(a.np + cbs);
 #define D1_LAUNCH(DT, BO)                                                                     \
   do {                                                                                        \
     static LdsLimitOnce lds_once;                                                             \

@@ -51,7 +51,7 @@ static_assert(EP_OUT + 8 * EP_OUT_WAVE <= GEMM_LDS, "epilogue regions exceed the
 // behind the ring, written at the start of the kernel: per-row constants of the epilogue - the x row scales, the B_out
 // scales 2^(mbits - e[m]) and 2^(e[m] - mbits) - fp32 [256] each
 constexpr int EP_TAB = GEMM_LDS;
-constexpr int KERNEL_LDS = GEMM_LDS + 3 * 1024;
+constexpr int KERNEL_LDS = GEMM_LDS + 4 * 1024;  // ... and 1e-9 * 2^(mbits - e[m]), the B_out quantizer's epsilon after scaling
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
@@ -77,17 +77,20 @@ __device__ __forceinline__ int w_byte_offset(int rl, int W) {
   return rl * 64 + ((((off >> 4) ^ ((rl >> 2) & 3)) << 4) | (off & 15));
 }
 
-// per weight row: group exponents -> base exponent, shifts, row scale; i32 range and format checks (flags[0] != 0: not eligible)
+// per weight row: group exponents -> base exponent, shifts, row scale; i32 range and format checks (flags[0] != 0: not
+// eligible).  One workgroup = one n tile of 256 rows: the tile's MODE (common.h I8_MODE_*) is decided here - PRESHIFT when no
+// row of the tile spreads its group exponents over more than 4 binades (the int8 lane cw << (4 - q) then carries the group's
+// exponent itself and the main loop accumulates without folds), else FOLD; NONE when no group of the tile differs from its row.
 __global__ __launch_bounds__(256) void k_i8_rows(const uint8_t* __restrict__ wp, int64_t N, int64_t Np, int nk, int nk8,
                                                   uint8_t* __restrict__ img, int32_t* __restrict__ flags) {
-  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (n >= Np) return;
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (Np is a multiple of 256: every thread owns a row)
   float* wscale = (float*)(img + (size_t)(Np / 256) * nk8 * I8_WBLOCK);
+  uint8_t* mode_tab = img + i8_weight_mode_offset(Np, nk8);
   const int64_t tn = n / 256;
   const int rl = (int)(n - tn * 256);
-  int bmin = 255;
+  int bmin = 255, bmax = 0;
   bool bad = false;
-  // pass 1: the biased exponent byte of every 128-k group (0 = no non-zero code in it), minimum over the row
+  // pass 1: the biased exponent byte of every 128-k group (0 = no non-zero code in it), minimum and maximum over the row
   for (int s = 0; s < nk8; ++s) {
     int bg = 0;
     for (int half = 0; half < 2; ++half) {
@@ -104,17 +107,22 @@ __global__ __launch_bounds__(256) void k_i8_rows(const uint8_t* __restrict__ wp,
       }
     }
     if (bg && bg < bmin) bmin = bg;
+    if (bg > bmax) bmax = bg;
     img[(tn * nk8 + s) * I8_WBLOCK + 256 * 64 + rl] = (uint8_t)bg;  // (the byte for now; the shift in pass 2)
   }
-  // pass 2: shifts and the i32 bound  sum_g 2^s * sum_k |16 c| * 127 < 2^31
+  const bool row_any = bmin != 255 && bmax != bmin;
+  const int tile_wide = __syncthreads_or(bmin != 255 && bmax - bmin > 4);
+  const int tile_two = __syncthreads_or(bmin != 255 && bmax - bmin > 1);
+  const int tile_any = __syncthreads_or(row_any);
+  const int mode = !tile_any ? I8_MODE_NONE : (tile_wide ? I8_MODE_FOLD : (tile_two ? I8_MODE_PRESHIFT : I8_MODE_PRESHIFT1));
+  if (threadIdx.x == 0) mode_tab[tn] = (uint8_t)mode;
+  // pass 2: shift bytes and the i32 bound  sum_g sum_k |lane| * 127 < 2^31  (lane = 16 c 2^s, or c 2^(4-q))
   unsigned long long bound = 0;
-  bool any_shift = false;
   for (int s = 0; s < nk8; ++s) {
     uint8_t* sp = img + (tn * nk8 + s) * I8_WBLOCK + 256 * 64 + rl;
     const int bg = *sp;
     int sh = 0;
     if (bg) {
-      sh = bg - bmin;
       unsigned asum = 0;
       for (int half = 0; half < 2; ++half) {
         const int kp = 2 * s + half;
@@ -125,17 +133,23 @@ __global__ __launch_bounds__(256) void k_i8_rows(const uint8_t* __restrict__ wp,
           for (int p = 0; p < 8; ++p) asum += (m >> (4 * p)) & 7u;
         }
       }
-      if (sh > 20) bad = true;
-      else bound += ((unsigned long long)asum << sh) * (16ull * 127ull);
-      any_shift |= sh != 0;
+      if (mode == I8_MODE_PRESHIFT || mode == I8_MODE_PRESHIFT1) {
+        sh = bmax - bg;  // q: the lane is cw << (4 - q)
+        bound += ((unsigned long long)asum << (4 - sh)) * 127ull;
+      } else {
+        sh = bg - bmin;
+        if (sh > 20) bad = true;
+        else bound += ((unsigned long long)asum << sh) * (16ull * 127ull);
+      }
     }
     *sp = (uint8_t)sh;
   }
   if (bound >= (1ull << 31)) bad = true;
-  if (bmin != 255 && bmin < 5) bad = true;  // row scale 2^(e - mbits - 4) would not be a normal float
-  wscale[n] = bmin == 255 ? 0.0f : __uint_as_float((uint32_t)(bmin - 4) << 23);
+  const int bbase = (mode == I8_MODE_PRESHIFT || mode == I8_MODE_PRESHIFT1) ? bmax : bmin;  // value = lane * 2^(bbase - 4 - 127)
+  if (bmin != 255 && bbase < 5) bad = true;  // row scale 2^(e - mbits - 4) would not be a normal float
+  wscale[n] = bmin == 255 ? 0.0f : __uint_as_float((uint32_t)(bbase - 4) << 23);
   if (bad) atomicOr(flags, 1);
-  if (any_shift) atomicOr(flags + 1, 1);
+  if (row_any) atomicOr(flags + 1, 1);
 }
 
 // per (row, step): 16 words of sign-magnitude nibbles -> two's complement, reordered
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(256) void k_i8_unpack(const uint8_t* __restrict__ i
   const int64_t n = idx / K, k = idx - n * K;
   const float* wscale = (const float*)(img + (size_t)(Np / 256) * nk8 * I8_WBLOCK);
   const int64_t tn = n / 256;
+  const int mode = img[i8_weight_mode_offset(Np, nk8) + tn];
   const int rl = (int)(n - tn * 256), s = (int)(k / 128), kk = (int)(k % 128);
   const uint8_t* blk = img + (tn * nk8 + s) * I8_WBLOCK;
   const int W = kk >> 3, q = kk & 7;
@@ -181,11 +196,16 @@ __global__ __launch_bounds__(256) void k_i8_unpack(const uint8_t* __restrict__ i
   int c = (int)((w >> (4 * p)) & 0xfu);
   c = c >= 8 ? c - 16 : c;
   const int sh = blk[256 * 64 + rl];
-  out[idx] = (float)(16 * c * (1 << sh)) * wscale[n];
+  // the int8 lane the main loop multiplies: 16 c 2^s (FOLD / NONE: s applied to the group sum), c 2^(4-q) (PRESHIFT)
+  out[idx] = (float)((mode == I8_MODE_PRESHIFT || mode == I8_MODE_PRESHIFT1) ? c * (1 << (4 - sh)) : 16 * c * (1 << sh)) * wscale[n];
 }
 
 // ---- the GEMM -----------------------------------------------------------------------------------------------------------
-// BOUT: 0 pass-through, 2 one block per row (exponent from the k_bout_amax pre-pass).  SHIFT: per-group shifts present.
+// BOUT: 0 pass-through, 2 one block per row (exponent from the k_bout_amax pre-pass).  SHIFT: the weight's blocks are shorter
+// than its rows - every n tile then says in its MODE byte how its group exponents travel (k_i8_rows): PRESHIFT (the lane
+// cw << (4 - q) carries them: 11 vector instructions per 8 weights - 7 when no row of the tile spreads over more than two
+// binades, PRESHIFT1 -, no folds), FOLD (one v_lshl_add_u32 per output element and group), or NONE.  The main loops live in one
+// kernel; the choice is uniform per tile.
 template <int DT, bool LOWRANK, int BOUT, bool SHIFT>
 __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -240,6 +260,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int w_voff0 = (2 * wave) * 1024 + lane * 16, w_voff1 = w_voff0 + 1024, s_voff = 256 * 64 + lane * 4;
   const uint8_t* const a_base = xq8 + (int64_t)m0 * Kp8;
   const uint8_t* const w_base = g.w8 + (size_t)tn * nk * I8_WBLOCK;
+  int tile_mode = I8_MODE_NONE;  // (workgroup-uniform)
+  if constexpr (SHIFT) tile_mode = __builtin_amdgcn_readfirstlane((int)g.w8[i8_weight_mode_offset(g.Np, nk) + tn]);
   auto make_rs = [](const uint8_t* base, uint32_t range) {
     const unsigned long long b64 = (unsigned long long)base;
     return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64),
@@ -298,8 +320,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         // pass-through whatever the scale - clamp, the result does not change
         int up = g.bout.mbits - block_exponent(t_amax, g.bout);
         up = up > 126 ? 126 : (up < -126 ? -126 : up);
-        asm volatile("ds_write_b32 %0, %1 offset:1024\n\tds_write_b32 %0, %2 offset:2048" ::"v"(ta),
-                     "v"((uint32_t)(127 + up) << 23), "v"((uint32_t)(127 - up) << 23)
+        const uint32_t upb = (uint32_t)(127 + up) << 23;
+        asm volatile("ds_write_b32 %0, %1 offset:1024\n\tds_write_b32 %0, %2 offset:2048\n\tds_write_b32 %0, %3 offset:3072" ::"v"(ta),
+                     "v"(upb), "v"((uint32_t)(127 - up) << 23), "v"(1e-9f * __uint_as_float(upb))
                      : "memory");
       }
     }
@@ -336,13 +359,14 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // partner wave of the SIMD is computing then and the vector ALU is idle -, those of the other three tiles under the MFMAs
   // of the tile after them (4 folds per MFMA slot, from two slots behind the tile's last MFMA: its results have landed)
   i32x16 Gd = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  auto half_step = [&](int kt, auto slot_c, auto half_c) {
+  auto half_step = [&](int kt, auto slot_c, auto half_c, auto mode_c) {
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr int P = decltype(half_c)::value;
+    constexpr int MODE = decltype(mode_c)::value;  // I8_MODE_* of this tile
     constexpr int slot_new = (SLOT + DEPTH) % NSLOT;
     constexpr int A_IMM = (SLOT == 2 ? 0 : SLOT * A_SLOT) + 4 * P * 4096;  // tile t of this half: + 4096 t
     __builtin_amdgcn_s_setprio(1);
-    if constexpr (SHIFT) {  // the previous half-step's last tile (sv still holds that step's shift: the asm below updates it)
+    if constexpr (MODE == I8_MODE_FOLD) {  // the previous half-step's last tile (sv still holds that step's shift: the asm below updates it)
       constexpr int prev = 4 * (1 - P) + 3;
 #pragma unroll
       for (int j = 0; j < 16; ++j) R[prev][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[prev][j]);
@@ -399,8 +423,31 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #undef I8_DMA
 #undef I8_OUTS_X
 #undef I8_INS
-    auto expand = [](uint32_t w0, uint32_t w1) {
-      return (i32x4){(int)((w0 << 4) & 0xF0F0F0F0u), (int)(w0 & 0xF0F0F0F0u), (int)((w1 << 4) & 0xF0F0F0F0u), (int)(w1 & 0xF0F0F0F0u)};
+    // PRESHIFT: the lane is the nibble's value arithmetically shifted: (cw << 4) >> q per byte.  The logical shift moves only
+    // zeros across byte borders (the low nibble of every byte of x is 0, q <= 4); the sign fill comes from v_perm_b32's
+    // sign selectors (a byte of 0x00 / 0xFF per odd byte of its sources: w and w << 8 give the four high-nibble signs, w << 4
+    // and w << 12 the low-nibble ones) masked to the q vacated bits.  11 vector instructions per word of 8 weights.
+    uint32_t hq4 = 0;  // per byte: the q high bits
+    if constexpr (MODE == I8_MODE_PRESHIFT && P == 0) hq4 = ((0xFF00u >> sv) & 0xFFu) * 0x01010101u;
+    auto expand = [&](uint32_t w0, uint32_t w1) {
+      if constexpr (MODE == I8_MODE_PRESHIFT1) {  // q <= 1: (x >> q) | (x & 0x80808080) - the one vacated bit is the sign bit
+        const uint32_t a0 = (w0 << 4) & 0xF0F0F0F0u, b0 = w0 & 0xF0F0F0F0u, a1 = (w1 << 4) & 0xF0F0F0F0u, b1 = w1 & 0xF0F0F0F0u;
+        return (i32x4){(int)((a0 & 0x80808080u) | (a0 >> sv)), (int)((b0 & 0x80808080u) | (b0 >> sv)),
+                       (int)((a1 & 0x80808080u) | (a1 >> sv)), (int)((b1 & 0x80808080u) | (b1 >> sv))};
+      } else if constexpr (MODE == I8_MODE_PRESHIFT) {
+        auto one = [&](uint32_t w, uint32_t& lo, uint32_t& hi) {
+          const uint32_t t = w << 4;
+          const uint32_t m_hi = __builtin_amdgcn_perm(w, w << 8, 0x0B090A08u), m_lo = __builtin_amdgcn_perm(t, w << 12, 0x0B090A08u);
+          lo = (m_lo & hq4) | ((t & 0xF0F0F0F0u) >> sv);
+          hi = (m_hi & hq4) | ((w & 0xF0F0F0F0u) >> sv);
+        };
+        uint32_t l0, h0, l1, h1;
+        one(w0, l0, h0);
+        one(w1, l1, h1);
+        return (i32x4){(int)l0, (int)h0, (int)l1, (int)h1};
+      } else {
+        return (i32x4){(int)((w0 << 4) & 0xF0F0F0F0u), (int)(w0 & 0xF0F0F0F0u), (int)((w1 << 4) & 0xF0F0F0F0u), (int)(w1 & 0xF0F0F0F0u)};
+      }
     };
     if constexpr (P == 0) {
       wf[0] = expand(wr0[0], wr0[1]);
@@ -416,11 +463,22 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       wf[2] = expand(wr1[0], wr1[1]);
       wf[3] = expand(wr1[2], wr1[3]);
     }
-    if constexpr (!SHIFT) {
+    if constexpr (MODE != I8_MODE_FOLD) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int t = 0; t < 4; ++t) R[4 * P + t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][ks], wf[ks], R[4 * P + t], 0, 0, 0);
+      if constexpr ((MODE == I8_MODE_PRESHIFT || MODE == I8_MODE_PRESHIFT1) && P == 0) {
+        // issue order: the expand of slice ks + 1 (22 vector instructions) in the shadow of the four MFMAs of slice ks
+#define I8_SLOT(NV)                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+        if constexpr ((NV) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);
+        I8_SLOT(6) I8_SLOT(6) I8_SLOT(5) I8_SLOT(5)
+        I8_SLOT(6) I8_SLOT(6) I8_SLOT(5) I8_SLOT(5)
+        I8_SLOT(6) I8_SLOT(6) I8_SLOT(5) I8_SLOT(5)
+        I8_SLOT(0) I8_SLOT(0) I8_SLOT(0) I8_SLOT(0)
+#undef I8_SLOT
+      }
     } else {
       const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       i32x16 G[4];
@@ -450,27 +508,147 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+
+  // ---- the same half-step with the step split along K instead of along the token tiles (NONE / PRESHIFT: no group tile is
+  // needed): half P multiplies the 32-k slices 2P and 2P + 1 of ALL 8 token tiles.  The weight words of a half are one 16-byte
+  // read and their expansion - 22 vector instructions per slice with pre-shifted lanes - is spread evenly: one slice before
+  // the barrier, one in the shadow of the first eight MFMAs, in BOTH halves (the token-tile split needs all four slices in
+  // its first half and none in its second).  Ring, prefetch pieces, waits and barriers are those of half_step.
+  uint32_t hq4_k = 0;  // PRESHIFT: per byte the q high bits (from the step's shift byte, read in half 0)
+  auto half_step_k = [&](int kt, auto slot_c, auto half_c, auto mode_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int P = decltype(half_c)::value;
+    constexpr int MODE = decltype(mode_c)::value;
+    constexpr int slot_new = (SLOT + DEPTH) % NSLOT;
+    constexpr int A_IMM = (SLOT == 2 ? 0 : SLOT * A_SLOT);  // tile t: + 4096 t
+    __builtin_amdgcn_s_setprio(1);
+    const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
+    const int a_soff = ktn * I8_BK, w_soff = ktn * I8_WBLOCK;
+    const uint32_t m0a0 = m0_a + slot_new * A_SLOT + (2 * P) * 1024, m0a1 = m0a0 + 1024;
+    const uint32_t m0w = m0_w + slot_new * W_SLOT + P * 1024, m0s = m0_s + slot_new * W_SLOT;
+    i32x4 xk[8][2];  // [token tile][slice of this half]
+    u32x4 wr;        // the half's weight words: slices 2P, 2P + 1
+#define I8K_READS                                                                                                      \
+      "ds_read_b128 %[x00], %[fa0] offset:%c[aimm]\n\tds_read_b128 %[x01], %[fa1] offset:%c[aimm]\n\t"  \
+      "ds_read_b128 %[x10], %[fa0] offset:%c[aimm]+4096\n\tds_read_b128 %[x11], %[fa1] offset:%c[aimm]+4096\n\t"  \
+      "ds_read_b128 %[x20], %[fa0] offset:%c[aimm]+8192\n\tds_read_b128 %[x21], %[fa1] offset:%c[aimm]+8192\n\t"  \
+      "ds_read_b128 %[x30], %[fa0] offset:%c[aimm]+12288\n\tds_read_b128 %[x31], %[fa1] offset:%c[aimm]+12288\n\t"  \
+      "ds_read_b128 %[x40], %[fa0] offset:%c[aimm]+16384\n\tds_read_b128 %[x41], %[fa1] offset:%c[aimm]+16384\n\t"  \
+      "ds_read_b128 %[x50], %[fa0] offset:%c[aimm]+20480\n\tds_read_b128 %[x51], %[fa1] offset:%c[aimm]+20480\n\t"  \
+      "ds_read_b128 %[x60], %[fa0] offset:%c[aimm]+24576\n\tds_read_b128 %[x61], %[fa1] offset:%c[aimm]+24576\n\t"  \
+      "ds_read_b128 %[x70], %[fa0] offset:%c[aimm]+28672\n\tds_read_b128 %[x71], %[fa1] offset:%c[aimm]+28672\n\t"  \
+      "ds_read_b128 %[wr], %[fw] offset:%c[wimm]\n\t"
+#define I8K_DMA                                                                                                        \
+      "s_mov_b32 m0, %[m0a0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av0], %[ars], %[asoff] offen lds\n\t"                   \
+      "s_mov_b32 m0, %[m0a1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av1], %[ars], %[asoff] offen lds\n\t"                   \
+      "s_mov_b32 m0, %[m0w]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv], %[wrs], %[wsoff] offen lds\n\t"
+#define I8K_OUTS [x00] "=&v"(xk[0][0]), [x01] "=&v"(xk[0][1]), [x10] "=&v"(xk[1][0]), [x11] "=&v"(xk[1][1]), [x20] "=&v"(xk[2][0]), [x21] "=&v"(xk[2][1]), [x30] "=&v"(xk[3][0]), [x31] "=&v"(xk[3][1]), [x40] "=&v"(xk[4][0]), [x41] "=&v"(xk[4][1]), [x50] "=&v"(xk[5][0]), [x51] "=&v"(xk[5][1]), [x60] "=&v"(xk[6][0]), [x61] "=&v"(xk[6][1]), [x70] "=&v"(xk[7][0]), [x71] "=&v"(xk[7][1]), [wr] "=&v"(wr)
+#define I8K_INS                                                                                                        \
+      [fa0] "v"(SLOT == 2 ? fa_hi[2 * P] : fa_lo[2 * P]), [fa1] "v"(SLOT == 2 ? fa_hi[2 * P + 1] : fa_lo[2 * P + 1]),         \
+      [aimm] "i"(A_IMM), [fw] "v"(P == 0 ? fw_a : fw_b), [wimm] "i"(SLOT * W_SLOT), [av0] "v"(a_voff[2 * P]),                 \
+      [av1] "v"(a_voff[2 * P + 1]), [wv] "v"(P == 0 ? w_voff0 : w_voff1), [ars] "s"(a_rs), [wrs] "s"(w_rs), [m0a0] "s"(m0a0), \
+      [m0a1] "s"(m0a1), [asoff] "s"(a_soff), [m0w] "s"(m0w), [wsoff] "s"(w_soff)
+    if constexpr (P == 0) {
+      asm volatile(I8K_READS "ds_read_u8 %[sv], %[fs] offset:%c[wimm]\n\t" I8K_DMA "s_waitcnt lgkmcnt(0)"
+                   : I8K_OUTS, [sv] "=&v"(sv)
+                   : I8K_INS, [fs] "v"(fs_addr)
+                   : "memory");
+    } else {
+      asm volatile(I8K_READS I8K_DMA
+                   "s_cmp_lg_u32 %[wave], 0\n\ts_cbranch_scc1 1f\n\t"
+                   "s_mov_b32 m0, %[m0s]\n\ts_nop 0\n\tbuffer_load_dword %[sv4], %[wrs], %[wsoff] offen lds\n\t"
+                   "1:\n\ts_waitcnt vmcnt(6) lgkmcnt(0)"
+                   : I8K_OUTS
+                   : I8K_INS, [wave] "s"(wave), [sv4] "v"(s_voff), [m0s] "s"(m0s)
+                   : "memory", "scc");
+    }
+#undef I8K_READS
+#undef I8K_DMA
+#undef I8K_OUTS
+#undef I8K_INS
+    if constexpr (MODE == I8_MODE_PRESHIFT && P == 0) hq4_k = ((0xFF00u >> sv) & 0xFFu) * 0x01010101u;
+    auto expand = [&](uint32_t w0, uint32_t w1) {
+      if constexpr (MODE == I8_MODE_PRESHIFT1) {  // q <= 1: (x >> q) | (x & 0x80808080) - the one vacated bit is the sign bit
+        const uint32_t a0 = (w0 << 4) & 0xF0F0F0F0u, b0 = w0 & 0xF0F0F0F0u, a1 = (w1 << 4) & 0xF0F0F0F0u, b1 = w1 & 0xF0F0F0F0u;
+        return (i32x4){(int)((a0 & 0x80808080u) | (a0 >> sv)), (int)((b0 & 0x80808080u) | (b0 >> sv)),
+                       (int)((a1 & 0x80808080u) | (a1 >> sv)), (int)((b1 & 0x80808080u) | (b1 >> sv))};
+      } else if constexpr (MODE == I8_MODE_PRESHIFT) {  // (the lane cw << (4 - q): see half_step)
+        auto one = [&](uint32_t w, uint32_t& lo, uint32_t& hi) {
+          const uint32_t t = w << 4;
+          const uint32_t m_hi = __builtin_amdgcn_perm(w, w << 8, 0x0B090A08u), m_lo = __builtin_amdgcn_perm(t, w << 12, 0x0B090A08u);
+          lo = (m_lo & hq4_k) | ((t & 0xF0F0F0F0u) >> sv);
+          hi = (m_hi & hq4_k) | ((w & 0xF0F0F0F0u) >> sv);
+        };
+        uint32_t l0, h0, l1, h1;
+        one(w0, l0, h0);
+        one(w1, l1, h1);
+        return (i32x4){(int)l0, (int)h0, (int)l1, (int)h1};
+      } else {
+        return (i32x4){(int)((w0 << 4) & 0xF0F0F0F0u), (int)(w0 & 0xF0F0F0F0u), (int)((w1 << 4) & 0xF0F0F0F0u), (int)(w1 & 0xF0F0F0F0u)};
+      }
+    };
+    i32x4 wa = expand(wr[0], wr[1]);
+    asm volatile("s_barrier" : "+v"(wa)::"memory");
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE
+    const i32x4 wb = expand(wr[2], wr[3]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) R[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xk[t][0], wa, R[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) R[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xk[t][1], wb, R[t], 0, 0, 0);
+    if constexpr (MODE == I8_MODE_PRESHIFT || MODE == I8_MODE_PRESHIFT1) {  // the second slice's expand: <= 3 vector instructions per MFMA slot
+#define I8_SLOT(NV)                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+      if constexpr ((NV) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);
+      I8_SLOT(3) I8_SLOT(3) I8_SLOT(3) I8_SLOT(3) I8_SLOT(3) I8_SLOT(3) I8_SLOT(3) I8_SLOT(3)
+      I8_SLOT(0) I8_SLOT(0) I8_SLOT(0) I8_SLOT(0) I8_SLOT(0) I8_SLOT(0) I8_SLOT(0) I8_SLOT(0)
+#undef I8_SLOT
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   using std::integral_constant;
-  for (int kt = 0; kt < nk; kt += NSLOT) {  // unrolled by the ring size: slots are compile-time constants
-    half_step(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-    half_step(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
-    if (kt + 1 < nk) {
-      half_step(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-      half_step(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+#ifndef LQER_I8_KSPLIT
+#define LQER_I8_KSPLIT 1  // 0: the token-tile split for every mode (A/B builds)
+#endif
+  auto main_loop = [&](auto mode_c) {
+    auto hs = [&](int kt, auto slot_c, auto half_c) {
+      if constexpr (LQER_I8_KSPLIT && decltype(mode_c)::value != I8_MODE_FOLD) half_step_k(kt, slot_c, half_c, mode_c);
+      else half_step(kt, slot_c, half_c, mode_c);
+    };
+    for (int kt = 0; kt < nk; kt += NSLOT) {  // unrolled by the ring size: slots are compile-time constants
+      hs(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+      hs(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+      if (kt + 1 < nk) {
+        hs(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+        hs(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+      }
+      if (kt + 2 < nk) {
+        hs(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 0>{});
+        hs(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+      }
     }
-    if (kt + 2 < nk) {
-      half_step(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 0>{});
-      half_step(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
-    }
+  };
+  if constexpr (!SHIFT) {
+    main_loop(integral_constant<int, I8_MODE_NONE>{});
+  } else {
+    if (tile_mode == I8_MODE_PRESHIFT1) main_loop(integral_constant<int, I8_MODE_PRESHIFT1>{});
+    else if (tile_mode == I8_MODE_PRESHIFT) main_loop(integral_constant<int, I8_MODE_PRESHIFT>{});
+    else if (tile_mode == I8_MODE_FOLD) main_loop(integral_constant<int, I8_MODE_FOLD>{});
+    else main_loop(integral_constant<int, I8_MODE_NONE>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetches issued past the end of K have drained
   if (!late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
   I8_STAMP(cp_c[2], cp_r[2]);
 #endif
-  if constexpr (SHIFT) {  // the last half-step's last tile
+  if constexpr (SHIFT) {  // FOLD: the last half-step's last tile
+    if (tile_mode == I8_MODE_FOLD) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) R[7][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[7][j]);
+      for (int j = 0; j < 16; ++j) R[7][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[7][j]);
+    }
   }
   // every wave is past its last LDS read of the ring: the epilogue may overwrite it after one more barrier
   asm volatile("s_barrier" ::: "memory");
@@ -505,6 +683,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // (EP_TAB + 0: 2^(ex[m] - mbits), read in the conversion pass below)
   const float* const tab_up = (const float*)(smem + EP_TAB + 1024);  // B_out: 2^(mbits - e[m]) ...
   const float* const tab_dn = (const float*)(smem + EP_TAB + 2048);  // ... and 2^(e[m] - mbits)
+  const float* const tab_es = (const float*)(smem + EP_TAB + 3072);  // ... and 1e-9 * 2^(mbits - e[m])
   // the side product's operands: the tile's rows of xAq by LDS-DMA into the ring's place (panels of 64 columns, the
   // activation tile's row pitch and swizzle); this wave's B^T fragments in registers when there are at most 8 (limb,
   // 16-deep slice) pairs - rank 64 with fp16 A / B, rank 128 with 8-bit A / B -, else re-fetched from L2 for every token
@@ -658,6 +837,33 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     float yv[16];
     f32x16 sp;
     if constexpr (LOWRANK) sp = side(i);
+    // B_out with one block per row, FAST form: r = rne(fma(s, 2^(mbits-e), +-1e-9 2^(mbits-e))) - the same number as
+    // rne((s +- 1e-9) 2^(mbits-e)): scaling by a power of two commutes with the rounding of the sum -, y = fma(r, 2^(e-mbits), v)
+    // (r 2^(e-mbits) is exact).  Six packed instructions per pair of elements instead of fourteen; what it leaves out - the clamp
+    // at +-mmax (only a row's largest element can round up to 2^mbits) and the |s| <= 1e-8 pass-through - is detected through a
+    // running max |r| / min |s| and sends the WAVE's whole token tile through the general form below (rare: ~1e-3 of the tiles).
+    bool general = !(LOWRANK && BOUT == 2);
+    if constexpr (LOWRANK && BOUT == 2) {
+      float rmax = 0.f, smin = 3.0e38f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rloc = 32 * i + 8 * q + 4 * lh;  // + (j & 3)
+        const f32x4 up4 = *(const f32x4*)(tab_up + rloc), dn4 = *(const f32x4*)(tab_dn + rloc), es4 = *(const f32x4*)(tab_es + rloc);
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          const int j = 4 * q + t;
+          const f2 s2 = {sp[j], sp[j + 1]};
+          const f2 c = {copysignf(es4[t], s2[0]), copysignf(es4[t + 1], s2[1])};
+          const f2 r = (__builtin_elementwise_fma(s2, (f2){up4[t], up4[t + 1]}, c) + magic) - magic;
+          rmax = fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), rmax);
+          smin = fminf(fminf(fabsf(s2[0]), fabsf(s2[1])), smin);
+          const f2 y = __builtin_elementwise_fma(r, (f2){dn4[t], dn4[t + 1]}, (f2){__int_as_float(R[i][j]), __int_as_float(R[i][j + 1])});
+          yv[j] = y[0], yv[j + 1] = y[1];
+        }
+      }
+      general = __builtin_amdgcn_ballot_w64(rmax > mmax || smin <= 1e-8f) != 0;  // (wave-uniform)
+    }
+    if (general)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int rloc = 32 * i + 8 * q + 4 * lh;  // + (j & 3)
@@ -699,12 +905,15 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     } else {
       // 16-bit outputs: two tiles (64 rows x 32 columns) at a time through this wave's LDS region, then 16-byte stores
       unsigned char* const dst = out_w + (i & 1) * 32 * 80 + l31 * 2 + 4 * lh * 80;
+      // (pairs of rows: one v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 per two elements, the halves stored by ds_write_b16 and
+      // ds_write_b16_d16_hi; the packed bf16 conversion keeps a NaN a NaN - MI355X_MICROARCH.md, correctness boundaries)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        uint16_t hv;
-        if constexpr (DT == LQER_BF16) hv = f32_to_bf16_rne(yv[j]);
-        else hv = __builtin_bit_cast(uint16_t, (_Float16)yv[j]);
-        *(uint16_t*)(dst + ((j & 3) + 8 * (j >> 2)) * 80) = hv;
+      for (int j = 0; j < 16; j += 2) {
+        uint32_t pk;  // (asm: left to itself the compiler splits the pair back into two scalar conversions)
+        if constexpr (DT == LQER_BF16) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(yv[j]), "v"(yv[j + 1]));
+        else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(yv[j]), "v"(yv[j + 1]));
+        *(uint16_t*)(dst + ((j & 3) + 8 * (j >> 2)) * 80) = (uint16_t)pk;
+        *(uint16_t*)(dst + ((j & 3) + 1 + 8 * (j >> 2)) * 80) = (uint16_t)(pk >> 16);
       }
       if (i & 1) {
 #pragma unroll

@@ -370,6 +370,11 @@ class _LinearBase(nn.Linear):
         if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < K):
             x2 = x2.contiguous()
         M = x2.shape[0]
+        if self._group is not None and 0 < M <= 8:
+            # decode sizes: the whole group (q/k/v, gate/up) in ONE launch; later members are handed the outputs it produced
+            yg = self._group.decode_member(self, x, x2)
+            if yg is not None:
+                return yg.reshape(*x.shape[:-1], N)
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         if M == 0 or (self._group is not None and self._group.forward_member(self, x, x2, y)):
             return y.reshape(*x.shape[:-1], N)
@@ -448,6 +453,11 @@ class SharedActivation:
         self._cur = None
         self._served = set()  # members served from the current images
         self._plans = {}      # (M, dtype) -> launch constants of the group quantizer and of every member's GEMM
+        # decode sizes (M <= 8): ONE launch for the whole group (lqer_linear_forward_group)
+        self._dplans = {}     # (M, dtype) -> member table of the group launch, or None when the C ABI refuses the group
+        self._dx, self._dver = None, -1   # the tensor the current outputs were computed from
+        self._dys = None      # outputs of the current round, one per member
+        self._dserved = set()
         if self.enabled:
             for m in self.members:
                 m._group = self
@@ -455,12 +465,14 @@ class SharedActivation:
     def invalidate(self):
         self._cat, self._x, self._cur, self._served = None, None, None, set()
         self._plans = {}
+        self._dplans, self._dx, self._dys, self._dserved = {}, None, None, set()
 
     def __getstate__(self):
         # copy.deepcopy / pickle (a whole model is copied with its groups): the launch plans and the current round hold raw device
         # pointers of THIS group's members and of the shared pool - the copy rebuilds them at its first call
         st = self.__dict__.copy()
-        st.update(_cat=None, _x=None, _cur=None, _served=set(), _plans={}, _ver=-1)
+        st.update(_cat=None, _x=None, _cur=None, _served=set(), _plans={}, _ver=-1, _dplans={}, _dx=None, _dys=None, _dserved=set(),
+                  _dver=-1)
         return st
 
     @classmethod
@@ -491,6 +503,76 @@ class SharedActivation:
             ok16, a16 = ops.a_f16_image(m0._packed["w"], m0.out_features, K, a_t, 2, off)
             if ok16:
                 self._cat["a_t_f16"] = a16
+
+    @torch.no_grad()
+    def decode_member(self, mod, x, x2):
+        """Up to 8 tokens: every member's forward in ONE launch (lqer_linear_forward_group: the producers multiply x with the
+        concatenated A, each member's weight-streaming workgroups read their rank columns - per member the bits of its own
+        forward).  The first member that is handed a tensor launches the group and gets its output; the others are handed
+        theirs when they come with the very same tensor object, unmodified, once each.  None = not applicable (the caller
+        takes the per-member route)."""
+        if not self.enabled:
+            return None
+        ver = None if x.is_inference() else x._version
+        idx = self.members.index(mod)
+        if x is self._dx and ver == self._dver and self._dys is not None and idx not in self._dserved:
+            self._dserved.add(idx)
+            y = self._dys[idx]
+            if len(self._dserved) == len(self.members):
+                self._dx, self._dys = None, None  # every member served: do not pin the tensors until the next round
+            return y
+        M, K = x2.shape
+        dtc = ops.dtype_code(x2)
+        plan = self._dplans.get((M, dtc), False)
+        if plan is None:
+            return None
+        L = _lib.lib()
+        dev = x2.device
+        if plan is False:
+            if any(m._packed_only for m in self.members):  # (a packed checkpoint carries no dense A to concatenate)
+                self._dplans[(M, dtc)] = None
+                return None
+            for m in self.members:
+                if m._packed is None or m.w_is_quantized is False:
+                    m._pack()
+            if self._cat is None:
+                self._pack_cat(dev)
+            n = len(self.members)
+            descs = [m._desc(plain=True) for m in self.members]  # (decode sizes never take the int8 tile kernel)
+            tab = (_lib.GroupMember * n)()
+            for i, (m, d) in enumerate(zip(self.members, descs)):
+                pk = m._packed
+                tab[i].desc, tab[i].w_packed, tab[i].b_t = C.pointer(d), pk["w"].data_ptr(), pk["b_t"].data_ptr()
+                tab[i].b_limbs, tab[i].bias_q, tab[i].ldy = pk["b_limbs"], ops._ptr(pk.get("bias")), m.out_features
+            ok = (2 <= n <= 4 and self._cat["a_limbs"] == 1 and all(L.lqer_decode_partials(C.byref(d), M) == 1 for d in descs)
+                  and not any(m._x_f16 for m in self.members) and self._cat["rp_total"] <= 128)
+            if not ok:
+                self._dplans[(M, dtc)] = None
+                return None
+            if len(self._dplans) > 64:
+                self._dplans = {}
+            plan = self._dplans[(M, dtc)] = {
+                "tab": tab, "descs": descs, "n": n, "Ns": [m.out_features for m in self.members],
+                "ws": L.lqer_group_workspace_bytes(K, self._cat["rp_total"]), "a_t": self._cat["a_t"].data_ptr()}
+        if x2.stride(0) < K or (x2.data_ptr() & 15) or (x2.stride(0) * x2.element_size()) % 16:
+            return None
+        Ns = plan["Ns"]
+        buf = torch.empty(M * sum(Ns), dtype=x.dtype, device=dev)
+        ys, off, tab = [], 0, plan["tab"]
+        for i, N in enumerate(Ns):
+            ys.append(buf[off: off + M * N].view(M, N))
+            tab[i].y = ys[-1].data_ptr()
+            off += M * N
+        ws = ops.workspace(dev, plan["ws"])
+        rc = L.lqer_linear_forward_group(tab, plan["n"], x2.data_ptr(), dtc, M, x2.stride(0) if M > 1 else K, plan["a_t"], 1,
+                                         ws.data_ptr(), ws.numel(), ops._stream(dev))
+        if rc == -2:  # LQER_E_UNSUPPORTED (nothing was launched): this token count / shape stays on the per-member route
+            self._dplans[(M, dtc)] = None
+            return None
+        if rc:
+            check(rc, "lqer_linear_forward_group")
+        self._dx, self._dver, self._dys, self._dserved = x, ver, ys, {idx}
+        return ys[idx]
 
     @torch.no_grad()
     def forward_member(self, mod, x, x2, y) -> bool:

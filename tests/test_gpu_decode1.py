@@ -184,3 +184,129 @@ def test_graphed_callable_runs_a_chain_of_module_forwards(ops):
             assert torch.equal(got, want), (M, scale)
     with pytest.raises(ValueError):
         gc(xs[:1])
+
+
+def _group(Ns, K, r, bias, cfg, dtype, seed=70):
+    """Linears that will be handed the same tokens (q/k/v, gate/up): own weights, A, B and bias each."""
+    import lqer_amd
+    from bench import make_case
+
+    mods, x = [], None
+    for i, N in enumerate(Ns):
+        case = make_case(8, K, N, r, seed=seed + i, bias=bias)
+        x = case[0] if x is None else x
+        m = lqer_amd.LinearFlexibleLqer(K, N, bias=bias, q_config=cfg, l_config={"rank": r})
+        sd = {"weight": case[1], "A": case[2], "B": case[3]}
+        if bias:
+            sd["bias"] = case[4]
+        m.load_state_dict(sd)
+        mods.append(m.to(DEV).to(dtype))
+    return mods, x
+
+
+@pytest.mark.parametrize("Ns,K,r,bias,dtype", [((512, 256, 384), 1024, 32, False, torch.float16),   # q/k/v with GQA-style widths
+                                               ((1376, 1376), 4096, 32, False, torch.float16),        # gate/up
+                                               ((272, 512), 1088, 16, True, torch.float32),           # ragged K and N, bias
+                                               ((256, 256, 256, 256), 512, 32, False, torch.bfloat16),  # four members: rank columns 0..127
+                                               ((512, 512), 2048, 64, False, torch.float16)])         # 2 x rank 64 = 128 columns
+def test_group_decode_is_one_launch_with_the_members_own_bits(ops, Ns, K, r, bias, dtype):
+    """lqer_linear_forward_group through SharedActivation: the members of a group (handed the very same tensor) at M <= 8 run
+    as ONE launch; every member's output carries the bits of its own one-launch forward, with the producers' wait bounded at
+    0 (every workgroup computes the tiles itself) as well; a member that comes with ANOTHER tensor starts a new round."""
+    from bench import MXINT_Q, OPT_Q
+    from lqer_amd import _lib
+    from lqer_amd.linear import SharedActivation
+
+    cfg = OPT_Q if bias else MXINT_Q
+    mods, x = _group(Ns, K, r, bias, cfg, dtype)
+    for M in (1, 5, 8):
+        xd = x[:M].to(dtype).to(DEV)
+        alone = [m(xd).clone() for m in mods]  # (no group yet: each member's own launch)
+        grp = SharedActivation(mods)
+        assert grp.enabled
+        got = [m(xd) for m in mods]
+        assert grp._dplans[(M, ops.dtype_code(xd))] is not None  # the group launch was taken ...
+        assert grp._dx is None and grp._dys is None              # ... and every member has been served
+        for a, g_ in zip(alone, got):
+            assert torch.equal(a, g_)
+        # a second round with new values in a NEW tensor; only two of the members come (the third output is dropped)
+        x2 = (xd * 0.5).contiguous()
+        assert torch.equal(mods[1](x2), (lambda t: (setattr(mods[1], "_group", None), mods[1](t), setattr(mods[1], "_group", grp))[1])(x2))
+        assert torch.equal(mods[0](x2), (lambda t: (setattr(mods[0], "_group", None), mods[0](t), setattr(mods[0], "_group", grp))[1])(x2))
+        # an in-place write to the tensor between two members' calls: the second member must not be handed stale outputs
+        x3 = xd.clone()
+        y0 = mods[0](x3)
+        x3.mul_(2.0)
+        y1 = mods[1](x3)
+        mods[1]._group = None
+        assert torch.equal(y1, mods[1](x3))
+        mods[1]._group = grp
+        for m in mods:  # the consumers' fall-back inside the group launch
+            m.tuning = _lib.TUNE_DECODE_NO_POLL
+        grp.invalidate()
+        got_fb = [m(xd) for m in mods]
+        for a, g_ in zip(alone, got_fb):
+            assert torch.equal(a, g_)
+        for m in mods:
+            m.tuning = 0
+            m._group = None
+
+
+def test_group_decode_under_graph_capture(ops):
+    """A decoder layer's q/k/v (one group launch) captured in a graph: replays with new inputs follow them bit for bit."""
+    from bench import MXINT_Q
+    from lqer_amd.graph import GraphedCallable
+    from lqer_amd.linear import SharedActivation
+
+    mods, x = _group((512, 512, 512), 1024, 32, False, MXINT_Q, torch.float16)
+    grp = SharedActivation(mods)
+    assert grp.enabled
+    fn = lambda t: torch.cat([m(t) for m in mods], dim=-1)
+    xs = x[:4].half().to(DEV).clone()
+    gc = GraphedCallable(fn, xs, warmup=1)
+    for scale in (1.0, -0.25, 3.0, 0.5):
+        xn = (x[:4] * scale).half().to(DEV)
+        want = fn(xn)
+        got = gc(xn).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), scale
+
+
+def test_group_forward_c_abi_refuses_what_it_does_not_serve(ops):
+    """lqer_linear_forward_group returns LQER_E_UNSUPPORTED without launching for member sets outside the one-launch route:
+    M > 8, one member, members of different K; the Python group then runs member by member (same results)."""
+    from bench import MXINT_Q
+    from lqer_amd import _lib
+    from lqer_amd.linear import SharedActivation
+
+    L = _lib.lib()
+    mods, x = _group((256, 256), 512, 32, False, MXINT_Q, torch.float16)
+    xd = x.half().to(DEV)
+    for m in mods:
+        m(xd)
+    descs = [m._desc() for m in mods]
+    tab = (_lib.GroupMember * 2)()
+    ys = [torch.empty(8, 256, dtype=torch.float16, device=DEV) for _ in mods]
+    for i, (m, d) in enumerate(zip(mods, descs)):
+        p = m._packed
+        tab[i].desc, tab[i].w_packed, tab[i].b_t, tab[i].b_limbs = C.pointer(d), p["w"].data_ptr(), p["b_t"].data_ptr(), p["b_limbs"]
+        tab[i].bias_q, tab[i].y, tab[i].ldy = None, ys[i].data_ptr(), 256
+    grp = SharedActivation(mods)
+    grp._pack_cat(torch.device(DEV))
+    ws = torch.empty(L.lqer_group_workspace_bytes(512, 64), dtype=torch.uint8, device=DEV)
+    call = lambda n, M: L.lqer_linear_forward_group(tab, n, xd.data_ptr(), _lib.F16, M, 512, grp._cat["a_t"].data_ptr(), 1, ws.data_ptr(),
+                                                    ws.numel(), None)
+    assert call(2, 8) == 0
+    torch.cuda.synchronize()
+    for m, y in zip(mods, ys):
+        m._group = None
+        assert torch.equal(m(xd), y)
+        m._group = grp
+    assert call(2, 9) == -2 and call(1, 8) == -2
+    assert L.lqer_linear_forward_group(tab, 2, xd.data_ptr(), _lib.F16, 8, 512, grp._cat["a_t"].data_ptr(), 1, ws.data_ptr(), 64, None) == -4
+    # M = 16: the group keeps the shared-image route (one quantizer + side GEMM launch, then each member's GEMM)
+    x16 = torch.cat([xd, xd * 0.5]).contiguous()
+    outs = [m(x16) for m in mods]
+    for m, o in zip(mods, outs):
+        m._group = None
+        assert float((m(x16).float() - o.float()).norm() / o.float().norm()) <= 2e-3

@@ -223,3 +223,75 @@ def test_int8_route_side_gemm_on_one_fp16_limb(lq):
     for f16 in (True, False):
         assert float((outs[f16] - ref).norm() / ref.norm()) <= 1e-3
     assert float((outs[True] - outs[False]).norm() / ref.norm()) <= 5e-4
+
+
+def _mode_weights(N, K, seed):
+    """Weights whose 256-row n tiles take the three ways group exponents travel in the int8 image (csrc/common.h I8_MODE_*):
+    tile 0 - every 128-k group of every row in one binade (NONE); tile 1 - a row whose groups span 7 binades (FOLD);
+    the tiles in between - random group scales over 3..5 binades (PRESHIFT: the int8 lane itself carries the exponent); the last
+    tile - plain Gaussian rows (PRESHIFT1: at most two binades)."""
+    g = torch.Generator().manual_seed(seed)
+    W = 0.02 * torch.randn(N, K, generator=g)
+    G = -(-K // 128)
+    W *= 2.0 ** torch.randint(-1, 2, (N, G), generator=g).float().repeat_interleave(128, dim=1)[:, :K]  # spread 2 (+ <= 2 of the maxima)
+    W[-256:] = 0.02 * torch.randn(256, K, generator=g)  # the last tile: plain Gaussian rows - group maxima within two binades
+    W[:256] = (0.04 * torch.rand(256, K, generator=g) - 0.02)
+    W[:256, ::128] = 0.06  # one element per group pins the group maximum: e = ceil(log2 0.06) = -4 everywhere
+    W[300] = 0.02 * torch.randn(K, generator=g)  # tile 1: this row's first group lies ~8 binades under its second
+    W[300, :128] *= 2.0 ** -6
+    W[300, 128:256] *= 4.0
+    return W
+
+
+def test_int8_weight_image_tile_modes(lq):
+    from lqer_amd import ops
+
+    N, K = 1024, 640
+    W = _mode_weights(N, K, 3)
+    fmt = _wfmt(ops, 128)
+    packed = ops.pack_weight(W.to(DEV), fmt)
+    ok, buf = ops.i8_prepare(packed, N, K, fmt)
+    assert ok
+    Np, nk8 = 1024, 5
+    img = buf[packed.numel():]  # (the int8 image lies behind the sign-magnitude one: 64 x 10 panels of 576 B, a multiple of 256)
+    off = (Np // 256) * nk8 * (256 * 64 + 256) + Np * 4
+    assert img[off: off + 4].cpu().tolist() == [0, 1, 2, 3]  # NONE, FOLD, PRESHIFT, PRESHIFT1
+    assert torch.equal(ops.unpack_weight_i8(buf, N, K).cpu(), ops.unpack_weight(packed, N, K, fmt).cpu())
+    # shift bytes: FOLD s = e - emin >= 0 (up to 7 here), PRESHIFT q = emax - e in [0, 4]
+    blocks = img[: (Np // 256) * nk8 * (256 * 64 + 256)].view(Np // 256, nk8, 256 * 64 + 256)[:, :, 256 * 64:].cpu()
+    assert int(blocks[0].max()) == 0 and int(blocks[1].max()) >= 5 and 2 <= int(blocks[2].max()) <= 4 and int(blocks[3].max()) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_int8_route_tile_modes_forward(lq, dtype):
+    """One Linear whose n tiles take all three main loops of k_lqer_gemm_i8 (plain, fold, pre-shifted lanes): the int8
+    route against the SAME module on the bf16 route (same exact operands: 16-bit outputs agree except for rare roundings of
+    differently ordered fp32 sums) and against the oracle; run-to-run bit stability of the mixed-mode launch."""
+    from bench import INT_Q, make_case
+    from lqer_amd import _lib
+
+    M, K, N, r = 2048, 640, 8192, 64
+    x, _, A, B = make_case(M, K, N, r, seed=41, quantize_ab=False)
+    W = _mode_weights(N, K, 4)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=INT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).to(dtype)
+    xin = x.to(dtype).to(DEV)
+    y = mod(xin).clone()
+    assert mod._x_i8
+    assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16 if dtype != torch.float32 else _lib.F32) == _lib.ROUTE_TILE256_I8
+    for _ in range(5):
+        assert torch.equal(mod(xin), y)
+    cast = lambda t: t.to(dtype).float()
+    ref = O.lqer_linear_forward(cast(x), cast(W), None, cast(A), cast(B), INT_Q)
+    tol = 2e-5 if dtype == torch.float32 else 1e-3
+    assert float((y.float().cpu() - ref).norm() / ref.norm()) <= tol
+    mod.a8_native = False
+    mod.invalidate_packed(weight_changed=False)
+    y2 = mod(xin)
+    assert not mod._x_i8
+    for lo, hi in ((0, 256), (256, 512), (512, N - 256), (N - 256, N)):  # per tile mode
+        d = float((y[:, lo:hi].float() - y2[:, lo:hi].float()).norm() / y2[:, lo:hi].float().norm())
+        assert d <= (1e-5 if dtype == torch.float32 else tol / 4), (lo, d)
+        if dtype != torch.float32:
+            assert float((y[:, lo:hi] != y2[:, lo:hi]).float().mean()) <= 0.01, lo
