@@ -684,15 +684,8 @@ def _decode_group_region(ctx, unit, M, r, has_bias, rotate, warmup, steps, ev_fl
         for _ in range(max(1, warmup // 2)):
             step_mod()
         el_m = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_mod() for _ in range(n)], steps), dev)
-        # the pair overhead, as for the headline sample
-        cal = []
-        for _ in range(16):
-            fwd(*calls[0])
-            c0, c1 = new_pair()
-            c0.record(stream), c1.record(stream)
-            cal.append((c0, c1))
-        torch.cuda.synchronize()
-        ovh = sorted(c0.elapsed_time(c1) for c0, c1 in cal)[len(cal) // 2]
+        # the pair overhead: the headline sample's calibration (an empty pair right behind a small kernel)
+        ovh = RL.event_pair_overhead_ms(L, _lib, ops, dev, stream, (xd, K), new_pair, M)
         tot_ms = sum(max(e0.elapsed_time(e1) - ovh, 1e-6) for e0, e1 in events)
         nl = max(len(events), 1)
         Kp, Np, rp = -(-K // 64) * 64, -(-N // 256) * 256, -(-r // 16) * 16

@@ -42,8 +42,10 @@ constexpr int MAXNT = 4;       // rank tiles of 16 (padded rank <= 64)
 #ifndef LQER_QD1_SPIN
 #define LQER_QD1_SPIN 4096
 #endif
-// LDS (dynamic): [xs image: M x Kp bf16][red 7 KiB][xaq 1 KiB][pslab 4 KiB][pred 28 KiB]
-constexpr int RED_BYTES = (NW - 1) * 4 * 64 * 4;
+// LDS (dynamic): [xs image: M x Kp bf16  |alias|  pslab 4 KiB, pred 28 KiB][red: cpw x 8 KiB][xaq 1 KiB][flag]
+constexpr int MAXCPW = 4;                         // column blocks of 16 per consumer workgroup
+constexpr int RED1_BYTES = NW * 4 * 64 * 4;       // one block's partial sums of the 8 waves
+                                                  // (every block keeps its own: ONE barrier for all of a workgroup's blocks)
 constexpr int XAQ_BYTES = MAXM * 64 * 2;
 constexpr int PSLAB_BYTES = MAXM * SLAB_K * 2;
 constexpr int PRED_BYTES = (NW - 1) * MAXNT * 4 * 64 * 4;
@@ -87,10 +89,16 @@ struct Member {        // one Linear of the launch: its own packed operands and 
   int N, Np, rp, b_limbs;
   int r_off;           // its first column in the concatenated x A (granules, A^T image)
   int cb0;             // its first consumer workgroup (consumer ids run member-major)
+  int nblk;            // its column blocks of 16 (Np / 16); a consumer workgroup takes `cpw` consecutive ones
 };
+// The kernel-argument block is kept SMALL: on this stack the host writes it per launch at ~7 ns per byte (measured: 920 B against
+// 616 B = +2.2 us per lqer_linear_forward call, and decode steps at M <= 4 are host-bound) - only what the kernel reads, and a
+// single Linear's launch carries one table entry (NM = 1: 280 B), a group's four.
+template <int NM>
 struct Args {
-  GemmArgs g;          // formats and shapes shared by the members: M, Kp, aout, bout (per-member fields: `mem`)
-  Member mem[MAXMEM];
+  Member mem[NM];
+  int M, Kp;           // tokens, padded K (shared by the members)
+  QP aout, bout;       // A_out / B_out formats (shared)
   int nmem;
   int rp_all;          // padded ranks summed over the members: row pitch of the granules and rows of the A^T image
   const void* x;       // [M, K] tokens, row stride ldx
@@ -102,6 +110,7 @@ struct Args {
   uint32_t nonce;      // host part of the granule tag (a per-call counter); the kernel mixes in its dispatch id and queue
   int np;              // producers = ceil(Kp / 256)
   int spin;            // poll sweeps before a consumer computes the tiles itself
+  int cpw;             // column blocks per consumer workgroup: the grid never exceeds what is resident at once (one round)
 };
 
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
@@ -199,12 +208,17 @@ __device__ __forceinline__ void quant_block16(const float (&v)[16], const QP& q,
 // lane group touches (8 rows x two neighbouring chunks) spread over the 16 chunk slots of a 256-byte bank row
 __device__ __forceinline__ int img_off(int r, int c, int pitch) { return r * pitch + ((c ^ (2 * (r & 7))) << 4); }
 
-template <int DT, int BOUT>
+// GROUP: more than one Linear in the launch (lqer_linear_forward_group) - a single Linear's instantiation reads its one table
+// entry from static argument offsets only (the scan of the table's other entries costs its first weight request ~0.8 us:
+// measured, rocprofv3 kernel durations 9.0 vs 8.1 us at M = 1).
+template <int DT, int BOUT, bool GROUP>
 // (two workgroups per CU: the grid is the N/16 consumers PLUS the producers - 272 for N = 4096 -, with one workgroup per CU the
-// last 16 would wait for a whole round; 4 waves per SIMD caps the kernel at 128 registers)
-__global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
+// last 16 would wait for a whole round; 4 waves per SIMD caps the kernel at 128 registers.  Wider launches - a group of
+// Linears, or M >= 6 where the x image leaves room for one workgroup per CU - give every consumer up to four column blocks, so
+// that the whole launch is resident at once)
+__global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args<GROUP ? MAXMEM : 1> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const GemmArgs& g = a.g;
+  const auto& g = a;  // (the shared formats and shapes: M, Kp, aout, bout)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
@@ -215,13 +229,17 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   const uint32_t tag = (a.nonce + (uint32_t)lqer_dispatch_id() * 0x9E3779B1u) ^
                        ((uint32_t)((unsigned long long)__builtin_amdgcn_queue_ptr() >> 6) * 0x85EBCA6Bu);
   const int xpitch = (Kp * 2 + 255) / 256 * 256;  // (the chunk XOR stays inside a 256-byte group)
+  // LDS: the producers' slab + reduction area ALIAS the consumers' x image - a consumer touches them (gather sums, the
+  // fall-back's produce()) only behind the one barrier that follows its last weight stream, when the image is dead
   const int xs_bytes = M * xpitch;
+  const int img_bytes = xs_bytes > PSLAB_BYTES + PRED_BYTES ? xs_bytes : PSLAB_BYTES + PRED_BYTES;
   unsigned char* const xs = smem;
-  float* const red = (float*)(smem + xs_bytes);
-  bf16_t* const xaq_l = (bf16_t*)(smem + xs_bytes + RED_BYTES);
-  unsigned char* const pslab = smem + xs_bytes + RED_BYTES + XAQ_BYTES;
+  unsigned char* const pslab = smem;
   float* const pred = (float*)(pslab + PSLAB_BYTES);
-  volatile uint32_t* const miss_flag = (volatile uint32_t*)((unsigned char*)pred + PRED_BYTES);  // (not inside pred: produce() writes there)
+  float* const red = (float*)(smem + img_bytes);
+  const int red_bytes = a.cpw * RED1_BYTES;
+  bf16_t* const xaq_l = (bf16_t*)(smem + img_bytes + red_bytes);
+  volatile uint32_t* const miss_flag = (volatile uint32_t*)(smem + img_bytes + red_bytes + XAQ_BYTES);  // (its own word)
   if (tid == 0) *miss_flag = 0u;  // (ordered before its use by the barriers below)
   const auto gran_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, a.np * MAXM * rp_all * 8, 0x00020000);
   const int nt16_all = rp_all / 16;
@@ -318,17 +336,29 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
 
   // ================================================== consumer =========================================================
   // which Linear of the launch this workgroup belongs to (consumer ids run member-major; scalar index into the argument table)
+  // (what the weight stream's first request depends on - the member's packed image, its first workgroup and block count - is
+  // selected from STATIC argument offsets: one batch of scalar loads with everything else; a table entry fetched by a computed
+  // index would put a second, dependent scalar-memory round trip in front of the first weight panel.  The epilogue's fields come
+  // from the indexed entry: their latency passes under the stream.)
   const int cb_all = (int)blockIdx.x - a.np;
-  int mi = 0;
-  for (int i = 1; i < a.nmem; ++i) mi = cb_all >= a.mem[i].cb0 ? i : mi;
-  mi = __builtin_amdgcn_readfirstlane(mi);
-  const Member& mb = a.mem[mi];
+  int mi = 0, m_cb0 = 0, m_nblk = a.mem[0].nblk;
+  const uint8_t* m_wp = a.mem[0].wp;
+  if constexpr (GROUP) {
+#pragma unroll
+    for (int i = 1; i < MAXMEM; ++i) {
+      const bool in = cb_all >= a.mem[i].cb0;  // (unused entries: cb0 = INT_MAX)
+      mi = in ? i : mi, m_cb0 = in ? a.mem[i].cb0 : m_cb0, m_nblk = in ? a.mem[i].nblk : m_nblk, m_wp = in ? a.mem[i].wp : m_wp;
+    }
+    mi = __builtin_amdgcn_readfirstlane(mi);
+  }
+  const Member& mb = a.mem[GROUP ? mi : 0];
   const int rp = mb.rp, r_off = mb.r_off;
-  const int cb = cb_all - mb.cb0;
+  // this workgroup's column blocks of 16: cpw consecutive ones of its member (x is quantized into LDS once for all of them,
+  // the member's x A is gathered once; the launch then fits the chip in ONE round whatever N and the group size are)
+  const int cb_first = (cb_all - m_cb0) * a.cpw;
+  const int nb_here = m_nblk - cb_first < a.cpw ? m_nblk - cb_first : a.cpw;
   const int row = l15, q = lq;  // weight row / token within the tile; k group (gemm_smallm.hip's names)
-  const int n0 = cb * 16;
   const int nk = Kp / 64;
-  const uint8_t* prow = mb.wp + (int64_t)cb * nk * LQER_PANEL_BYTES;
   const int codes_off = row * 32 + (q & 1) * 16;
   const int exps_off = 512 + row * 4;
   const bool hi = (q >> 1) != 0;
@@ -337,11 +367,15 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
 
   // weight panels through a buffer descriptor: a request past the end is dropped by the range check,
   // so no load sits under a branch and the compiler's vmcnt counts stay exact
-  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)prow, 0, nk * LQER_PANEL_BYTES, 0x00020000);
-  auto load_panel = [&](int kt, SmPanel& p) {  // kt >= nk: zeros
-    const uint32_t base = kt < nk ? (uint32_t)kt * LQER_PANEL_BYTES : 0x7ffffff0u;
-    p.cw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, base + codes_off, 0, 0));
-    p.ex = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, base + exps_off, 0, 0);
+  auto block_rsrc = [&](int cb) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(m_wp + (int64_t)cb * nk * LQER_PANEL_BYTES), 0, nk * LQER_PANEL_BYTES, 0x00020000);
+  };
+  auto load_panel = [&](const auto& w_rsrc, int kt, SmPanel& p) {  // kt >= nk: zeros
+    // (the panel's base as the SCALAR offset - part of the range check on gfx9 -, the lane's place inside a panel as the one
+    // vector offset: no per-panel address registers to keep alive across column blocks)
+    const int base = __builtin_amdgcn_readfirstlane(kt < nk ? kt * LQER_PANEL_BYTES : 0x7ffffff0);
+    p.cw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, codes_off, base, 0));
+    p.ex = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, exps_off, base, 0);
   };
   // wave w takes panels w, w + 8, ...; two register buffers of 4 panels
   constexpr int UNR = 4;
@@ -365,8 +399,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   };
   request_x(tid);
   asm volatile("" ::: "memory");  // (keeps the requests HERE: the compiler otherwise sinks them to their use, behind the panels)
+  {
+    const auto w_first = block_rsrc(cb_first);
 #pragma unroll
-  for (int u = 0; u < UNR; ++u) load_panel(kt_of(u), pa[u]);
+    for (int u = 0; u < UNR; ++u) load_panel(w_first, kt_of(u), pa[u]);
+  }
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // ---- the activation image of ALL of x in LDS: block b = (row b / (Kp/16), segment b % (Kp/16))
@@ -392,25 +429,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
   __syncthreads();
   D1_STAMP(1);
 
-  // ---- main loop (gemm_smallm.hip with the activation fragments from LDS).  Token rows >= M read row 0: their output
-  // columns are never stored
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int xrow = row < M ? row : 0;
-  auto compute_panel = [&](int kt, const SmPanel& p) {
-    const uint32_t w0 = hi ? p.cw[1] : p.cw[0], w1 = hi ? p.cw[3] : p.cw[2];
-    const bf16x8 wb0 = expand_frag(w0, ((p.ex >> sh0) & 0xffu) << 23);
-    const bf16x8 wb1 = expand_frag(w1, ((p.ex >> sh1) & 0xffu) << 23);
-    const int kc = kt < nk ? kt : 0;  // (past the end: zero weights, any finite activation chunk)
-    const bf16x8 x0 = *(const bf16x8*)(xs + img_off(xrow, kc * 8 + q, xpitch));
-    const bf16x8 x1 = *(const bf16x8*)(xs + img_off(xrow, kc * 8 + 4 + q, xpitch));
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0, x0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1, x1, acc, 0, 0, 0);
-  };
   // ---- x A from the producers' granules: one thread per 4 rank entries of a token, slabs summed in a fixed order.
   // The 512 threads read the granules as 4 groups x 128 items: group pg takes the slabs pg, pg + 4, pg + 8, ... (4 requested
   // together: one memory round trip per batch), the groups' sums are added in the order 0..3 through LDS.  The FIRST batch
-  // is requested inside the main loop's last iteration, behind the last weight panels: loads return in order, so the
-  // granules are there when the weight stream ends (their ~1.3 us round trip past this CU's caches is not paid after it).
+  // is requested at the end of the first column block's weight stream: loads return in order, so the granules are there when
+  // the cross-wave combine is done (their ~1.3 us round trip past this CU's caches is not paid after it).
   const int items = lowrank ? M * rp / 4 : 0;  // <= 128
   const int rq = lowrank ? rp / 4 : 1;
   const int pg = tid >> 7, it = tid & 127;
@@ -427,52 +450,141 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
       b.v1[u] = __builtin_amdgcn_raw_buffer_load_b128(gran_rsrc, (int)(off + 16u), 0, 16);
     }
   };
+  // ---- one column block's weight stream (gemm_smallm.hip's main loop with the activation fragments from LDS; token rows >= M
+  // read row 0: their output columns are never stored), then (prefetch_c) the request for the NEXT block's first panels: they
+  // travel under the combine and wave 0's epilogue (unconditional - past the workgroup's blocks the descriptor's range drops
+  // them: no load under a branch)
+  auto request_first_panels = [&](int jb) {  // of column block jb (past the workgroup's blocks: an empty range, no traffic)
+    const auto w_blk = __builtin_amdgcn_make_buffer_rsrc((void*)(m_wp + (int64_t)(cb_first + jb) * nk * LQER_PANEL_BYTES), 0,
+                                                         jb < nb_here ? nk * LQER_PANEL_BYTES : 0, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) load_panel(w_blk, kt_of(u), pa[u]);
+  };
+  auto stream_block = [&](int jb, auto prefetch_c) -> f32x4 {
+    const int cb = cb_first + jb;
+    const auto w_rsrc = block_rsrc(cb);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int lrow = l15;
+    asm volatile("" : "+v"(lrow));  // (re-derived per block: kept alive from the top of the kernel it costs a spill)
+    const int xrow = lrow < M ? lrow : 0;
+    auto compute_panel = [&](int kt, const SmPanel& p) {
+      const uint32_t w0 = hi ? p.cw[1] : p.cw[0], w1 = hi ? p.cw[3] : p.cw[2];
+      const bf16x8 wb0 = expand_frag(w0, ((p.ex >> sh0) & 0xffu) << 23);
+      const bf16x8 wb1 = expand_frag(w1, ((p.ex >> sh1) & 0xffu) << 23);
+      const int kc = kt < nk ? kt : 0;  // (past the end: zero weights, any finite activation chunk)
+      const bf16x8 x0 = *(const bf16x8*)(xs + img_off(xrow, kc * 8 + q, xpitch));
+      const bf16x8 x1 = *(const bf16x8*)(xs + img_off(xrow, kc * 8 + 4 + q, xpitch));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0, x0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1, x1, acc, 0, 0, 0);
+    };
+    // (no tests around loads or MFMAs: a panel past the end is zeros times the image's first chunk)
+    for (int i = 0; i < per_wave; i += 2 * UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) load_panel(w_rsrc, kt_of(i + UNR + u), pb[u]);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + u), pa[u]);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) load_panel(w_rsrc, kt_of(i + 2 * UNR + u), pa[u]);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + UNR + u), pb[u]);
+    }
+    if constexpr (decltype(prefetch_c)::value) request_first_panels(jb + 1);
+    return acc;
+  };
+  // the waves' partial sums of a column block, parked in the block's own LDS buffer; its epilogue wave adds them in the fixed
+  // order (((w0 + w1) + w2) + ...) + w7
+  auto park = [&](int jb, const f32x4& acc) {
+    float* const redj = red + jb * (RED1_BYTES / 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) redj[(wave * 4 + j) * 64 + lane] = acc[j];
+  };
+  auto combine_sum = [&](int jb) -> f32x4 {
+    const float* const redj = red + jb * (RED1_BYTES / 4);
+    f32x4 acc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = redj[j * 64 + lane];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) t += redj[(w2 * 4 + j) * 64 + lane];
+      acc[j] = t;
+    }
+    return acc;
+  };
+  // wave 0's operands of the epilogue that do not depend on x A: requested right behind the combine barrier
+  auto side_b_first = [&](int n0) -> bf16x8 {
+    bf16x8 sp_b = zero8;
+    if (lowrank && mb.b_limbs > 0 && 8 * q < rp) sp_b = *(const bf16x8*)(mb.bt + (int64_t)(n0 + row) * rp + 8 * q);
+    return sp_b;
+  };
+  auto bias_of = [&](int n0) -> f32x4 {
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};  // (the bias image is padded to Np: columns n0 + 4 q .. + 3 exist)
+    if (mb.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bias4[j] = mb.bias[n0 + 4 * q + j];
+    }
+    return bias4;
+  };
+  // ---- side path + bias + store (wave 0, gemm_smallm.hip's epilogue): lane = token `row`, output columns n0 + 4 q + j
+  auto epilogue = [&](int n0, const f32x4& acc, const bf16x8& sp_b, const f32x4& bias4) {
+    const int nq = n0 + 4 * q;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (lowrank) {
+      bf16x8 sp_x = zero8;
+      if (8 * q < rp && row < M) sp_x = *(const bf16x8*)(xaq_l + row * rp + 8 * q);
+      if (mb.b_limbs > 0) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_b, sp_x, s, 0, 0, 0);  // prefetched
+      for (int l = 0; l < mb.b_limbs; ++l)
+        for (int ks = (l == 0 ? 1 : 0); ks * 32 < rp; ++ks) {
+          const int j0 = ks * 32 + 8 * q;
+          bf16x8 bb = zero8, xv = zero8;
+          if (j0 < rp) {
+            bb = *(const bf16x8*)(mb.bt + ((int64_t)l * mb.Np + n0 + row) * rp + j0);
+            if (row < M) xv = *(const bf16x8*)(xaq_l + row * rp + j0);
+          }
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, xv, s, 0, 0, 0);
+        }
+      D1_STAMP_AFTER(9, s[0]);
+      if constexpr (BOUT == 1) {
+        float amax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3])));
+        {  // max over lanes l, l ^ 16, l ^ 32 without the LDS crossbar: v_permlane16_swap / v_permlane32_swap
+          auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+          amax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+          auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+          amax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+        }
+        const int e = block_exponent(amax, g.bout);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = fabsf(s[j]) <= 1e-8f ? s[j] : mxint_value(s[j], e, g.bout);
+      }
+    }
+    D1_STAMP_AFTER(10, s[0]);
+    if (row < M) {
+      float out[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] = (s[j] + bias4[j]) + acc[j];
+      store_row4<DT>(mb.y, (int64_t)row * mb.ldy + nq, nq, mb.N, out);
+    }
+  };
+
+  // ================= every column block's weight stream first (the next block's first panels are requested as the current
+  // stream ends), the partial sums parked per block; then - ONE barrier - the member's x A (gathered and re-quantized once);
+  // then the epilogues, block b by wave b, side by side
+  for (int jb = 0; jb < nb_here; ++jb) {  // (behind the last block the request has an empty range: eight loads without traffic)
+    const f32x4 acc = stream_block(jb, std::true_type{});
+    park(jb, acc);
+  }
   GBatch gb;
-  // (no tests around loads or MFMAs: a panel past the end is zeros times the image's first chunk)
-  for (int i = 0; i < per_wave; i += 2 * UNR) {
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) load_panel(kt_of(i + UNR + u), pb[u]);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + u), pa[u]);
-    // (unconditional: every other iteration requests out-of-range offsets, which cost no memory access - a load under a
-    // branch would make the compiler wait for everything in flight at the next use)
-#if LQER_D1_PREFETCH == 2
-    gather_issue(lowrank && i + 2 * UNR >= per_wave ? pg : (1 << 20), gb);
-#endif
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) load_panel(kt_of(i + 2 * UNR + u), pa[u]);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) compute_panel(kt_of(i + UNR + u), pb[u]);
-  }
-
-#if LQER_D1_PREFETCH == 2
-  if (per_wave <= 0) gather_issue(lowrank ? pg : (1 << 20), gb);  // (a wave without panels: K < 64 x 8)
-#elif LQER_D1_PREFETCH == 1
-  gather_issue(lowrank ? pg : (1 << 20), gb);  // at the end of the weight stream: under the cross-wave combine
-#endif
+  gather_issue(lowrank ? pg : (1 << 20), gb);  // at the end of the weight streams: under the barrier and the epilogue waves' first loads
   D1_STAMP(2);
-
-  // fixed-order combine of the main product: (((w0 + w1) + w2) + ...) + w7, summed by wave 0 while the granules travel
-  if (wave > 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red[((wave - 1) * 4 + j) * 64 + lane] = acc[j];
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (not __syncthreads(): that would wait for the granule loads)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (not __syncthreads(): that would wait for the loads in flight)
   D1_STAMP(3);
-  // wave 0 requests the first side-path fragment of B now: its latency passes under the granule round trip (requested at
-  // the top of the kernel it would sit under a branch in front of the weight stream and cost a register for the whole loop)
+  // the epilogue waves request their operands that do not depend on x A now: their latency passes under the granule round trip
+  const bool ep_wave = wave < nb_here;
+  const int n0 = (cb_first + wave) * 16;
   bf16x8 sp_b = zero8;
-  if (lowrank && wave == 0 && mb.b_limbs > 0 && 8 * q < rp) sp_b = *(const bf16x8*)(mb.bt + (int64_t)(n0 + row) * rp + 8 * q);
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};  // (the bias image is padded to Np: columns n0 + 4 q .. + 3 exist)
-  if (wave == 0 && mb.bias) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bias4[j] = mb.bias[n0 + 4 * q + j];
-  }
-  if (wave == 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int w2 = 0; w2 < NW - 1; ++w2) acc[j] += red[(w2 * 4 + j) * 64 + lane];
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (ep_wave) {
+    sp_b = side_b_first(n0);
+    bias4 = bias_of(n0);
   }
   if (lowrank) {
     // prefetched: the first batch is already in flight (gb)
@@ -529,7 +641,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
       return sum;  // (threads 0 .. items-1 hold the totals)
     };
     bool complete;
-    float4 s = gather(a.spin, complete, LQER_D1_PREFETCH != 0);
+    float4 s = gather(a.spin, complete, true);
     D1_STAMP(4);
     if (!complete) {  // (workgroup-uniform: read back from LDS behind the barrier)
       // a producer has not been seen: compute every partial tile here (same routine, same bits), then read them back
@@ -561,45 +673,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args a) {
     __syncthreads();
   }
   D1_STAMP(8);
-  if (wave != 0) return;
-
-  // ---- side path + bias + store (wave 0, gemm_smallm.hip's epilogue): lane = token `row`, output columns n0 + 4 q + j
-  const int nq = n0 + 4 * q;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  if (lowrank) {
-    bf16x8 sp_x = zero8;
-    if (8 * q < rp && row < M) sp_x = *(const bf16x8*)(xaq_l + row * rp + 8 * q);
-    if (mb.b_limbs > 0) s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sp_b, sp_x, s, 0, 0, 0);  // prefetched
-    for (int l = 0; l < mb.b_limbs; ++l)
-      for (int ks = (l == 0 ? 1 : 0); ks * 32 < rp; ++ks) {
-        const int j0 = ks * 32 + 8 * q;
-        bf16x8 bb = zero8, xv = zero8;
-        if (j0 < rp) {
-          bb = *(const bf16x8*)(mb.bt + ((int64_t)l * mb.Np + n0 + row) * rp + j0);
-          if (row < M) xv = *(const bf16x8*)(xaq_l + row * rp + j0);
-        }
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb, xv, s, 0, 0, 0);
-      }
-    D1_STAMP_AFTER(9, s[0]);
-    if constexpr (BOUT == 1) {
-      float amax = fmaxf(fmaxf(fabsf(s[0]), fabsf(s[1])), fmaxf(fabsf(s[2]), fabsf(s[3])));
-      {  // max over lanes l, l ^ 16, l ^ 32 without the LDS crossbar: v_permlane16_swap / v_permlane32_swap
-        auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
-        amax = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
-        auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
-        amax = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
-      }
-      const int e = block_exponent(amax, g.bout);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[j] = fabsf(s[j]) <= 1e-8f ? s[j] : mxint_value(s[j], e, g.bout);
-    }
-  }
-  D1_STAMP_AFTER(10, s[0]);
-  if (row < M) {
-    float out[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = (s[j] + bias4[j]) + acc[j];
-    store_row4<DT>(mb.y, (int64_t)row * mb.ldy + nq, nq, mb.N, out);
+  if (ep_wave) {
+    const f32x4 acc = combine_sum(wave);
+    epilogue(n0, acc, sp_b, bias4);
   }
   D1_STAMP(5);
 }
@@ -612,8 +688,9 @@ static std::atomic<uint32_t> g_nonce{1};  // the call's granule tag: any value t
 extern "C" int lqer_debug_set_d1_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(d1::g_d1_stamps), &p, sizeof(p)); }
 #endif
 
-size_t decode1_lds_bytes(int M, int64_t Kp) {
-  return (size_t)M * ((Kp * 2 + 255) / 256 * 256) + d1::RED_BYTES + d1::XAQ_BYTES + d1::PSLAB_BYTES + d1::PRED_BYTES + d1::FLAG_BYTES;
+size_t decode1_lds_bytes(int M, int64_t Kp, int cpw) {  // cpw: column blocks per consumer workgroup (one 8-KiB sum buffer each)
+  const size_t xs = (size_t)M * ((Kp * 2 + 255) / 256 * 256), prod = d1::PSLAB_BYTES + d1::PRED_BYTES;  // (aliased: see the kernel)
+  return (xs > prod ? xs : prod) + (size_t)cpw * d1::RED1_BYTES + d1::XAQ_BYTES + d1::FLAG_BYTES;
 }
 
 size_t decode1_scratch_bytes(int64_t Kp, int rp) { return (size_t)((Kp + d1::SLAB_K - 1) / d1::SLAB_K) * d1::MAXM * rp * 8; }
@@ -624,21 +701,43 @@ size_t decode1_scratch_bytes(int64_t Kp, int rp) { return (size_t)((Kp + d1::SLA
 int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, const QP& qx, const bf16_t* a_t, int bout,
                      const DecodeMember* mem, int nmem, void* scratch, size_t scratch_bytes, hipStream_t st) {
   if (g.M < 1 || g.M > d1::MAXM || nmem < 1 || nmem > d1::MAXMEM || bout > 1 || K % 16 != 0) return LQER_E_UNSUPPORTED;
-  d1::Args a;
-  int rp_all = 0, cbs = 0;
+  d1::Args<d1::MAXMEM> a;
+  int rp_all = 0, blocks = 0;
   for (int i = 0; i < nmem; ++i) {
     if (mem[i].rp <= 0 || mem[i].rp > 16 * d1::MAXNT || mem[i].rp % 16 || mem[i].Np % 16 || !mem[i].bt || mem[i].b_limbs < 1 ||
         mem[i].b_limbs > 3)
       return LQER_E_UNSUPPORTED;
-    a.mem[i] = d1::Member{mem[i].wp, mem[i].bt, mem[i].bias, mem[i].y, mem[i].ldy, mem[i].N, mem[i].Np, mem[i].rp, mem[i].b_limbs, rp_all, cbs};
     rp_all += mem[i].rp;
-    cbs += mem[i].Np / 16;
+    blocks += mem[i].Np / 16;
   }
-  for (int i = nmem; i < d1::MAXMEM; ++i) a.mem[i] = d1::Member{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0x7fffffff};
   if (rp_all > 128) return LQER_E_UNSUPPORTED;
-  const size_t lds = decode1_lds_bytes(g.M, g.Kp);
-  if (lds > 150 * 1024 || scratch_bytes < decode1_scratch_bytes(g.Kp, rp_all) || ((uintptr_t)scratch & 15)) return LQER_E_UNSUPPORTED;
-  a.g = g;
+  if (scratch_bytes < decode1_scratch_bytes(g.Kp, rp_all) || ((uintptr_t)scratch & 15)) return LQER_E_UNSUPPORTED;
+  a.np = (int)((g.Kp + d1::SLAB_K - 1) / d1::SLAB_K);
+  // ONE round: at most what the chip holds at once (two workgroups per CU by registers, one when a workgroup's LDS - the x image
+  // above all - takes more than half of the CU's); a consumer then walks `cpw` consecutive column blocks of its member.  The
+  // smallest cpw whose own LDS footprint still leaves that many workgroups resident:
+  constexpr int CUS = 256;
+  size_t lds = 0;
+  a.cpw = 0;
+  for (int c = 1; c <= d1::MAXCPW; ++c) {
+    lds = decode1_lds_bytes(g.M, g.Kp, c);
+    if (lds > 150 * 1024) break;
+    const int slots = CUS * (2 * lds <= 160 * 1024 ? 2 : 1) - a.np;
+    if (slots > 0 && (int64_t)slots * c >= blocks) {
+      a.cpw = c;
+      break;
+    }
+  }
+  if (a.cpw == 0) return LQER_E_UNSUPPORTED;  // (K too long for the LDS image, or more than 4 x 16 columns per resident workgroup)
+  int cbs = 0, roff = 0;
+  for (int i = 0; i < nmem; ++i) {
+    const int nblk = mem[i].Np / 16;
+    a.mem[i] = d1::Member{mem[i].wp, mem[i].bt, mem[i].bias, mem[i].y, mem[i].ldy, mem[i].N, mem[i].Np, mem[i].rp, mem[i].b_limbs, roff, cbs, nblk};
+    roff += mem[i].rp;
+    cbs += (nblk + a.cpw - 1) / a.cpw;
+  }
+  for (int i = nmem; i < d1::MAXMEM; ++i) a.mem[i] = d1::Member{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0x7fffffff, 0};
+  a.M = g.M, a.Kp = g.Kp, a.aout = g.aout, a.bout = g.bout;
   a.nmem = nmem, a.rp_all = rp_all;
   a.x = x, a.ldx = ldx, a.K = K, a.qx = qx, a.a_t = a_t;
   a.gran = (uint32_t*)scratch;
@@ -646,14 +745,23 @@ int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, c
   // 2^32 calls) - small integers, zeros and the bit patterns of ordinary floats are what stale workspace bytes look like
   const uint32_t n = d1::g_nonce.fetch_add(1, std::memory_order_relaxed);
   a.nonce = n * 0x9E3779B1u ^ 0xA5C35A3Cu;
-  a.np = (int)((g.Kp + d1::SLAB_K - 1) / d1::SLAB_K);
   a.spin = (g.tuning & LQER_TUNE_DECODE_NO_POLL) ? 0 : LQER_QD1_SPIN;  // (tests: every consumer computes the tiles itself)
   const unsigned grid = (unsigned)(a.np + cbs);
+  d1::Args<1> a1;  // the single Linear's compact block
+  a1.mem[0] = a.mem[0];
+  a1.M = a.M, a1.Kp = a.Kp, a1.aout = a.aout, a1.bout = a.bout, a1.nmem = 1, a1.rp_all = a.rp_all, a1.x = a.x, a1.ldx = a.ldx, a1.K = a.K,
+  a1.qx = a.qx, a1.a_t = a.a_t, a1.gran = a.gran, a1.nonce = a.nonce, a1.np = a.np, a1.spin = a.spin, a1.cpw = a.cpw;
 #define D1_LAUNCH(DT, BO)                                                                     \
   do {                                                                                        \
-    static LdsLimitOnce lds_once;                                                             \
-    lds_once.set((const void*)d1::k_decode1<DT, BO>, 150 * 1024);                             \
-    d1::k_decode1<DT, BO><<<grid, 64 * d1::NW, lds, st>>>(a);                                 \
+    if (nmem > 1) {                                                                           \
+      static LdsLimitOnce lds_once;                                                           \
+      lds_once.set((const void*)d1::k_decode1<DT, BO, true>, 150 * 1024);                     \
+      d1::k_decode1<DT, BO, true><<<grid, 64 * d1::NW, lds, st>>>(a);                         \
+    } else {                                                                                  \
+      static LdsLimitOnce lds_once;                                                           \
+      lds_once.set((const void*)d1::k_decode1<DT, BO, false>, 150 * 1024);                    \
+      d1::k_decode1<DT, BO, false><<<grid, 64 * d1::NW, lds, st>>>(a1);                       \
+    }                                                                                         \
   } while (0)
   switch (dtype) {
     case LQER_F32: if (bout == 1) D1_LAUNCH(LQER_F32, 1); else D1_LAUNCH(LQER_F32, 0); break;

@@ -29,6 +29,14 @@ from . import _lib, ops
 from ._lib import LinearDesc, QFmt, check
 
 _SIG_BITS = {torch.float32: 24, torch.float16: 11, torch.bfloat16: 8}  # significand bits incl. the hidden one
+_NDEV = []
+
+
+def _device_count() -> int:
+    """torch.cuda.device_count(), asked once (it does not initialise the GPU): a one-GPU process never needs the device guard."""
+    if not _NDEV:
+        _NDEV.append(torch.cuda.device_count())
+    return _NDEV[0]
 
 
 class _LinearBase(nn.Linear):
@@ -106,8 +114,8 @@ class _LinearBase(nn.Linear):
         self._x_i8 = False
         self._fw_cache = {}
         fx, fw, K = self._fmt["x"], self._fmt["w"], self.in_features
-        if (self.a8_native and fx.kind == _lib.Q_MXINT and fx.width <= 8 and (fx.block <= 0 or fx.block >= K) and K >= 128
-                and (fw.block <= 0 or fw.block >= K or fw.block % 128 == 0)):
+        if (self.a8_native and fx.kind == _lib.Q_MXINT and fw.kind == _lib.Q_MXINT and fx.width <= 8 and (fx.block <= 0 or fx.block >= K)
+                and K >= 128 and (fw.block <= 0 or fw.block >= K or fw.block % 128 == 0)):
             # one activation exponent per token, weight blocks of 128 k or more (the W4A8 INT configurations): integer
             # accumulation is exact - the int8 MFMA route, if every weight row's sums provably stay inside i32
             ok, w2 = ops.i8_prepare(p["w"], self.out_features, K, fw)
@@ -121,7 +129,8 @@ class _LinearBase(nn.Linear):
                     ok16, a16 = ops.a_f16_image(w2, self.out_features, K, p["a_t"], 2, self.rank)
                     if ok16:
                         p["a_t_f16"] = a16
-        if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native):
+        if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native
+                and fw.kind == _lib.Q_MXINT):  # (integer weights - two's-complement nibbles - have no fp16 main loop: the limb route)
             ok, a16 = ops.f16_prepare(p["w"], self.out_features, self.in_features, p.get("a_t"), int(p.get("a_limbs", 0)), self.rank)
             if ok:
                 self._x_f16 = True
@@ -336,21 +345,30 @@ class _LinearBase(nn.Linear):
 
     # -- forward -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # (decode steps are host-bound through eager Python: this path is written for few interpreter operations - no
+        # decorator, no repeated nn.Module attribute look-ups; kernels are launched through ctypes, autograd never sees them)
+        g = self._group
+        if g is not None and x is g._dx:  # an open decode round of this Linear's group (q/k/v, gate/up) for this very tensor
+            y = g.take(self, x)
+            if y is not None:
+                return y
         if not self.is_ptq:
             raise NotImplementedError("lqer_amd implements the PTQ inference branch only (q_config['is_ptq'] = True)")
-        ops._need_gpu(x)
+        if not x.is_cuda:
+            raise RuntimeError("lqer_amd runs on the HIP device only: got a CPU tensor (there is no CPU fallback)")
         # the C ABI launches on the calling thread's current device: make x's device current for the call (a module on
         # cuda:1 under a single-process device map, reference experiments/infer_device_map.py:29-37)
-        if x.device.index != torch.cuda.current_device():
+        if _device_count() > 1 and x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):
                 return self._forward_on_current_device(x)
         return self._forward_on_current_device(x)
 
-    @torch.no_grad()
     def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
         if self._packed is not None and not self._packed_only:
             # (images of a packed checkpoint are the only copy of the operands: its dense parameters are never consulted)
-            cur = (self.weight._version, None if self.bias is None else self.bias._version)
+            prm = self._parameters
+            bias_p = prm["bias"]
+            cur = (prm["weight"]._version, None if bias_p is None else bias_p._version)
             if self._w_ver is None:  # first forward after copy.deepcopy / unpickling: the copied images belong to these parameters
                 self._w_ver = cur
             elif cur != self._w_ver:  # the dense parameters were written in place since their images were built
@@ -363,7 +381,7 @@ class _LinearBase(nn.Linear):
         K, N = self.in_features, self.out_features
         if x.shape[-1] != K:
             raise RuntimeError(f"expected last dim {K}, got {tuple(x.shape)}")
-        if self._fmt["x"].kind == _lib.Q_PASSTHROUGH and x.dtype != self.weight.dtype:
+        if self._fmt["x"].kind == _lib.Q_PASSTHROUGH and x.dtype != self._parameters["weight"].dtype:
             # the packed images hold one copy per bf16 limb of the module's dtype (F.linear raises here as well)
             raise RuntimeError(f"expected input dtype {self.weight.dtype} (pass-through x_quantizer), got {x.dtype}")
         x2 = x.reshape(-1, K)
@@ -374,7 +392,7 @@ class _LinearBase(nn.Linear):
             # decode sizes: the whole group (q/k/v, gate/up) in ONE launch; later members are handed the outputs it produced
             yg = self._group.decode_member(self, x, x2)
             if yg is not None:
-                return yg.reshape(*x.shape[:-1], N)
+                return yg  # (already [..., N])
         y = torch.empty(M, N, dtype=x.dtype, device=x.device)
         if M == 0 or (self._group is not None and self._group.forward_member(self, x, x2, y)):
             return y.reshape(*x.shape[:-1], N)
@@ -397,9 +415,10 @@ class _LinearBase(nn.Linear):
                                           a_limbs, p.get("b_limbs", 0), ops._ptr(p.get("bias"))))
         desc, ws_bytes, dt, consts = ent
         dref = C.byref(desc)
-        ws = ops.workspace(x.device, ws_bytes)
+        st = ops._stream(x.device)
+        ws = ops.workspace_on(x.device, st, ws_bytes)
         rc = _lib.lib().lqer_linear_forward(dref, x2.data_ptr(), dt, M, x2.stride(0) if M > 1 else K, *consts,
-                                            y.data_ptr(), N, ws.data_ptr(), ws.numel(), ops._stream(x.device))
+                                            y.data_ptr(), N, ws.data_ptr(), ws.numel(), st)
         if rc:
             check(rc, "lqer_linear_forward")
         return y.reshape(*x.shape[:-1], N)
@@ -459,8 +478,9 @@ class SharedActivation:
         self._dys = None      # outputs of the current round, one per member
         self._dserved = set()
         if self.enabled:
-            for m in self.members:
+            for i, m in enumerate(self.members):
                 m._group = self
+                m._gidx = i  # (its place in the group: the decode round's output table)
 
     def invalidate(self):
         self._cat, self._x, self._cur, self._served = None, None, None, set()
@@ -504,7 +524,21 @@ class SharedActivation:
             if ok16:
                 self._cat["a_t_f16"] = a16
 
-    @torch.no_grad()
+    def take(self, mod, x):
+        """A member comes with the tensor of the open decode round: its output, once, if the tensor is unmodified."""
+        ys = self._dys
+        if ys is None or (None if x.is_inference() else x._version) != self._dver:
+            return None
+        idx = mod._gidx
+        served = self._dserved
+        if idx in served:
+            return None
+        served.add(idx)
+        y = ys[idx]
+        if len(served) == len(ys):
+            self._dx, self._dys = None, None  # every member served: do not pin the tensors until the next round
+        return y
+
     def decode_member(self, mod, x, x2):
         """Up to 8 tokens: every member's forward in ONE launch (lqer_linear_forward_group: the producers multiply x with the
         concatenated A, each member's weight-streaming workgroups read their rank columns - per member the bits of its own
@@ -514,13 +548,7 @@ class SharedActivation:
         if not self.enabled:
             return None
         ver = None if x.is_inference() else x._version
-        idx = self.members.index(mod)
-        if x is self._dx and ver == self._dver and self._dys is not None and idx not in self._dserved:
-            self._dserved.add(idx)
-            y = self._dys[idx]
-            if len(self._dserved) == len(self.members):
-                self._dx, self._dys = None, None  # every member served: do not pin the tensors until the next round
-            return y
+        idx = mod._gidx
         M, K = x2.shape
         dtc = ops.dtype_code(x2)
         plan = self._dplans.get((M, dtc), False)
@@ -557,15 +585,16 @@ class SharedActivation:
         if x2.stride(0) < K or (x2.data_ptr() & 15) or (x2.stride(0) * x2.element_size()) % 16:
             return None
         Ns = plan["Ns"]
-        buf = torch.empty(M * sum(Ns), dtype=x.dtype, device=dev)
-        ys, off, tab = [], 0, plan["tab"]
+        buf = torch.empty(M * sum(Ns), dtype=x.dtype, device=dev)  # one allocation: every member's [M, N_i] lies dense in it
+        ys, off, tab, base, esz, lead = [], 0, plan["tab"], buf.data_ptr(), buf.element_size(), x.shape[:-1]
         for i, N in enumerate(Ns):
-            ys.append(buf[off: off + M * N].view(M, N))
-            tab[i].y = ys[-1].data_ptr()
+            ys.append(buf[off: off + M * N].view(*lead, N))
+            tab[i].y = base + off * esz
             off += M * N
-        ws = ops.workspace(dev, plan["ws"])
+        st = ops._stream(dev)
+        ws = ops.workspace_on(dev, st, plan["ws"])
         rc = L.lqer_linear_forward_group(tab, plan["n"], x2.data_ptr(), dtc, M, x2.stride(0) if M > 1 else K, plan["a_t"], 1,
-                                         ws.data_ptr(), ws.numel(), ops._stream(dev))
+                                         ws.data_ptr(), ws.numel(), st)
         if rc == -2:  # LQER_E_UNSUPPORTED (nothing was launched): this token count / shape stays on the per-member route
             self._dplans[(M, dtc)] = None
             return None

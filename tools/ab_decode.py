@@ -63,9 +63,21 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[q].append(e0.elapsed_time(e1) / a.iters * 1e3)
+    # host cost of one call (the loop above is GPU-bound only while this stays under the kernel's duration): wall time of a burst
+    # of calls that are all queued before the first kernel can have finished much
+    import time
+
+    host = {}
+    for q, L in libs:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(64):
+            call(q, L)
+        host[q] = (time.perf_counter() - t0) / 64 * 1e6
+        torch.cuda.synchronize()
     for q, _ in libs:
         t = sorted(times[q])
-        print(f"{os.path.basename(q):28s} M={M} K={K} N={N}: median {t[len(t) // 2]:7.2f} us  min {t[0]:7.2f} us per forward")
+        print(f"{q:40s} M={M} K={K} N={N}: median {t[len(t) // 2]:7.2f} us  min {t[0]:7.2f} us per forward   host {host[q]:5.2f} us per call")
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@ import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lqer_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+_probe = C.CDLL(_lib.LIB_PATH)  # (an older build of the library: bind only the entry points it has)
+_lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(_probe, k)}
 import lqer_amd
 from lqer_amd import ops
 from bench import make_case, MXINT_Q
