@@ -340,13 +340,19 @@ int lqer_replicate_rows(const void* src, void* dst, int64_t rows, int64_t row_by
 /* ---- quantized attention products (reference quantized_functions/matmul.py:12-37: matmul_flexible / bmm_flexible; call
  * sites models/llama_decoder.py:263,294, opt_decoder.py:125,190) -------------------------------------------------------
  *     out[b] = x_quantizer(x[b]) @ w_quantizer(y[b]),   b < batch;  x[b]: [S1, K], y[b]: [K, S2], out[b]: [S1, S2] (dense)
- * Both quantizers block_fp with blocks of 16 along the LAST dim of their operand (width <= 8) - for y that is the
- * output dim j, not the contraction dim (llama-7b.toml:110-126).  x is quantized in the GEMM's load path (read from HBM
+ * Both quantizers block_fp with blocks along the LAST dim of their operand (width <= 8; blocks of 16 - the templates' - run fused,
+ * other lengths see lqer_matmul_q_workspace_bytes_fmt) - for y that is the output dim j, not the contraction dim (llama-7b.toml:110-126).  x is quantized in the GEMM's load path (read from HBM
  * once, no quantized copy); y goes through a bf16 image [batch][S2 padded to 128][K padded to 64] in `workspace`
  * (lqer_matmul_q_workspace_bytes).  Element strides: x[b][i][k] at b x_bs + i x_rs + k (k contiguous);
  * y[b][k][j] at b y_bs + k y_ks + j y_js with y_ks == 1 or y_js == 1 (Q K^T hands over the transposed VIEW of K: y_ks == 1).
  * fp32 accumulation of exact products (every 8-bit MXINT value is a bf16 number); out has the element type `dtype` of x, y. */
 size_t lqer_matmul_q_workspace_bytes(int64_t batch, int64_t K, int64_t S2);
+/* Blocks other than 16 (16 n elements, or whole rows: quantized_functions/matmul.py:12-29 takes any block_size): the library's
+ * standalone quantizer writes that operand's bf16 image into the workspace first and the image / product kernels take it as
+ * it is - same bits, one more pass over the operand.  Such an operand needs evenly spaced rows over the batch (x_bs == S1
+ * x_rs; y dense along j with y_bs == K y_ks); the workspace then also holds those images: */
+size_t lqer_matmul_q_workspace_bytes_fmt(int64_t batch, int64_t S1, int64_t K, int64_t S2, const lqer_qfmt_t* x_fmt,
+                                         const lqer_qfmt_t* y_fmt);
 int lqer_matmul_q(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2,
                   int64_t x_bs, int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const lqer_qfmt_t* x_fmt,
                   const lqer_qfmt_t* y_fmt, void* workspace, size_t workspace_bytes, void* stream);

@@ -41,10 +41,13 @@ static bool fmt_ok(const lqer_qfmt_t* f, const char* name, int max_width) {
   }
   if (f->kind == LQER_Q_INT) {  // fixed point: exp_bias = frac_width, exp_width = is_signed
     const bool role_ok = !strcmp(name, "x_quantizer") || !strcmp(name, "b_quantizer") || !strcmp(name, "A_out_quantizer") ||
-                         !strcmp(name, "B_out_quantizer") || !strcmp(name, "quantize_mxint");
+                         !strcmp(name, "B_out_quantizer") || !strcmp(name, "quantize_mxint") || !strcmp(name, "w_quantizer");
     if (!role_ok) {
-      set_error("%s: the integer quantizer is implemented for x, b, A_out and B_out (a 4-bit integer weight has the code -8, which "
-                "the sign-magnitude weight image cannot hold)", name);
+      set_error("%s: the integer quantizer is not implemented in this role", name);
+      return false;
+    }
+    if (!strcmp(name, "w_quantizer") && !f->exp_width) {  // codes travel as two's-complement nibbles: signed, 2..4 bits
+      set_error("w_quantizer: an unsigned integer weight is not implemented (4-bit codes 0..15 do not fit the two's-complement nibble)");
       return false;
     }
     const int maxw = f->exp_width ? max_width : max_width - 1;  // unsigned: one magnitude bit more per width
@@ -114,6 +117,7 @@ static bool f16_image_is_input(const lqer_linear_desc_t* d, const void* x, int64
 // (lqer_quantize_act_xa / lqer_linear_gemm with xaq == NULL), one launch less on a launch-bound path.
 static bool decode_partials_ok(const lqer_linear_desc_t* d, int64_t M) {
   if (!d || d->rank <= 0 || M <= 0 || M > 64) return false;
+  if (d->w_fmt.kind != LQER_Q_MXINT) return false;  // (integer weights: two's-complement nibbles - the tile kernel at every M)
   if (d->x_fmt.kind != LQER_Q_MXINT || d->a_out_fmt.kind != LQER_Q_MXINT) return false;
   if (!xa_fused_partials_ok(make_qp(d->x_fmt), make_qp(d->a_out_fmt), d->rank)) return false;
   const lqer_qfmt_t& bo = d->b_out_fmt;  // the small-M kernel: B_out pass-through or blocks of 16
@@ -292,8 +296,8 @@ int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64
     return LQER_E_INVALID;
   }
   if (!fmt_ok(fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
-  if (fmt->kind != LQER_Q_MXINT) {
-    set_error("w_quantizer: only block_fp weights can be packed");
+  if (fmt->kind != LQER_Q_MXINT && fmt->kind != LQER_Q_INT) {
+    set_error("w_quantizer: only block_fp and integer weights can be packed");
     return LQER_E_UNSUPPORTED;
   }
   return pack_weight_dispatch(W, dtype, N, K, ldw, make_qp(*fmt), 1, w_packed, scratch, (hipStream_t)stream);
@@ -319,7 +323,7 @@ int lqer_unpack_weight_mxint(const void* w_packed, int64_t N, int64_t K, const l
     set_error("unpack_weight: bad argument");
     return LQER_E_INVALID;
   }
-  return unpack_weight_dispatch(w_packed, N, K, fmt->width - 1, w_f32, (hipStream_t)stream);
+  return unpack_weight_dispatch(w_packed, N, K, fmt->width - 1, fmt->kind == LQER_Q_INT, w_f32, (hipStream_t)stream);
 }
 
 int lqer_pack_lowrank(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r, void* a_t, void* b_t,
@@ -445,6 +449,7 @@ static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, Ge
   g.rp = (int)lqer_padded_r(d->rank) * al;
   g.w_mbits = d->w_fmt.width - 1;
   g.tuning = d->tuning;
+  g.w_twos = d->w_fmt.kind == LQER_Q_INT ? 1 : 0;
   if (lowrank) g.bout = make_qp(d->b_out_fmt);
   if (x_is_i8(d)) {
     if (!i8_formats_ok(d)) return LQER_E_UNSUPPORTED;
@@ -668,6 +673,11 @@ size_t lqer_matmul_q_workspace_bytes(int64_t batch, int64_t K, int64_t S2) {
   return (batch > 0 && K > 0 && S2 > 0) ? qmatmul_workspace_bytes(batch, K, S2) : 0;
 }
 
+size_t lqer_matmul_q_workspace_bytes_fmt(int64_t batch, int64_t S1, int64_t K, int64_t S2, const lqer_qfmt_t* x_fmt, const lqer_qfmt_t* y_fmt) {
+  if (batch <= 0 || K <= 0 || S2 <= 0 || S1 < 0 || !x_fmt || !y_fmt) return 0;
+  return qmatmul_workspace_bytes_ex(batch, S1, K, S2, x_fmt->block != 16, y_fmt->block != 16);
+}
+
 int lqer_matmul_q(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs,
                   int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const lqer_qfmt_t* x_fmt, const lqer_qfmt_t* y_fmt,
                   void* workspace, size_t workspace_bytes, void* stream) {
@@ -681,9 +691,10 @@ int lqer_matmul_q(const void* x, const void* y, void* out, int dtype, int64_t ba
     return LQER_E_INVALID;
   }
   if (!fmt_ok(x_fmt, "matmul x_quantizer", 8) || !fmt_ok(y_fmt, "matmul w_quantizer", 8)) return LQER_E_UNSUPPORTED;
-  if (x_fmt->kind != LQER_Q_MXINT || y_fmt->kind != LQER_Q_MXINT || x_fmt->block != 16 || y_fmt->block != 16) {
-    set_error("matmul_q: both quantizers must be block_fp with blocks of 16 along the last dim (got kinds %d / %d, blocks %d / %d)",
-              x_fmt->kind, y_fmt->kind, x_fmt->block, y_fmt->block);
+  auto blk_ok = [](const lqer_qfmt_t* f, int64_t cols) { return f->block <= 0 || f->block >= cols || f->block % 16 == 0; };
+  if (x_fmt->kind != LQER_Q_MXINT || y_fmt->kind != LQER_Q_MXINT || !blk_ok(x_fmt, K) || !blk_ok(y_fmt, S2)) {
+    set_error("matmul_q: both quantizers must be block_fp with blocks of 16 n elements, or whole rows, along the last dim (got kinds %d / %d, "
+              "blocks %d / %d)", x_fmt->kind, y_fmt->kind, x_fmt->block, y_fmt->block);
     return LQER_E_UNSUPPORTED;
   }
   if (x_rs < K || (y_ks != 1 && y_js != 1)) {
@@ -691,8 +702,17 @@ int lqer_matmul_q(const void* x, const void* y, void* out, int dtype, int64_t ba
               (long long)x_rs, (long long)y_ks, (long long)y_js);
     return LQER_E_INVALID;
   }
-  if (workspace_bytes < qmatmul_workspace_bytes(batch, K, S2)) {
-    set_error("matmul_q: workspace %zu B < %zu B", workspace_bytes, qmatmul_workspace_bytes(batch, K, S2));
+  // blocks other than 16: the standalone quantizer writes the operand's bf16 image first - rows evenly spaced over the batch,
+  // y dense along j (its blocks' dim)
+  const bool x_pre = x_fmt->block != 16, y_pre = y_fmt->block != 16;
+  if ((x_pre && batch > 1 && x_bs != S1 * x_rs) || (y_pre && (y_js != 1 || (batch > 1 && y_bs != K * y_ks)))) {
+    set_error("matmul_q: operands with blocks other than 16 must have evenly spaced rows over the batch (x_bs == S1 x_rs; y dense along j with "
+              "y_bs == K y_ks)");
+    return LQER_E_INVALID;
+  }
+  if (workspace_bytes < qmatmul_workspace_bytes_ex(batch, S1, K, S2, x_pre, y_pre)) {
+    set_error("matmul_q: workspace %zu B < %zu B (lqer_matmul_q_workspace_bytes_fmt)", workspace_bytes,
+              qmatmul_workspace_bytes_ex(batch, S1, K, S2, x_pre, y_pre));
     return LQER_E_WORKSPACE;
   }
   return qmatmul_dispatch(x, y, out, dtype, batch, S1, K, S2, x_bs, x_rs, y_bs, y_ks, y_js, make_qp(*x_fmt), make_qp(*y_fmt), workspace,

@@ -314,6 +314,28 @@ __device__ __forceinline__ bf16x8 expand_frag(uint32_t word, uint32_t scale_bits
 }
 
 
+// Two's-complement nibbles (the `integer` weight quantizer: codes -8 .. 7, reference quantizers/integer.py:37-40): the e4m3 byte
+// comes from one of two 8-entry tables indexed by the low three bits - values 0..7, or -8..-1 with the sign baked in - chosen per
+// byte by a mask of the nibbles' sign bits (v_perm_b32's sign selectors: 0x00 / 0xFF per odd byte of its sources).  20 vector
+// instructions per 8 weights instead of 14; every step exact.
+__device__ __forceinline__ bf16x8 expand_frag_twos(uint32_t word, uint32_t scale_bits) {
+  const float scale = __uint_as_float(scale_bits);
+  constexpr uint32_t LUT_LO = 0x44403800u, LUT_HI = 0x4E4C4A48u;    // e4m3 of 0,1,2,3 | 4,5,6,7
+  constexpr uint32_t LUTN_LO = 0xCACCCED0u, LUTN_HI = 0xB8C0C4C8u;  // e4m3 of -8,-7,-6,-5 | -4,-3,-2,-1
+  const uint32_t ie = word & 0x07070707u, io = (word >> 4) & 0x07070707u, t = word << 4;
+  const uint32_t me = __builtin_amdgcn_perm(t, word << 12, 0x0B090A08u);    // low nibbles (k 0..3): 0xFF where negative
+  const uint32_t mo = __builtin_amdgcn_perm(word, word << 8, 0x0B090A08u);  // high nibbles (k 4..7)
+  const uint32_t pe = __builtin_amdgcn_perm(LUT_HI, LUT_LO, ie), ne = __builtin_amdgcn_perm(LUTN_HI, LUTN_LO, ie);
+  const uint32_t po = __builtin_amdgcn_perm(LUT_HI, LUT_LO, io), no = __builtin_amdgcn_perm(LUTN_HI, LUTN_LO, io);
+  const uint32_t fe = (me & ne) | (~me & pe), fo = (mo & no) | (~mo & po);
+  u32x4 r;
+  r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, false));
+  r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fe, scale, true));
+  r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, false));
+  r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(fo, scale, true));
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 // The same with fp16 results (v_cvt_scalef32_pk_f16_fp8): exact while code * 2^scale stays inside the fp16 range,
 // subnormals included (checked once per weight image, pack.hip::weight_f16_ok).
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -428,13 +450,14 @@ struct GemmArgs {
   const float* xscale;  // [Mp] row scales 2^(e - mbits) of the int8 activation image
   int i8_shift;         // some weight group carries a non-zero shift (blocks of 128 with differing exponents)
   int tuning;           // lqer_linear_desc_t.tuning of the call (LQER_TUNE_*: kernel-variant knobs of tests, same bits)
+  int w_twos;           // the packed weight holds two's-complement nibbles (w_quantizer = integer): the 128-row tile kernel only
 };
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
                       const QuantOut& o, hipStream_t st);
 int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, int64_t block_rows, void* out,
                          void* scratch, hipStream_t st);
-int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, float* out, hipStream_t st);
+int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, bool twos, float* out, hipStream_t st);
 int pack_lowrank_dispatch(const void* A, const void* B, int dtype, int64_t K, int64_t N, int64_t r, void* a_t,
                           void* b_t, int32_t* flags, hipStream_t st);
 int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, hipStream_t st);
@@ -476,6 +499,7 @@ int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, c
                      const DecodeMember* mem, int nmem, void* scratch, size_t scratch_bytes, hipStream_t st);
 
 size_t qmatmul_workspace_bytes(int64_t batch, int64_t K, int64_t S2);  // matmul_q.hip
+size_t qmatmul_workspace_bytes_ex(int64_t batch, int64_t S1, int64_t K, int64_t S2, bool x_pre, bool y_pre);
 int qmatmul_dispatch(const void* x, const void* y, void* out, int dtype, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs,
                      int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const QP& qx, const QP& qy, void* workspace, hipStream_t st);
 

@@ -130,9 +130,13 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 // operands go through LDS (below) - a separate instantiation, so that the direct route keeps its own register allocation.
 // MT: 32-row tiles per wave = tile height / 32.  4: the 128 x 256 tile.  2: a 64 x 256 tile for token counts whose 128-row
 // grid leaves most of the chip idle (half the MFMA work per expanded weight fragment, twice the workgroups).
-template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4>
+// WTWOS: the packed weight holds two's-complement nibbles (w_quantizer = integer, codes -8 .. 7): the second expand of common.h
+// (128-row tiles, staged side path and 16-bit / fp32 tensors only: a format no template configuration uses gets a working
+// kernel, not a tuned one).
+template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4, bool WTWOS = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   static_assert(MT == 4 || MT == 2, "128- or 64-row tiles");
+  static_assert(!WTWOS || DT != LQER_F16X, "integer weights: no fp16 main loop");
   constexpr int BMk = 32 * MT;   // tile rows
   constexpr int AP = MT / 2;     // 8-row LDS-DMA pieces of the activation tile per wave and k-step
   constexpr bool XF16 = DT == LQER_F16X;  // fp16 activation image, weights expanded to fp16, v_mfma_f32_32x32x16_f16
@@ -478,7 +482,11 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
           : "memory", "scc");
     }
     STAMP(1);  // LDS reads + DMA issue + waits
-    bf16x8 wb_first = expand_frag_t<XF16>(wr[0], (we & 0xffu) << 23);
+    auto expand = [](uint32_t word, uint32_t scale_bits) {
+      if constexpr (WTWOS) return expand_frag_twos(word, scale_bits);
+      else return expand_frag_t<XF16>(word, scale_bits);
+    };
+    bf16x8 wb_first = expand(wr[0], (we & 0xffu) << 23);
     asm volatile("s_barrier" : "+v"(wb_first)::"memory");
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     for (int ks = 0; ks < 4; ++ks) {
       // biased exponent byte ks -> fp32 bits of the block scale 2^(e - mbits)
       const uint32_t sc = ((we >> (8 * ks)) & 0xffu) << 23;
-      const bf16x8 wb = ks == 0 ? wb_first : expand_frag_t<XF16>(wr[ks], sc);
+      const bf16x8 wb = ks == 0 ? wb_first : expand(wr[ks], sc);
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i] = mfma_32x32x16<XF16>(wb, xa[ks][i], acc[i]);
     }
@@ -846,6 +854,25 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
 #define LQER_STAGE_MIN 32
 #endif
   const bool staged = lowrank && g.rp * g.b_limbs > LQER_STAGE_MIN;  // more than two 16-deep slices of side product
+  if (g.w_twos) {  // integer weights: one instantiation per (element type, side path, B_out) - 128-row tiles, staged side path
+    if constexpr (DT == LQER_F16X) {
+      set_error("linear_gemm: integer weights have no fp16 main loop (pass-through fp16 activations take the limb route)");
+      return LQER_E_UNSUPPORTED;
+    } else {
+#define LQER_GEMM_LAUNCH_TWOS(LR, BO, ST)                                                                       \
+  do {                                                                                                          \
+    static LdsLimitOnce lds_once;                                                                               \
+    lds_once.set((const void*)k_lqer_gemm<DT, LR, BO, ST, 4, true>, gemm_lds_bytes(4));                         \
+    k_lqer_gemm<DT, LR, BO, ST, 4, true><<<grid, 512, gemm_lds_bytes(4), st>>>(g);                              \
+  } while (0)
+      if (!lowrank) LQER_GEMM_LAUNCH_TWOS(false, 0, false);
+      else if (bout == 1) LQER_GEMM_LAUNCH_TWOS(true, 1, true);
+      else if (bout == 2) LQER_GEMM_LAUNCH_TWOS(true, 2, true);
+      else LQER_GEMM_LAUNCH_TWOS(true, 0, true);
+#undef LQER_GEMM_LAUNCH_TWOS
+      return check_launch("lqer_gemm");
+    }
+  }
 #define LQER_GEMM_LAUNCH_H64(LR, BO, ST)                                                                        \
   do {                                                                                                          \
     static LdsLimitOnce lds_once;                                                                               \
@@ -923,6 +950,7 @@ int gemm_route(const GemmArgs& g, bool lowrank) {
     t.w8 = nullptr;
     return gemm_route(t, lowrank);
   }
+  if (g.w_twos) return LQER_ROUTE_TILE128;  // integer weights (two's-complement nibbles): the 128-row tile kernel at every M
   if (smallm_eligible(g, bout)) return LQER_ROUTE_SMALLM;
   if (m256_eligible(g)) return LQER_ROUTE_TILE256;
   return LQER_ROUTE_TILE128;
@@ -995,8 +1023,10 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
     }
     return i8_dispatch(g, dtype, lowrank, bout, st);
   }
-  if (smallm_eligible(g, bout)) return smallm_dispatch(g, dtype, lowrank, bout, st);  // decode sizes: HBM-bound variant
-  if (m256_eligible(g)) return m256_dispatch(g, dtype, lowrank, bout, st);            // large M: 256 x 256 tiles
+  if (!g.w_twos) {
+    if (smallm_eligible(g, bout)) return smallm_dispatch(g, dtype, lowrank, bout, st);  // decode sizes: HBM-bound variant
+    if (m256_eligible(g)) return m256_dispatch(g, dtype, lowrank, bout, st);            // large M: 256 x 256 tiles
+  }
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
   g.tiles_m_rows = BM;
@@ -1007,7 +1037,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
     constexpr int CUS = 256;
     const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;
     const int pin = (g.tuning & LQER_TUNE_TILE_ROWS_128) ? 128 : ((g.tuning & LQER_TUNE_TILE_ROWS_64) ? 64 : 0);  // (tests)
-    if ((pin != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) || (pin == 64 && g.M > 64)) {
+    if (!g.w_twos && ((pin != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) || (pin == 64 && g.M > 64))) {
       g.tiles_m = (g.M + 63) / 64;
       g.tiles_m_rows = 64;
     }

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int6
         for (int i = 0; i < 16; ++i) {
           const float w = (k0 + i < K) ? load_elem<DT>(W, row * ld + k0 + i) : 0.0f;
           const int mi = (int)mxint_mantissa(w, e, q);
-          const uint32_t c = (uint32_t)(mi < 0 ? (8 - mi) : mi);  // sign-magnitude, +0 canonical
+          // sign-magnitude, +0 canonical; the `integer` quantizer's codes -2^(w-1) .. 2^(w-1)-1 (quantizers/integer.py:37-40) do
+          // not fit that - they travel as two's-complement nibbles (GemmArgs.w_twos: the tile kernel's second expand)
+          const uint32_t c = q.kind == LQER_Q_INT ? ((uint32_t)mi & 0xfu) : (uint32_t)(mi < 0 ? (8 - mi) : mi);
           const int j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
           if (i < 8)
             lo |= c << (4 * pos);
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int6
 }
 
 __global__ __launch_bounds__(256) void k_w_unpack(const uint8_t* __restrict__ in, int64_t N, int64_t K, int64_t Kp,
-                                                  int mbits, float* __restrict__ out) {
+                                                  int mbits, bool twos, float* __restrict__ out) {
   const int64_t segs = Kp / 16;
   const int64_t total = N * segs;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void k_w_unpack(const uint8_t* __restrict__ in
       const uint32_t word = i < 8 ? c.x : c.y;
       const int j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
       const uint32_t nib = (word >> (4 * pos)) & 0xfu;
-      const int v = (nib & 8u) ? -(int)(nib & 7u) : (int)nib;
+      const int v = twos ? ((int)nib >= 8 ? (int)nib - 16 : (int)nib) : ((nib & 8u) ? -(int)(nib & 7u) : (int)nib);
       if (k0 + i < K) out[row * K + k0 + i] = ldexpf((float)v, e - mbits);
     }
   }
@@ -158,8 +160,8 @@ static int pack_w(const void* W, int64_t N, int64_t K, int64_t ld, const QP& q, 
 
 int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, int64_t block_rows, void* out,
                          void* scratch, hipStream_t st) {
-  if (q.mbits < 1 || q.mbits > 3) {
-    set_error("packed weights hold 4-bit codes: w_quantizer width must be 2..4, got %d", q.mbits + 1);
+  if (q.width < 2 || q.width > 4) {
+    set_error("packed weights hold 4-bit codes: w_quantizer width must be 2..4, got %d", q.width);
     return LQER_E_UNSUPPORTED;
   }
   if (!(q.block <= 0 || q.block >= K || q.block % 16 == 0)) {
@@ -175,12 +177,12 @@ int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t
   return LQER_E_INVALID;
 }
 
-int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, float* out, hipStream_t st) {
+int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, bool twos, float* out, hipStream_t st) {
   const int64_t Kp = lqer_padded_k(K);
   const int64_t total = N * (Kp / 16);
   if (total == 0) return LQER_OK;
   const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-  k_w_unpack<<<grid, 256, 0, st>>>((const uint8_t*)in, N, K, Kp, mbits, out);
+  k_w_unpack<<<grid, 256, 0, st>>>((const uint8_t*)in, N, K, Kp, mbits, twos, out);
   return check_launch("unpack_weight");
 }
 

@@ -58,7 +58,8 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
     routine (quantizers/utils.py:42-67, :261-284).  The HIP path implements blocks that run along the last dim within
     one row: [1, L], or a one-entry [L] / [-1] where the reference reads it per row (activations and weights with
     skip_first_dim = true - the default, block_fp.py:111-118 - and the bias), and for the WEIGHT also 2-D tiles [R, L]
-    (skip_first_dim = false; a lone [L] then means all rows x L).  Anything else raises instead of being silently read per row."""
+    (skip_first_dim = false; a lone [L] then means all rows x L).  Anything else raises instead of being silently read per row.
+    An `integer` WEIGHT (fixed point, signed, width 2..4) is packed as two's-complement nibbles and runs the 128-row tile kernel."""
     if cfg is None:
         raise KeyError("quantizer config missing")
     name = cfg["name"]
@@ -66,11 +67,10 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
         return QFmt(_lib.Q_PASSTHROUGH, 0, 0, 8, 127)
     if name == "integer":
         # fixed point (reference quantizers/integer.py:10-43): clamp(rne(x 2^frac_width), lo, hi) / 2^frac_width
-        if role == "w":
-            raise NotImplementedError(
-                "the integer quantizer is not implemented for the weight on the HIP path: a 4-bit integer weight has the code -8, "
-                "which the sign-magnitude weight image cannot hold (no template configuration uses a fixed-point weight)")
         signed = bool(cfg.get("is_signed", True))
+        if role == "w" and (not signed or not 2 <= int(cfg["width"]) <= 4):
+            # (codes -2^(w-1) .. 2^(w-1)-1 travel as two's-complement nibbles of the packed image: signed, 2..4 bits)
+            raise NotImplementedError("an integer weight quantizer must be signed with width 2..4 on the HIP path (4-bit packed image)")
         return QFmt(_lib.Q_INT, int(cfg["width"]), -1, 1 if signed else 0, int(cfg["frac_width"]))
     if name != "block_fp":
         raise NotImplementedError(f"quantizer '{name}' is not implemented on the HIP path (block_fp, integer, passthrough)")
@@ -321,6 +321,16 @@ def pack_bias(bias: torch.Tensor, fmt: QFmt) -> torch.Tensor:
 
 # grow-only per-(device, stream) scratch shared by every Linear (stream-ordered reuse is safe)
 _workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def workspace_on(dev: torch.device, stream: int, nbytes: int) -> torch.Tensor:
+    """workspace() for a caller that already holds the stream handle (one torch.cuda.current_stream() less per forward)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws
 
 
 def workspace(dev: torch.device, nbytes: int) -> torch.Tensor:

@@ -208,6 +208,9 @@ def main():
         # 2-D weight tiles (round 3)
         ("tile8", (7, 176), 176, 160, 32, True, dict(mxint_q, w_quantizer=bfp_cfg(4, [8, 16], False)), abq, False),
         ("tileall", (70, 128), 128, 96, 16, False, dict(mxint_q, w_quantizer=bfp_cfg(4, [32], False)), abq, False),
+        # fixed-point WEIGHTS (round 4): 4-bit `integer`, frac_width 7 - sigma 0.02 is 2.56 steps, both clamps (-8, +7) occur
+        ("intw", (12, 192), 192, 112, 32, True, dict(mxint_q, w_quantizer=dict(name="integer", width=4, frac_width=7)), abq, False),
+        ("intxw", (2, 35, 128), 128, 160, 16, False, dict(intx5_q, w_quantizer=dict(name="integer", width=4, frac_width=7)), None, True),
     ]
     f = {}
     for name, xs, K, N, r, has_b, qc, abc, use_s in cases:

