@@ -115,10 +115,22 @@ __device__ __forceinline__ void quant16_bf16(const float (&v)[16], const QP& q, 
   }
 }
 
+// PRE: the values are ALREADY the quantizer's outputs (the standalone quantizer ran over the operand: block lengths other than
+// 16 - 16 n or whole rows - of formats whose values are bf16 numbers, width <= 9): the bf16 image is their high halves
+template <bool PRE, bool FLUSH_TINY>
+__device__ __forceinline__ void image16(const float (&v)[16], const QP& q, uint32_t (&w)[8]) {
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = exact_bf16_bits(v[2 * i]) | (exact_bf16_bits(v[2 * i + 1]) << 16);
+  } else {
+    quant16_bf16<FLUSH_TINY>(v, q, w);
+  }
+}
+
 // ---- y [b][k][j], j contiguous -> img [b][S2p][Kp] (blocks of 16 along j), transposed through LDS -------------------------
 // One workgroup = 64 k x 64 j.  Thread t quantizes the block (k = t / 4, j = 16 (t % 4) ..): four threads read 128 B of a
 // k row; the bf16 values go to an LDS tile [j][k] and leave as 32-byte pieces of the image's j rows.
-template <int DT>
+template <int DT, bool PRE = false>  // PRE: y is the bf16 image of the standalone quantizer (DT = LQER_BF16): transposed only
 __global__ __launch_bounds__(256) void k_qmm_bimage_j(const void* __restrict__ y, int64_t K, int64_t S2, int64_t y_bs, int64_t y_ks, QP q,
                                                       bf16_t* __restrict__ img, int64_t S2p, int64_t Kp, bool vec) {
   __shared__ bf16_t tile[64][64 + 2];  // (+2: the 16 two-byte stores of a thread walk 16 rows - spread them over banks)
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256) void k_qmm_bimage_j(const void* __restrict__ y
     uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (k < K && j < S2) {
       load16<DT>(y, b * y_bs + k * y_ks + j, S2 - j, vec, v);
-      quant16_bf16<DT != LQER_F16>(v, q, w);
+      image16<PRE, DT != LQER_F16>(v, q, w);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -214,10 +226,13 @@ __global__ __launch_bounds__(256) void k_qmm_bimage_k(const void* __restrict__ y
 // NW = 8 (with PF): the same tile on 512 threads, waves as 2 x 4, each 64 x 32 - one activation block and two image pieces
 // per thread and chunk, half the accumulators and prefetch registers per thread: twice the waves per CU hide the latencies
 // of a loop that alternates vector work (the quantizer), barriers and MFMAs (P V: 131 -> ? us).
-template <int DT, bool PF, int NW = 4>
+// XPRE (without PF): x is the bf16 image of the standalone quantizer (block lengths other than 16): copied into the slab as it is.
+template <int DT, bool PF, int NW = 4, bool XPRE = false>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_qmatmul(const void* __restrict__ x, const bf16_t* __restrict__ img, void* __restrict__ out,
                                                  int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs, int64_t S2p, int64_t Kp,
                                                  QP q, bool vec) {
+  static_assert(!(XPRE && PF), "pre-quantized x: the plain loop only");
+  constexpr int XDT = XPRE ? LQER_BF16 : DT;  // element type of x as it is read
   __shared__ __attribute__((aligned(16))) unsigned char smem[BM * BK * 2 + BN * BK * 2];
   unsigned char* const sa = smem;                // x tile, quantized: 128 rows x 128 B
   unsigned char* const sb = smem + BM * BK * 2;  // image tile (after the loop the 32 KiB hold the 16-bit output tile)
@@ -330,30 +345,30 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_qmatmul(const void
   } else {
   // this thread's two blocks of the x tile (rows tid / 4 and 64 + tid / 4, block tid % 4) and four 16-byte pieces of the image tile
   float xv[2][16];
-  uint4 bv[4];
+  uint4 bv0, bv1, bv2, bv3;  // (named, not an array: indexed under the conditional prefetch it ended up in scratch memory - 80 B per lane)
   auto fetch = [&](int kc) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int row = (tid >> 2) + 64 * u;
       const int64_t i = i0 + row, k = (int64_t)kc * BK + (tid & 3) * 16;
       if (i < S1 && k < K) {
-        load16<DT>(x, b * x_bs + i * x_rs + k, K - k, vec, xv[u]);
+        load16<XDT>(x, b * x_bs + i * x_rs + k, K - k, vec, xv[u]);
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) xv[u][e] = 0.f;
       }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    auto piece = [&](int u) {
       const int p = tid + 256 * u, row = p >> 3, ch = p & 7;
-      bv[u] = *(const uint4*)(ib + (int64_t)row * Kp + (int64_t)kc * BK + ch * 8);  // (rows up to S2p exist, zero beyond S2)
-    }
+      return *(const uint4*)(ib + (int64_t)row * Kp + (int64_t)kc * BK + ch * 8);  // (rows up to S2p exist, zero beyond S2)
+    };
+    bv0 = piece(0), bv1 = piece(1), bv2 = piece(2), bv3 = piece(3);
   };
   fetch(0);
   for (int kc = 0; kc < nkc; ++kc) {
     uint32_t w[2][8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) quant16_bf16<DT != LQER_F16>(xv[u], q, w[u]);
+    for (int u = 0; u < 2; ++u) image16<XPRE, DT != LQER_F16>(xv[u], q, w[u]);
     __syncthreads();  // the previous chunk's fragment reads are done
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -361,10 +376,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void k_qmatmul(const void
       *(uint4*)(sa + swz(row, c)) = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
       *(uint4*)(sa + swz(row, c + 1)) = make_uint4(w[u][4], w[u][5], w[u][6], w[u][7]);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = tid + 256 * u;
-      *(uint4*)(sb + swz(p >> 3, p & 7)) = bv[u];
+    {
+      auto put = [&](int u, const uint4& v) {
+        const int p = tid + 256 * u;
+        *(uint4*)(sb + swz(p >> 3, p & 7)) = v;
+      };
+      put(0, bv0), put(1, bv1), put(2, bv2), put(3, bv3);
     }
     __syncthreads();
     if (kc + 1 < nkc) fetch(kc + 1);  // the next chunk's loads travel under this chunk's MFMAs
@@ -637,6 +654,15 @@ size_t qmatmul_workspace_bytes(int64_t batch, int64_t K, int64_t S2) {
   const int64_t S2p = (S2 + qmm::BN - 1) / qmm::BN * qmm::BN, Kp = (K + qmm::BK - 1) / qmm::BK * qmm::BK;
   return (size_t)batch * S2p * Kp * sizeof(bf16_t);
 }
+// the same plus the bf16 images of the standalone quantizer for operands whose blocks are not 16 (x: [batch S1][Kp], y: [batch K][S2 padded to 64])
+static size_t qmm_align(size_t v) { return (v + 255) / 256 * 256; }
+size_t qmatmul_workspace_bytes_ex(int64_t batch, int64_t S1, int64_t K, int64_t S2, bool x_pre, bool y_pre) {
+  const int64_t Kp = (K + qmm::BK - 1) / qmm::BK * qmm::BK, S2q = (S2 + 63) / 64 * 64;
+  size_t n = qmm_align(qmatmul_workspace_bytes(batch, K, S2));
+  if (x_pre) n += qmm_align((size_t)lqer_padded_m(batch * S1) * Kp * sizeof(bf16_t));
+  if (y_pre) n += qmm_align((size_t)lqer_padded_m(batch * K) * S2q * sizeof(bf16_t));
+  return n;
+}
 
 template <int DT>
 static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, int64_t S1, int64_t K, int64_t S2, int64_t x_bs, int64_t x_rs,
@@ -644,6 +670,42 @@ static int launch_qmm(const void* x, const void* y, void* out, int64_t batch, in
   const int64_t S2p = (S2 + qmm::BN - 1) / qmm::BN * qmm::BN, Kp = (K + qmm::BK - 1) / qmm::BK * qmm::BK;
   const int esz = DT == LQER_F32 ? 4 : 2;
   auto al16 = [&](const void* p, int64_t a, int64_t c) { return ((uintptr_t)p % 16 == 0) && (a * esz) % 16 == 0 && (c * esz) % 16 == 0; };
+  // ---- operands whose blocks are not 16 elements: the standalone quantizer writes their bf16 images first (any 16 n, whole
+  // rows), the image / product kernels then take those as they are (PRE / XPRE) - the same bits as the fused form would give
+  const bool x_pre = qx.block != 16, y_pre = qy.block != 16;
+  if (x_pre || y_pre) {
+    unsigned char* wsp = (unsigned char*)img + qmm_align(qmatmul_workspace_bytes(batch, K, S2));
+    const int64_t S2q = (S2 + 63) / 64 * 64;
+    const bf16_t* xi = nullptr;
+    const bf16_t* yi = nullptr;
+    if (x_pre) {  // rows (b, i) must be evenly spaced: x_bs == S1 x_rs (the caller guarantees it)
+      QuantOut o{nullptr, nullptr, nullptr, (bf16_t*)wsp, Kp, 0};
+      const int rc = quantize_dispatch(x, DT, batch * S1, K, x_rs, qx, o, st);
+      if (rc) return rc;
+      xi = (const bf16_t*)wsp;
+      wsp += qmm_align((size_t)lqer_padded_m(batch * S1) * Kp * sizeof(bf16_t));
+    }
+    if (y_pre) {  // y [b][k][j] dense along j, rows (b, k) evenly spaced: y_bs == K y_ks
+      QuantOut o{nullptr, nullptr, nullptr, (bf16_t*)wsp, S2q, 0};
+      const int rc = quantize_dispatch(y, DT, batch * K, S2, y_ks, qy, o, st);
+      if (rc) return rc;
+      yi = (const bf16_t*)wsp;
+    }
+    const dim3 gi((unsigned)(S2p / 64), (unsigned)(Kp / 64), (unsigned)batch);
+    if (y_pre)
+      qmm::k_qmm_bimage_j<LQER_BF16, true><<<gi, 256, 0, st>>>(yi, K, S2, K * S2q, S2q, qy, img, S2p, Kp, true);
+    else if (y_js == 1)
+      qmm::k_qmm_bimage_j<DT><<<gi, 256, 0, st>>>(y, K, S2, y_bs, y_ks, qy, img, S2p, Kp, al16(y, y_bs, y_ks));
+    else
+      qmm::k_qmm_bimage_k<DT><<<dim3((unsigned)(Kp / 64), (unsigned)(S2p / 64), (unsigned)batch), 256, 0, st>>>(y, K, S2, y_bs, y_js, qy, img, S2p, Kp,
+                                                                                                          al16(y, y_bs, y_js));
+    const dim3 grid((unsigned)(S2p / qmm::BN), (unsigned)((S1 + qmm::BM - 1) / qmm::BM), (unsigned)batch);
+    if (x_pre)
+      qmm::k_qmatmul<DT, false, 4, true><<<grid, 256, 0, st>>>(xi, img, out, S1, K, S2, S1 * Kp, Kp, S2p, Kp, qx, true);
+    else
+      qmm::k_qmatmul<DT, false><<<grid, 256, 0, st>>>(x, img, out, S1, K, S2, x_bs, x_rs, S2p, Kp, qx, al16(x, x_bs, x_rs));
+    return check_launch("lqer_matmul_q");
+  }
   if (y_js == 1) {
     const dim3 grid((unsigned)(S2p / 64), (unsigned)(Kp / 64), (unsigned)batch);
     qmm::k_qmm_bimage_j<DT><<<grid, 256, 0, st>>>(y, K, S2, y_bs, y_ks, qy, img, S2p, Kp, al16(y, y_bs, y_ks));

@@ -6,10 +6,10 @@ Blocks run along the last dim of each operand, which for y is NOT the contractio
 templates' settings (block_fp, width <= 8, blocks of 16) the whole product is ONE fused HIP GEMM (lqer_matmul_q,
 csrc/matmul_q.hip): x is quantized in the GEMM's load path - read from HBM once, no quantized copy -, y through a small bf16
 image, bf16 MFMA with fp32 accumulation of exact products; 4-D [bsz, heads, ..] operands are folded into one batch dim.  Other
-block lengths (no template uses them: the fused kernels keep one block of 16 per thread, so that block maxima need no
-cross-lane work) and operands whose leading dims broadcast run the library's quantizer kernels on both operands and hand the two
-quantized images to torch.matmul / torch.bmm - the same bits.  Quantizer settings outside what the kernels
-implement raise - there is no software fallback.
+block lengths (16 n elements, or whole rows; no template uses them) take the same product kernel behind the library's
+standalone quantizer: that operand's bf16 image is written first and read as it is - the same bits.  Only operands whose
+leading dims broadcast (no call site has them) run the quantizer kernels on both operands and hand the two quantized tensors to
+torch.matmul / torch.bmm.  Quantizer settings outside what the kernels implement raise - there is no software fallback.
 """
 from __future__ import annotations
 
@@ -33,18 +33,23 @@ def _quantize(t: torch.Tensor, cfg: dict) -> torch.Tensor:
         raise NotImplementedError(f"lqer_amd.functional: quantizer {name!r} is not implemented on the HIP path")
     ops._need_gpu(t)
     fmt = ops.make_qfmt(cfg)
+    if fmt.block > 0 and fmt.block < t.shape[-1] and fmt.block % 16:
+        raise NotImplementedError(f"lqer_amd.functional: block_size {cfg.get('block_size')} - the quantizer kernels take blocks of 16 n "
+                                  "elements or whole rows along the last dim")
     return ops.quantize_mxint(t, fmt, want=("deq",))["deq"].to(t.dtype)
 
 
 def _fused_fmt(cfg: dict):
-    """The lqer_qfmt_t of a quantizer the fused kernel covers (block_fp, width <= 8, blocks of 16 along the last dim), else None."""
+    """The lqer_qfmt_t of a quantizer the library's product kernels cover (block_fp, width <= 8, blocks of 16 n elements or
+    whole rows along the last dim: 16 runs fused in the load path, other lengths through the standalone quantizer's bf16
+    image first - csrc/matmul_q.hip), else None."""
     if cfg.get("name") != "block_fp" or int(cfg.get("width", 12)) > 8:
         return None
     try:
         fmt = ops.make_qfmt(cfg, "x")
     except NotImplementedError:
         return None
-    return fmt if fmt.block == 16 else None
+    return fmt if (fmt.block <= 0 or fmt.block % 16 == 0) else None
 
 
 _MAX_GRID_Z = 65535  # the kernels put the batch on grid.z
@@ -65,13 +70,19 @@ def _matmul_fused(x: torch.Tensor, y: torch.Tensor, fx, fy) -> torch.Tensor:
         x3 = x3.contiguous()
     if y3.stride(1) != 1 and y3.stride(2) != 1:  # (the kernel reads y dense along k - the transposed view of K - or along j)
         y3 = y3.contiguous()
+    # an operand whose blocks are not 16 goes through the standalone quantizer first: evenly spaced rows over the batch, y dense along j
+    x_pre, y_pre = fx.block != 16, fy.block != 16
+    if x_pre and b > 1 and x3.stride(0) != S1 * x3.stride(1):
+        x3 = x3.contiguous()
+    if y_pre and (y3.stride(2) != 1 or (b > 1 and y3.stride(0) != K * y3.stride(1))):
+        y3 = y3.contiguous()
     out = torch.empty(b, S1, S2, dtype=x.dtype, device=x.device)
     L = _lib.lib()
     with torch.cuda.device(x.device):
         for b0 in range(0, b, _MAX_GRID_Z):
             xb, yb, ob = x3[b0:b0 + _MAX_GRID_Z], y3[b0:b0 + _MAX_GRID_Z], out[b0:b0 + _MAX_GRID_Z]
             nb = xb.shape[0]
-            nws = L.lqer_matmul_q_workspace_bytes(nb, K, S2)
+            nws = L.lqer_matmul_q_workspace_bytes_fmt(nb, S1, K, S2, C.byref(fx), C.byref(fy))
             ws = ops.workspace(x.device, max(nws, 16))
             ys = yb.stride()
             _lib.check(L.lqer_matmul_q(xb.data_ptr(), yb.data_ptr(), ob.data_ptr(), ops.dtype_code(x3), nb, S1, K, S2, xb.stride(0),

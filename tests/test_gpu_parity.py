@@ -397,6 +397,45 @@ def test_fused_quantized_matmul_vs_oracle(ops, dtype, tol, bh, s1, s2, d):
     assert torch.equal(lqer_amd.matmul_flexible(q[0].to(DEV), kt[0], qc), out[0])
 
 
+def test_quantized_matmul_blocks_other_than_16(ops, monkeypatch):
+    """matmul_flexible with block lengths other than the templates' 16 (quantized_functions/matmul.py:12-29 takes any
+    block_size): the library's standalone quantizer writes the operand's bf16 image, the library's own image / product kernels
+    take it as it is - torch.matmul is never reached.  Against the reference's vectors (blocks of 32 on both operands; x in
+    blocks of 32 with one block per row of y) and, for mixed settings at larger shapes, against the oracle."""
+    import json
+
+    import numpy as np
+
+    import lqer_amd
+    from lqer_amd import functional
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(here, "matmul.npz"))
+    cfgs = json.load(open(os.path.join(here, "matmul_config_blocks.json")))
+    monkeypatch.setitem(functional.MATMUL_MAP, "matmul", lambda *a, **k: (_ for _ in ()).throw(AssertionError("torch.matmul reached")))
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    for name in ("b32", "brow"):
+        out = lqer_amd.matmul_flexible(t(f"{name}/x"), t(f"{name}/y"), cfgs[name]).cpu()
+        ref = torch.from_numpy(g[f"{name}/out"])
+        assert float((out - ref).norm() / ref.norm()) <= 1e-6, name
+    # the transposed VIEW of K as y (dense along k): made dense along j first, same result
+    out_v = lqer_amd.matmul_flexible(t("b32/x"), t("b32/y").transpose(1, 2).contiguous().transpose(1, 2), cfgs["b32"]).cpu()
+    assert float((out_v - torch.from_numpy(g["b32/out"])).norm() / torch.from_numpy(g["b32/out"]).norm()) <= 1e-6
+    bfp = lambda blk: dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[1, blk], skip_first_dim=True)
+    gen = torch.Generator().manual_seed(9)
+    for dtype, tol in ((torch.float32, 2e-6), (torch.float16, 1e-3)):
+        for bx, by, (bh, s1, s2, d) in ((64, 16, (3, 300, 200, 128)), (16, 32, (2, 129, 70, 64)), (-1, 64, (2, 260, 520, 128)), (32, -1, (1, 16, 16, 40))):
+            qc = dict(name="flexible", default=False, x_quantizer=bfp(bx), w_quantizer=bfp(by))
+            x = torch.randn(bh, s1, d, generator=gen).to(dtype)
+            y = (torch.randn(bh, d, s2, generator=gen) * torch.logspace(-2, 1, s2)).to(dtype)
+            out = lqer_amd.matmul_flexible(x.to(DEV), y.to(DEV), qc)
+            assert out.dtype == dtype and out.shape == (bh, s1, s2)
+            ref = O.matmul_flexible(x.float(), y.float(), qc)
+            assert float((out.float().cpu() - ref).norm() / ref.norm()) <= tol, (bx, by, dtype)
+    with pytest.raises(NotImplementedError):  # a block length the quantizer kernels do not have (not 16 n): refused, never approximated
+        lqer_amd.matmul_flexible(t("b32/x"), t("b32/y"), dict(cfgs["b32"], x_quantizer=bfp(24)))
+
+
 def test_fused_quantized_matmul_takes_4d_operands_and_large_batches(ops, monkeypatch):
     """The llama call sites hand matmul_flexible 4-D [bsz, heads, ..] operands (reference llama_decoder.py:263,294): they are
     folded into one batch dim and run the fused kernel - same bits as head by head; a batch beyond the grid.z limit goes in

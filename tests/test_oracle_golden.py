@@ -133,6 +133,10 @@ def test_oracle_quantized_matmuls_vs_reference_vectors():
     here = os.path.join(os.path.dirname(__file__), "golden")
     g = np.load(os.path.join(here, "matmul.npz"))
     qc = json.load(open(os.path.join(here, "matmul_config.json")))
+    blk = json.load(open(os.path.join(here, "matmul_config_blocks.json")))  # (round 4) blocks of 32 / one block per row of y
+    for name in ("b32", "brow"):
+        out = O.matmul_flexible(torch.from_numpy(g[f"{name}/x"]), torch.from_numpy(g[f"{name}/y"]), blk[name])
+        assert torch.equal(out, torch.from_numpy(g[f"{name}/out"])), name
     for name, fn in (("qk", O.matmul_flexible), ("pv", O.matmul_flexible), ("bmm", O.bmm_flexible)):
         out = fn(torch.from_numpy(g[f"{name}/x"]), torch.from_numpy(g[f"{name}/y"]), qc)
         assert torch.equal(out, torch.from_numpy(g[f"{name}/out"])), name
