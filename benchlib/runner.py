@@ -210,7 +210,9 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
                           ws=ws.data_ptr(), ws_bytes=ws.numel(),
                           xscr=xscr, nscr=nscr, w=p["w"].data_ptr(),
                           b_t=p["b_t"].data_ptr(), b_limbs=p["b_limbs"], bias=ops._ptr(p.get("bias")), y=y.data_ptr(),
-                          gscr=gscr, K=K, N=N, reps=reps, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16)))
+                          gscr=gscr, K=K, N=N, reps=reps, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16),
+                          # 128-row tiles: lqer_linear_forward skips the reduce launch (xaq == NULL: the GEMM sums the partial tiles)
+                          part=bool(r > 0 and a_limbs == 1 and L.lqer_tile_partials(C.byref(desc), M, _lib.F16))))
 
     # M <= 8 with block_fp activations in blocks of 16: lqer_linear_forward issues ONE launch
     one_launch = (M <= 8 and r > 0 and bool(plans) and
@@ -234,17 +236,18 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
                 K, N = pl["K"], pl["N"]
                 fa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["w"], pl["a_t"], pl["b_t"], pl["a_limbs"], pl["b_limbs"], pl["bias"],
                       pl["y"], N, pl["ws"], pl["ws_bytes"], st)
-                qa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"], pl["xq"], pl["xaq"], pl["xscr"], pl["nscr"], st)
-                ga = (pl["dref"], pl["xq"], M, pl["w"], pl["xaq"], pl["b_t"], pl["b_limbs"], pl["bias"], pl["y"], _lib.F16, N,
-                      pl["xscr"], pl["gscr"], st)
+                xaq, gscr = (None, pl["nscr"]) if pl["part"] else (pl["xaq"], pl["gscr"])
+                qa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"], pl["xq"], xaq, pl["xscr"], pl["nscr"], st)
+                ga = (pl["dref"], pl["xq"], M, pl["w"], xaq, pl["b_t"], pl["b_limbs"], pl["bias"], pl["y"], _lib.F16, N,
+                      pl["xscr"], gscr, st)
                 per_unit = [(fa, qa, ga)]
                 for cw, ca, cb, cbias in pl["copies"]:  # the other Linears of this shape: own weight / A / B / bias images
                     per_unit.append(((pl["dref"], pl["x"], _lib.F16, M, K, cw, ca, cb, pl["a_limbs"], pl["b_limbs"], cbias,
                                       pl["y"], N, pl["ws"], pl["ws_bytes"], st),
-                                     (pl["dref"], pl["x"], _lib.F16, M, K, ca, pl["a_limbs"], pl["xq"], pl["xaq"], pl["xscr"],
+                                     (pl["dref"], pl["x"], _lib.F16, M, K, ca, pl["a_limbs"], pl["xq"], xaq, pl["xscr"],
                                       pl["nscr"], st),
-                                     (pl["dref"], pl["xq"], M, cw, pl["xaq"], cb, pl["b_limbs"], cbias, pl["y"], _lib.F16, N,
-                                      pl["xscr"], pl["gscr"], st)))
+                                     (pl["dref"], pl["xq"], M, cw, xaq, cb, pl["b_limbs"], cbias, pl["y"], _lib.F16, N,
+                                      pl["xscr"], gscr, st)))
                 rows.append((pl["reps"], K, N, per_unit))
             bound[(st, id(pls))] = rows
         return bound[(st, id(pls))]

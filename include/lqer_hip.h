@@ -109,6 +109,10 @@ typedef struct lqer_linear_desc {
                                          128-row kernel instead of rows of weight tiles; applied only where the tile grid divides
                                          (16 x 16 tiles: 8, 4 or 16); measured +-0 (the weight stream through every XCD's L2 is
                                          served by the Infinity Cache)                                                        */
+#define LQER_TUNE_XA_REDUCE_IN_GEMM 0x20000 /* lqer_linear_forward on 128-row tiles: no reduce launch between the quantizer and the
+                                         GEMM - its workgroups sum the partial tiles of x A for their own rows (lqer_tile_partials).
+                                         Off by default: measured slower (C2: the GEMM grows by 5.3 us, the launch it saves took
+                                         4.9 us - the sum sits in front of the main loop, whose accumulators it opens)           */
 #define LQER_TUNE_DECODE_NO_POLL 0x10000 /* one-launch decode route: no wait for the producers' tiles - every weight-streaming
                                          workgroup computes the partial tiles of x A itself (the bounded wait's fall-back)     */
 
@@ -250,6 +254,14 @@ int lqer_gemm_route(const lqer_linear_desc_t* desc, int64_t M, int dtype);
  * lqer_linear_gemm with xaq_bf16 == NULL and the SAME scratch buffer (scratch_bytes = lqer_lowrank_xa_scratch_bytes):
  * the GEMM sums the tiles in the same fixed order and applies A_out itself.  lqer_linear_forward does this on its own. */
 int lqer_decode_partials(const lqer_linear_desc_t* desc, int64_t M);
+/* The same hand-over at the token counts of the 128-row tile kernel, for callers that ask for it (descriptor tuning bit
+ * LQER_TUNE_XA_REDUCE_IN_GEMM; 1 when lqer_linear_forward then takes it for M tokens of `dtype`: LQER_ROUTE_TILE128 with
+ * 128-row tiles, fp16 / bf16 tensors, x / A_out in blocks of 16, padded rank <= 64, one limb of A, B_out pass-through or in
+ * blocks of 16): every GEMM workgroup sums the partial tiles for its own 128 rows in ascending chunk order and applies A_out
+ * on the way into the side product's LDS stage - k_xa_reduce4's arithmetic item by item, same bits (csrc/gemm_w4a8.hip,
+ * XAPART).  A measured dead end kept selectable: the sum delays the main loop by more than the launch it replaces.  Same
+ * calling convention: lqer_quantize_act_xa and lqer_linear_gemm with xaq_bf16 == NULL and the same scratch. */
+int lqer_tile_partials(const lqer_linear_desc_t* desc, int64_t M, int dtype);
 
 /* lqer_linear_gemm with an explicit row stride of xaq (elements; a multiple of 8, >= the padded rank): Linears that
  * share one input (q/k/v, gate/up; llama_decoder.py:246-248, :176) can run ONE lqer_quantize_act_xa over the

@@ -16,7 +16,7 @@ F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
 ROUTE_SMALLM, ROUTE_TILE128, ROUTE_TILE256, ROUTE_TILE256_I8 = 0, 1, 2, 3
-TUNE_TILE_ROWS_128, TUNE_TILE_ROWS_64, TUNE_DECODE_NO_POLL = 0x1, 0x2, 0x10000
+TUNE_TILE_ROWS_128, TUNE_TILE_ROWS_64, TUNE_DECODE_NO_POLL, TUNE_XA_REDUCE_IN_GEMM = 0x1, 0x2, 0x10000, 0x20000
 
 
 def tune_xcd_block(t: int) -> int:
@@ -82,6 +82,7 @@ SIGNATURES = {
     "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),
     "lqer_decode_partials": (_i, [_dp, _i64]),
+    "lqer_tile_partials": (_i, [_dp, _i64, _i]),
     "lqer_group_workspace_bytes": (_sz, [_i64, _i64]),
     "lqer_linear_forward_group": (_i, [C.POINTER(GroupMember), _i, _vp, _i, _i64, _i64, _vp, _i, _vp, _sz, _vp]),
     "lqer_gemm_route": (_i, [_dp, _i64, _i]),

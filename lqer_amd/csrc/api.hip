@@ -149,6 +149,20 @@ static bool passthrough_width_ok(const lqer_qfmt_t& f, const char* name) {
 using namespace lqer;
 
 extern "C" {
+static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, GemmArgs& g);
+// Token counts of the 128-row tile kernel, on request (LQER_TUNE_XA_REDUCE_IN_GEMM - measured slower, include/lqer_hip.h): its workgroups sum the partial tiles for their own rows on the way into the
+// side product's LDS stage (k_lqer_gemm XAPART) - the reduce launch between the quantizer and the GEMM is skipped
+static bool tile_partials_ok(const lqer_linear_desc_t* d, int64_t M, int dtype) {
+  if (!d || d->rank <= 0 || M <= 64 || (dtype != LQER_F16 && dtype != LQER_BF16) || !(d->tuning & LQER_TUNE_XA_REDUCE_IN_GEMM)) return false;
+  if (d->w_fmt.kind != LQER_Q_MXINT || d->x_fmt.kind != LQER_Q_MXINT || d->a_out_fmt.kind != LQER_Q_MXINT) return false;
+  if (!xa_fused_partials_ok(make_qp(d->x_fmt), make_qp(d->a_out_fmt), d->rank)) return false;
+  const lqer_qfmt_t& bo = d->b_out_fmt;  // (other B_out blocks: the pre-pass reads xAq)
+  if (!(bo.kind == LQER_Q_PASSTHROUGH || (bo.kind == LQER_Q_MXINT && bo.block == 16))) return false;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  if (gemm_shape_args(d, M, dtype, g)) return false;
+  return gemm_route(g, true) == LQER_ROUTE_TILE128 && gemm_tile_rows(g) == 128;
+}
 
 int lqer_version(void) { return LQER_ABI_VERSION; }
 const char* lqer_last_error(void) { return g_err; }
@@ -377,9 +391,9 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
     return LQER_E_INVALID;
   }
   if (d->rank > 0 && a_t && !xaq) {  // partial tiles only: the GEMM reduces them (decode sizes)
-    if (!decode_partials_ok(d, M)) {
-      set_error("quantize_act_xa: xaq == NULL needs M <= 64, x / A_out block_fp in blocks of 16 (width <= 9), padded rank <= 64 "
-                "and B_out pass-through or in blocks of 16");
+    if (!decode_partials_ok(d, M) && !tile_partials_ok(d, M, dtype)) {
+      set_error("quantize_act_xa: xaq == NULL needs M <= 64 or the 128-row tile kernel's token counts with fp16 / bf16 tensors, "
+                "x / A_out block_fp in blocks of 16 (width <= 9), padded rank <= 64 and B_out pass-through or in blocks of 16");
       return LQER_E_INVALID;
     }
     const int rc = quant_xa_fused_dispatch(x, dtype, M, d->in_features, ldx, make_qp(d->x_fmt), (bf16_t*)xq, (const bf16_t*)a_t,
@@ -480,7 +494,7 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
     return LQER_E_INVALID;
   }
   const bool lowrank = d->rank > 0;
-  const bool from_partials = lowrank && !xaq && b_t && scratch && decode_partials_ok(d, M);
+  const bool from_partials = lowrank && !xaq && b_t && scratch && (decode_partials_ok(d, M) || tile_partials_ok(d, M, dtype));
   if (lowrank && ((!xaq && !from_partials) || !b_t)) {
     set_error("linear_gemm: rank %d but no side-path operands (xaq == NULL: only the decode route, see lqer_decode_partials)", d->rank);
     return LQER_E_INVALID;
@@ -588,6 +602,14 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
     if (rc) return rc;
     return lqer_linear_gemm(d, xq, M, w_packed, nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch, nscr, stream);
   }
+#ifndef LQER_NO_TILE_PARTIALS
+  if (a_t && b_t && a_limbs == 1 && tile_partials_ok(d, M, dtype)) {  // two launches: no reduce kernel in between
+    const size_t nscr = lqer_lowrank_xa_scratch_bytes(d, M);
+    rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, nullptr, xa_scratch, nscr, stream);
+    if (rc) return rc;
+    return lqer_linear_gemm(d, xq, M, w_packed, nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch, nscr, stream);
+  }
+#endif
   rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, xa_scratch,
                             lqer_lowrank_xa_scratch_bytes(d, M), stream);
   if (rc) return rc;
@@ -659,6 +681,8 @@ int lqer_desc_limbs(const lqer_linear_desc_t* d, int* act, int* xa) {
 }
 
 int lqer_decode_partials(const lqer_linear_desc_t* d, int64_t M) { return decode_partials_ok(d, M) ? 1 : 0; }
+
+int lqer_tile_partials(const lqer_linear_desc_t* d, int64_t M, int dtype) { return tile_partials_ok(d, M, dtype) ? 1 : 0; }
 
 int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r, void* a_t_f16,
                      int32_t* flags, void* stream) {

@@ -476,6 +476,7 @@ void xa_fused_plan(int64_t M, int64_t K, int64_t r, int* nchunk, int64_t* cstrid
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
 int gemm_route(const GemmArgs& g, bool lowrank);  // LQER_ROUTE_* the dispatch would take (or an error code)
+int gemm_tile_rows(const GemmArgs& g);  // 128, or 64 for token counts that leave the 128-row grid thin (LQER_ROUTE_TILE128 family)
 bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) rounds with 256 x 256 tiles
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 bool i8_eligible(const GemmArgs& g, int bout);     // gemm_w4a8_i8.hip: the int8 MFMA main loop (g.w8 set, large M)

@@ -133,9 +133,15 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 // WTWOS: the packed weight holds two's-complement nibbles (w_quantizer = integer, codes -8 .. 7): the second expand of common.h
 // (128-row tiles, staged side path and 16-bit / fp32 tensors only: a format no template configuration uses gets a working
 // kernel, not a tuned one).
-template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4, bool WTWOS = false>
+// XAPART: there is no xAq yet - the fused quantize kernel left the split-K partial tiles of x A (g.xa_part: part[c][m][rp] fp32) and
+// the workgroup sums them in ascending chunk order and applies A_out (blocks of 16) to its 128 / 64 rows on the way into the
+// LDS stage: k_xa_reduce4's arithmetic, item by item, and one dependent launch less per Linear.  Selectable only
+// (LQER_TUNE_XA_REDUCE_IN_GEMM): at C2 the launch it saves took 4.9 us and this kernel grows by 5.3 us (1.0 of it the staged
+// route's barriers) - the sum sits in front of the main loop, whose accumulators it opens, with nothing to hide behind.
+template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4, bool WTWOS = false, bool XAPART = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   static_assert(MT == 4 || MT == 2, "128- or 64-row tiles");
+  static_assert(!XAPART || (LOWRANK && STAGED), "the partial tiles of x A enter through the LDS stage");
   static_assert(!WTWOS || DT != LQER_F16X, "integer weights: no fp16 main loop");
   constexpr int BMk = 32 * MT;   // tile rows
   constexpr int AP = MT / 2;     // 8-row LDS-DMA pieces of the activation tile per wave and k-step
@@ -229,6 +235,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   bf16x8 sb[STAGED ? 2 : 1][STAGED ? 4 : 1];  // B^T fragments of one limb of the pass, double-buffered
   const uint32_t stage = lds0 + OFF_A + (NSLOT - 1) * A_SLOT;
   const bf16_t* const bt_row = STAGED ? g.bt + (int64_t)(n0 + wn * 32 + l31) * g.rp + 8 * lh : nullptr;
+  float4 pv[XAPART ? 8 : 1];                                    // XAPART: the thread's first four chunk reads (8 floats each)
+  const int xa_rows = XAPART ? (int)(g.xa_cstride / g.rp) : 0;  // rows the partial tiles hold (a multiple of 32)
   auto side_fetch_b = [&](int p0, int l, auto buf_c) {  // limb l of this wave's B^T fragments -> sb[buf]
     constexpr int BUF = decltype(buf_c)::value;
     if constexpr (STAGED) {
@@ -242,6 +250,24 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     if constexpr (!STAGED) return;
     const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;  // a multiple of 16
     const int cpr = cols >> 3;                          // 16-byte chunks per row
+    if constexpr (XAPART) {
+      // one item = 8 consecutive rank entries of one token; a thread has one item (rank <= 32) or two.  The first four chunk
+      // reads of the thread (4 chunks of its item, or 2 of each) are requested here, ahead of the ring prefetch; side_reduce
+      // (behind it) sums, requests the rest and quantizes
+      const int nit = BMk * cpr > 512 ? 2 : 1;  // (workgroup-uniform)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = nit == 2 ? q >> 1 : 0, u = nit == 2 ? q & 1 : q;
+        const int c = tid + 512 * j;
+        const int row = c / cpr, ch = c - row * cpr;
+        // (branch-free: rows and chunks that do not exist read the last one that does and are dropped in side_reduce - a
+        // predicated load would be waited for on the spot, one round trip per chunk)
+        const int rowc = m0 + row < xa_rows ? m0 + row : xa_rows - 1, uc = u < g.xa_nchunk ? u : g.xa_nchunk - 1;
+        const float* src = g.xa_part + (int64_t)rowc * g.rp + p0 + 8 * ch + uc * g.xa_cstride;
+        pv[2 * q] = *(const float4*)src;
+        pv[2 * q + 1] = *(const float4*)(src + 4);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < STG; ++j) {
       const int c = tid + 512 * j;
@@ -250,7 +276,63 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         stg[j] = *(const u32x4*)(g.xaq + (int64_t)(m0 + row) * g.xaq_ld + p0 + 8 * ch);
       }
     }
+    }
     side_fetch_b(p0, 0, std::integral_constant<int, 0>{});
+  };
+  // XAPART: chunks summed in ascending order (k_xa_reduce4's order and arithmetic), A_out over the block of 16 = the items of
+  // lanes l and l ^ 1 (cpr is even), bf16 bits into the stage registers
+  auto side_reduce = [&](int p0) {
+    if constexpr (XAPART) {
+      const int cols = g.rp - p0 < 64 ? g.rp - p0 : 64;
+      const int cpr = cols >> 3;
+      auto items = [&](auto nit_c) {
+        constexpr int NIT = decltype(nit_c)::value, FB = 4 / NIT;  // items per thread, chunks per item already requested
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+          const int c = tid + 512 * j;
+          const int row = c / cpr, ch = c - row * cpr;
+          const bool live = c < BMk * cpr && m0 + row < xa_rows;
+          float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          auto add = [&](const float4& a, const float4& b, bool on) {  // (x + 0 = x: a dropped chunk leaves the sum's bits alone)
+            s[0] += on ? a.x : 0.f, s[1] += on ? a.y : 0.f, s[2] += on ? a.z : 0.f, s[3] += on ? a.w : 0.f;
+            s[4] += on ? b.x : 0.f, s[5] += on ? b.y : 0.f, s[6] += on ? b.z : 0.f, s[7] += on ? b.w : 0.f;
+          };
+#pragma unroll
+          for (int u = 0; u < FB; ++u) add(pv[2 * (FB * j + u)], pv[2 * (FB * j + u) + 1], live && u < g.xa_nchunk);
+          const int rowc = m0 + row < xa_rows ? m0 + row : xa_rows - 1;
+          const float* src = g.xa_part + (int64_t)rowc * g.rp + p0 + 8 * ch;
+          for (int cc = FB; cc < g.xa_nchunk; cc += 4) {  // K > 4096 (or two items): four more chunks per round trip
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int uc = cc + u < g.xa_nchunk ? cc + u : g.xa_nchunk - 1;
+              v[2 * u] = *(const float4*)(src + uc * g.xa_cstride), v[2 * u + 1] = *(const float4*)(src + uc * g.xa_cstride + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[2 * u], v[2 * u + 1], live && cc + u < g.xa_nchunk);
+          }
+          float amax = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(s[k]));
+          amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+          const bool any = amax > 0.f;
+          const int e = any ? block_exponent(amax, g.aout) : 0;
+          uint32_t w[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float v0 = any ? ldexpf(mxint_mantissa(s[2 * k], e, g.aout), e - g.aout.mbits) : 0.f;
+            const float v1 = any ? ldexpf(mxint_mantissa(s[2 * k + 1], e, g.aout), e - g.aout.mbits) : 0.f;
+            w[k] = exact_bf16_bits(v0) | (exact_bf16_bits(v1) << 16);
+          }
+          stg[j] = (u32x4){w[0], w[1], w[2], w[3]};
+        }
+      };
+      if (BMk * cpr > 512) {
+        if constexpr (STG == 2) items(std::integral_constant<int, 2>{});
+      } else {
+        items(std::integral_constant<int, 1>{});
+      }
+    }
   };
   // (a side product of at most two 16-deep slices - rank <= 32 with one limb - is cheaper fetched directly: the two
   // barriers of the staged route cost more than they save there; launch_gemm picks the instantiation)
@@ -303,6 +385,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         asm volatile("s_barrier" ::: "memory");  // the previous pass's fragment reads are done (lgkmcnt(0) below)
         side_fetch(p0);
       }
+      side_reduce(p0);
 #pragma unroll
       for (int j = 0; j < STG; ++j) {
         const int c = tid + 512 * j;
@@ -873,6 +956,26 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
       return check_launch("lqer_gemm");
     }
   }
+  if (lowrank && g.xa_part) {  // the partial tiles of x A instead of xAq (api: lqer_tile_partials): staged side path, 16-bit tensors
+    if constexpr (DT != LQER_F16 && DT != LQER_BF16) {
+      set_error("linear_gemm: the partial-tile route takes fp16 / bf16 tensors");
+      return LQER_E_UNSUPPORTED;
+    } else {
+#define LQER_GEMM_LAUNCH_XAP(BO, MTv)                                                                           \
+  do {                                                                                                          \
+    static LdsLimitOnce lds_once;                                                                               \
+    lds_once.set((const void*)k_lqer_gemm<DT, true, BO, true, MTv, false, true>, gemm_lds_bytes(MTv));          \
+    k_lqer_gemm<DT, true, BO, true, MTv, false, true><<<grid, 512, gemm_lds_bytes(MTv), st>>>(g);               \
+  } while (0)
+      if (bout == 2 || g.tiles_m_rows != BM) {  // (64-row tiles: two workgroups per CU leave the reduction no registers)
+        set_error("linear_gemm: the partial-tile route serves 128-row tiles with B_out in blocks of 16 or pass-through");
+        return LQER_E_UNSUPPORTED;
+      }
+      if (bout == 1) LQER_GEMM_LAUNCH_XAP(1, 4); else LQER_GEMM_LAUNCH_XAP(0, 4);
+#undef LQER_GEMM_LAUNCH_XAP
+      return check_launch("lqer_gemm");
+    }
+  }
 #define LQER_GEMM_LAUNCH_H64(LR, BO, ST)                                                                        \
   do {                                                                                                          \
     static LdsLimitOnce lds_once;                                                                               \
@@ -956,6 +1059,20 @@ int gemm_route(const GemmArgs& g, bool lowrank) {
   return LQER_ROUTE_TILE128;
 }
 
+// Rows of a tile of the 128-row kernel family.  Token counts whose 128-row grid covers at most half of the CUs: 64-row tiles
+// (twice the workgroups, half the MFMA work per expanded weight fragment - the k-step is then paced by the weight expand,
+// NOTEBOOK.md §4.1) as long as they still fit one round.
+int gemm_tile_rows(const GemmArgs& g) {
+#ifndef LQER_NO_H64
+  constexpr int CUS = 256;
+  const int64_t tn = g.Np / BN;
+  const int64_t t128 = (int64_t)((g.M + BM - 1) / BM) * tn, t64 = (int64_t)((g.M + 63) / 64) * tn;
+  const int pin = (g.tuning & LQER_TUNE_TILE_ROWS_128) ? 128 : ((g.tuning & LQER_TUNE_TILE_ROWS_64) ? 64 : 0);  // (tests)
+  if (!g.w_twos && ((pin != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) || (pin == 64 && g.M > 64))) return 64;
+#endif
+  return BM;
+}
+
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st) {
   if (g.M == 0 || g.N == 0) return LQER_OK;
   int L = 0;
@@ -1025,24 +1142,11 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   }
   if (!g.w_twos) {
     if (smallm_eligible(g, bout)) return smallm_dispatch(g, dtype, lowrank, bout, st);  // decode sizes: HBM-bound variant
-    if (m256_eligible(g)) return m256_dispatch(g, dtype, lowrank, bout, st);            // large M: 256 x 256 tiles
+    if (m256_eligible(g) && !g.xa_part) return m256_dispatch(g, dtype, lowrank, bout, st);  // large M: 256 x 256 tiles
   }
-  g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
-  g.tiles_m_rows = BM;
-#ifndef LQER_NO_H64
-  // Token counts whose 128-row grid covers at most half of the CUs: 64-row tiles (twice the workgroups, half the MFMA work
-  // per expanded weight fragment - the k-step is then paced by the weight expand, NOTEBOOK.md §4.1) as long as they still fit one round.
-  {
-    constexpr int CUS = 256;
-    const int64_t t128 = (int64_t)g.tiles_m * g.tiles_n, t64 = (int64_t)((g.M + 63) / 64) * g.tiles_n;
-    const int pin = (g.tuning & LQER_TUNE_TILE_ROWS_128) ? 128 : ((g.tuning & LQER_TUNE_TILE_ROWS_64) ? 64 : 0);  // (tests)
-    if (!g.w_twos && ((pin != 128 && 2 * t128 <= CUS && t64 > t128 && g.M > 64) || (pin == 64 && g.M > 64))) {
-      g.tiles_m = (g.M + 63) / 64;
-      g.tiles_m_rows = 64;
-    }
-  }
-#endif
+  g.tiles_m_rows = gemm_tile_rows(g);
+  g.tiles_m = (g.M + g.tiles_m_rows - 1) / g.tiles_m_rows;
   {
     const int bm = (g.tuning >> 4) & 0x3f, nt = g.tiles_m * g.tiles_n;  // LQER_TUNE_XCD_BLOCK (measurements)
     g.xcd_bm = 0;

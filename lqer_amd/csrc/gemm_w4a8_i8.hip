@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int lane_k = threadIdx.x & 63;
   const int wave_k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef LQER_CLOCKPROBE
-  unsigned long long cp_c[4], cp_r[4], cp_e1 = 0, cp_e1r = 0, cp_e2 = 0, cp_e2r = 0;
+  unsigned long long cp_c[4], cp_r[4], cp_e1 = 0, cp_e1r = 0, cp_e2 = 0, cp_e2r = 0, cp_a = 0, cp_b = 0, cp_cc = 0, cp_x = 0;
   I8_STAMP(cp_c[0], cp_r[0]);
 #endif
 
@@ -732,7 +732,6 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const float ws = wscale[n];
   const float bv = g.bias ? g.bias[n] : 0.f;
 #ifdef LQER_CLOCKPROBE
-  unsigned long long cp_a, cp_b, cp_cc, cp_x;
   I8_STAMP(cp_a, cp_x);
 #endif
   // the integer tile -> v = float(R) * xs[m] * ws[n] + bias[n], in place, two elements per packed fp32 instruction
@@ -943,8 +942,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #ifdef LQER_CLOCKPROBE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   I8_STAMP(cp_c[3], cp_r[3]);
-  if (g_i8_stamp_buf && lane == 0) {
-    unsigned long long* o = g_i8_stamp_buf + ((size_t)blockIdx.x * 8 + wave) * 8;
+  if (g_i8_stamp_buf && lane_k == 0) {  // (the workgroup's LAST tile)
+    unsigned long long* o = g_i8_stamp_buf + ((size_t)blockIdx.x * 8 + wave_k) * 8;
     o[0] = cp_c[2] - cp_c[1], o[1] = cp_r[2] - cp_r[1];  // main loop: cycles, 100 MHz ticks
     o[2] = cp_c[1] - cp_c[0];                            // prologue (ring fill)
     o[3] = ((cp_a - cp_c[2]) & 0xffff) | (((cp_b - cp_a) & 0xffff) << 16) | (((cp_cc - cp_b) & 0xffff) << 32) | (((cp_e1 - cp_cc) & 0xffff) << 48);

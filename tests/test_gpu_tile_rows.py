@@ -90,3 +90,44 @@ def test_forced_64_row_tiles_and_xcd_blocks_give_the_same_bits(lq):
         mod.tuning = _lib.tune_xcd_block(bm)
         assert torch.equal(mod(xd), y0), bm
     mod.tuning = 0
+
+
+PARTIAL_CASES = [  # M, K, N, rank, bias, B_out, dtype
+    (2048, 4096, 4096, 32, False, "mx", torch.float16),   # C2: four chunks, one item per thread
+    (300, 1100, 520, 20, True, "mx", torch.bfloat16),     # ragged M / K / N, padded rank, bias (128-row tiles pinned)
+    (1500, 11008, 512, 32, False, "mx", torch.float16),   # eleven chunks: three round trips
+    (640, 2048, 768, 64, True, "mx", torch.bfloat16),     # rank 64: two items per thread, two chunks each up front
+    (513, 1024, 1024, 48, False, "pass", torch.float16),  # padded rank 48, B_out pass-through
+]
+
+
+@pytest.mark.parametrize("M,K,N,r,bias,bout,dtype", PARTIAL_CASES)
+def test_gemm_summing_the_partial_tiles_equals_the_reduce_launch(lq, M, K, N, r, bias, bout, dtype):
+    """LQER_TUNE_XA_REDUCE_IN_GEMM: lqer_linear_forward on 128-row tiles skips k_xa_reduce4 - the GEMM's workgroups sum the
+    split-K partial tiles of x A in ascending chunk order and apply A_out on the way into the side product's LDS stage
+    (k_lqer_gemm XAPART) - the same arithmetic item by item, so y must carry the bits of the default three-launch route.
+    (Selectable, not the default: measured slower, include/lqer_hip.h.)"""
+    from bench import MXINT_Q, make_case
+    from lqer_amd import _lib
+
+    qc = {"mx": MXINT_Q, "pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"})}[bout]
+    case = make_case(M, K, N, max(r, 16), seed=37, bias=bias)
+    x, W, A, B = case[:4]
+    A, B = A[:, :r].contiguous(), B[:r].contiguous()
+    mod = lq.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = case[4]
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).to(dtype)
+    xd = x.to(dtype).to(DEV)
+    mod.tuning = _lib.TUNE_TILE_ROWS_128
+    y3 = mod(xd).clone()
+    mod.tuning = _lib.TUNE_TILE_ROWS_128 | _lib.TUNE_XA_REDUCE_IN_GEMM
+    assert _lib.lib().lqer_tile_partials(mod._desc(), M, _lib.F16 if dtype == torch.float16 else _lib.BF16) == 1
+    y2 = mod(xd).clone()
+    assert torch.equal(y2, y3)
+    h = lambda t: None if t is None else t.to(dtype).float()
+    ref = O.lqer_linear_forward(h(x), h(W), h(case[4]) if bias else None, h(A), h(B), qc)
+    err = float((y2.float().cpu() - ref).norm() / ref.norm())
+    assert err <= (4e-3 if dtype == torch.bfloat16 else 1e-3), err

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--also-128", action="store_true", help="time every build a second time with the 128-row tiles pinned (LQER_TUNE_TILE_ROWS_128)")
     ap.add_argument("--also-64", action="store_true", help="time every build once more with 64-row tiles forced (two workgroups per CU at large M)")
     ap.add_argument("--spin0", action="store_true", help="also time every build with the in-launch hand-offs' poll bound at 0 (every workgroup sums its own rows)")
+    ap.add_argument("--also-in-gemm", action="store_true", help="time every build once more with the GEMM summing the partial tiles of x A itself (LQER_TUNE_XA_REDUCE_IN_GEMM: two launches)")
     ap.add_argument("--gap", type=int, default=0, help="tiny unrelated kernels launched between the quantizer and the GEMM (boundary-effect probe)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -43,6 +44,8 @@ def main():
         libs += [(p + " [64-row tiles]", L) for p, L in base]
     if a.spin0:
         libs += [(p + " [spin 0]", L) for p, L in base]
+    if a.also_in_gemm:
+        libs += [(p + " [reduce in GEMM]", L) for p, L in base]
     st = torch.cuda.current_stream().cuda_stream
     scr, nscr = op["scr"], op["nscr"]
 
@@ -50,9 +53,11 @@ def main():
 
     def run(L, pin=0):
         # per-call knobs ride in the descriptor (lqer_linear_desc_t.tuning, ABI 9; older builds read a prefix of the struct)
-        desc.tuning = {128: _lib.TUNE_TILE_ROWS_128, 64: _lib.TUNE_TILE_ROWS_64, -1: _lib.TUNE_DECODE_NO_POLL}.get(pin, 0)
-        # (a build whose GEMM sums the partial tiles of x A itself - lqer_decode_partials - gets no xaq: two launches)
-        xa = None if L.lqer_decode_partials(C.byref(desc), M) else xaq.data_ptr()
+        desc.tuning = {128: _lib.TUNE_TILE_ROWS_128, 64: _lib.TUNE_TILE_ROWS_64, -1: _lib.TUNE_DECODE_NO_POLL,
+                       -2: _lib.TUNE_XA_REDUCE_IN_GEMM}.get(pin, 0)
+        # (a build whose GEMM sums the partial tiles of x A itself - lqer_decode_partials / lqer_tile_partials - gets no xaq: two launches)
+        part = L.lqer_decode_partials(C.byref(desc), M) or (hasattr(L, "lqer_tile_partials") and L.lqer_tile_partials(C.byref(desc), M, _lib.F16))
+        xa = None if part else xaq.data_ptr()
         rc = L.lqer_quantize_act_xa(C.byref(desc), x.data_ptr(), _lib.F16, M, K, at.data_ptr(), 1, xq.data_ptr(), xa,
                                     scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
@@ -62,7 +67,7 @@ def main():
                                 _lib.F16, N, scr.data_ptr(), nscr, st)
         assert rc == 0, L.lqer_last_error()
 
-    pin_of = lambda p: 128 if p.endswith("[128-row tiles]") else (64 if p.endswith("[64-row tiles]") else (-1 if p.endswith("[spin 0]") else 0))
+    pin_of = lambda p: 128 if p.endswith("[128-row tiles]") else (64 if p.endswith("[64-row tiles]") else (-1 if p.endswith("[spin 0]") else (-2 if p.endswith("[reduce in GEMM]") else 0)))
     times = {p: [] for p, _ in libs}
     for p, L in libs:
         for _ in range(10):
