@@ -112,7 +112,7 @@ typedef struct lqer_linear_desc {
 #define LQER_TUNE_XA_REDUCE_IN_GEMM 0x20000 /* lqer_linear_forward on 128-row tiles: no reduce launch between the quantizer and the
                                          GEMM - its workgroups sum the partial tiles of x A for their own rows (lqer_tile_partials).
                                          Off by default: measured slower (C2: the GEMM grows by 5.3 us, the launch it saves took
-                                         4.9 us - the sum sits in front of the main loop, whose accumulators it opens)           */
+                                         4.9 us - 16 partial tiles at K = 4096, summed in front of the main loop, whose accumulators it opens)           */
 #define LQER_TUNE_DECODE_NO_POLL 0x10000 /* one-launch decode route: no wait for the producers' tiles - every weight-streaming
                                          workgroup computes the partial tiles of x A itself (the bounded wait's fall-back)     */
 

@@ -137,7 +137,8 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 // the workgroup sums them in ascending chunk order and applies A_out (blocks of 16) to its 128 / 64 rows on the way into the
 // LDS stage: k_xa_reduce4's arithmetic, item by item, and one dependent launch less per Linear.  Selectable only
 // (LQER_TUNE_XA_REDUCE_IN_GEMM): at C2 the launch it saves took 4.9 us and this kernel grows by 5.3 us (1.0 of it the staged
-// route's barriers) - the sum sits in front of the main loop, whose accumulators it opens, with nothing to hide behind.
+// route's barriers) - the quantizer leaves one partial tile per 256 k (16 at K = 4096: 256 KB per workgroup, four round trips
+// of four chunks), and the sum sits in front of the main loop, whose accumulators it opens, with nothing to hide behind.
 template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4, bool WTWOS = false, bool XAPART = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   static_assert(MT == 4 || MT == 2, "128- or 64-row tiles");
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
           for (int u = 0; u < FB; ++u) add(pv[2 * (FB * j + u)], pv[2 * (FB * j + u) + 1], live && u < g.xa_nchunk);
           const int rowc = m0 + row < xa_rows ? m0 + row : xa_rows - 1;
           const float* src = g.xa_part + (int64_t)rowc * g.rp + p0 + 8 * ch;
-          for (int cc = FB; cc < g.xa_nchunk; cc += 4) {  // K > 4096 (or two items): four more chunks per round trip
+          for (int cc = FB; cc < g.xa_nchunk; cc += 4) {  // one chunk per 256 k: four more chunks per round trip
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

@@ -93,9 +93,9 @@ def test_forced_64_row_tiles_and_xcd_blocks_give_the_same_bits(lq):
 
 
 PARTIAL_CASES = [  # M, K, N, rank, bias, B_out, dtype
-    (2048, 4096, 4096, 32, False, "mx", torch.float16),   # C2: four chunks, one item per thread
+    (2048, 4096, 4096, 32, False, "mx", torch.float16),   # C2: sixteen chunks (one per 256 k), one item per thread
     (300, 1100, 520, 20, True, "mx", torch.bfloat16),     # ragged M / K / N, padded rank, bias (128-row tiles pinned)
-    (1500, 11008, 512, 32, False, "mx", torch.float16),   # eleven chunks: three round trips
+    (1500, 11008, 512, 32, False, "mx", torch.float16),   # 43 chunks
     (640, 2048, 768, 64, True, "mx", torch.bfloat16),     # rank 64: two items per thread, two chunks each up front
     (513, 1024, 1024, 48, False, "pass", torch.float16),  # padded rank 48, B_out pass-through
 ]
