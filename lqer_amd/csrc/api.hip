@@ -147,6 +147,25 @@ static bool passthrough_width_ok(const lqer_qfmt_t& f, const char* name) {
 }  // namespace lqer
 
 using namespace lqer;
+#ifdef LQER_HOST_TIMING  // diagnostic build: host nanoseconds between marks of lqer_linear_forward, printed at exit
+#include <ctime>
+namespace {
+struct FwdT {
+  double seg[8] = {0}; long n = 0; timespec last;
+  void start() { clock_gettime(CLOCK_MONOTONIC, &last); }
+  void mark(int i) { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); seg[i] += (t.tv_sec - last.tv_sec) * 1e9 + (t.tv_nsec - last.tv_nsec); last = t; }
+  ~FwdT() { if (n) { fprintf(stderr, "[forward host] calls %ld:", n); for (int i = 0; i < 8; ++i) fprintf(stderr, " seg%d %.0f ns", i, seg[i] / n); fprintf(stderr, "\n"); } }
+};
+FwdT fwd_t;
+}
+#define HT_START() fwd_t.start()
+#define HT_MARK(i) fwd_t.mark(i)
+#define HT_DONE() (fwd_t.n++)
+#else
+#define HT_START()
+#define HT_MARK(i)
+#define HT_DONE()
+#endif
 
 extern "C" {
 static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, GemmArgs& g);
@@ -546,9 +565,11 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
     set_error("linear_forward: null descriptor");
     return LQER_E_INVALID;
   }
+  HT_START();
   lqer_linear_sizes_t sz;
   int rc = lqer_linear_sizes(d, M, &sz);
   if (rc) return rc;
+  HT_MARK(0);
   lqer_linear_desc_t plain;
   if (x_is_i8(d) && lqer_gemm_route(d, M, dtype) != LQER_ROUTE_TILE256_I8) {
     // token counts the int8 tile kernel does not serve run the bf16 kernels on the sign-magnitude image (same buffers)
@@ -566,11 +587,15 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   void* xq = ws;
   const size_t rp = lqer_padded_r(d->rank);
   const size_t xl = act_limbs(d), al = xa_limbs(d);
+  HT_MARK(1);
   if (dtype == LQER_F16 && f16_image_is_input(d, x, M, ldx)) xq = const_cast<void*>(x);  // no copy (never written)
+  HT_MARK(2);
   void* xaq = ws + align_up(Mp * Kp * 2 * xl, 256);
   void* xa_scratch = ws + align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256);
   if (decode_partials_ok(d, M) && a_t && b_t) {
+    HT_MARK(3);
     const size_t nscr = lqer_lowrank_xa_scratch_bytes(d, M);
+    HT_MARK(4);
 #ifndef LQER_NO_DECODE1
     // up to 8 tokens: ONE launch (decode1.hip) - producer workgroups publish the partial tiles of x A, the weight-streaming
     // workgroups quantize x themselves and pick the tiles up at their very end
@@ -583,6 +608,7 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
       memset(&g, 0, sizeof(g));
       rc = gemm_shape_args(d, M, dtype, g);
       if (rc) return rc;
+      HT_MARK(5);
       g.wp = (const uint8_t*)w_packed;
       g.bt = (const bf16_t*)b_t;
       g.bias = d->has_bias ? bias_q : nullptr;
@@ -594,6 +620,8 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
       const DecodeMember one{g.wp, g.bt, g.bias, g.y, g.ldy, g.N, g.Np, g.rp, g.b_limbs};
       rc = decode1_dispatch(g, dtype, x, ldx, d->in_features, make_qp(d->x_fmt), (const bf16_t*)a_t, bout, &one, 1, xa_scratch, nscr,
                             (hipStream_t)stream);
+      HT_MARK(6);
+      HT_DONE();
       if (rc != LQER_E_UNSUPPORTED) return rc;
     }
 #endif

@@ -30,6 +30,9 @@
 #include <atomic>
 #include <type_traits>
 
+#include <cstdio>
+#include <ctime>
+
 #include "common.h"
 
 namespace lqer {
@@ -700,6 +703,9 @@ size_t decode1_scratch_bytes(int64_t Kp, int rp) { return (size_t)((Kp + d1::SLA
 // concatenation of their A^T images along the rank.  Returns LQER_E_UNSUPPORTED when the shape is outside.
 int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, const QP& qx, const bf16_t* a_t, int bout,
                      const DecodeMember* mem, int nmem, void* scratch, size_t scratch_bytes, hipStream_t st) {
+#ifdef LQER_HOST_TIMING
+  timespec ht0; clock_gettime(CLOCK_MONOTONIC, &ht0);
+#endif
   if (g.M < 1 || g.M > d1::MAXM || nmem < 1 || nmem > d1::MAXMEM || bout > 1 || K % 16 != 0) return LQER_E_UNSUPPORTED;
   d1::Args<d1::MAXMEM> a;
   int rp_all = 0, blocks = 0;
@@ -751,6 +757,14 @@ int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, c
   a1.mem[0] = a.mem[0];
   a1.M = a.M, a1.Kp = a.Kp, a1.aout = a.aout, a1.bout = a.bout, a1.nmem = 1, a1.rp_all = a.rp_all, a1.x = a.x, a1.ldx = a.ldx, a1.K = a.K,
   a1.qx = a.qx, a1.a_t = a.a_t, a1.gran = a.gran, a1.nonce = a.nonce, a1.np = a.np, a1.spin = a.spin, a1.cpw = a.cpw;
+#ifdef LQER_HOST_TIMING  // diagnostic build: host nanoseconds before / inside the launch call, printed at exit
+  struct HostT {
+    double pre = 0, launch = 0; long n = 0;
+    ~HostT() { if (n) fprintf(stderr, "[decode1 host] calls %ld: dispatch before launch %.0f ns, launch call %.0f ns\n", n, pre / n, launch / n); }
+  };
+  static HostT host_t;
+  timespec ht1; clock_gettime(CLOCK_MONOTONIC, &ht1);
+#endif
 #define D1_LAUNCH(DT, BO)                                                                     \
   do {                                                                                        \
     if (nmem > 1) {                                                                           \
@@ -770,6 +784,14 @@ int decode1_dispatch(GemmArgs g, int dtype, const void* x, int64_t ldx, int K, c
     default: set_error("unknown dtype %d", dtype); return LQER_E_INVALID;
   }
 #undef D1_LAUNCH
+#ifdef LQER_HOST_TIMING
+  {
+    timespec ht2; clock_gettime(CLOCK_MONOTONIC, &ht2);
+    host_t.pre += (ht1.tv_sec - ht0.tv_sec) * 1e9 + (ht1.tv_nsec - ht0.tv_nsec);
+    host_t.launch += (ht2.tv_sec - ht1.tv_sec) * 1e9 + (ht2.tv_nsec - ht1.tv_nsec);
+    host_t.n++;
+  }
+#endif
   return check_launch("lqer_decode1");
 }
 
