@@ -281,7 +281,12 @@ constexpr int ROWS = 128, BKB = 128;  // token rows per workgroup, activation by
 constexpr int X_SLOT = ROWS * BKB;    // 16 KiB
 typedef __attribute__((address_space(3))) void lds_void;
 constexpr int a_row_bytes(bool i8) { return i8 ? 256 : 128; }
-constexpr int lds_bytes(int nt, bool i8) { return 3 * (X_SLOT + 32 * nt * a_row_bytes(i8)); }
+#ifndef LQER_XAL_SLOTS
+#define LQER_XAL_SLOTS 3
+#endif
+constexpr int NS = LQER_XAL_SLOTS, AHEAD = NS - 1;  // ring slots; steps in flight ahead of the one being multiplied (a fourth slot -
+                                                 // 96 KB per CU in flight - measured +-0 at C4 and C5: tools/ab_xa.py)
+constexpr int lds_bytes(int nt, bool i8) { return NS * (X_SLOT + 32 * nt * a_row_bytes(i8)); }
 
 template <int NT, bool I8>  // 32-column rank tiles: rp = 32 NT
 __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restrict__ xq, int64_t x_ld, const bf16_t* __restrict__ a_img,
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
     }
   }
   auto issue = [&](int st) {
-    const int slot = st % 3;
+    const int slot = st % NS;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + slot * SLOT + (wave * 4 + i) * 1024), 16, x_voff[i], st * BKB, 0, 0);
@@ -356,17 +361,24 @@ __global__ __launch_bounds__(256) void k_xa_partial_lds(const uint8_t* __restric
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  issue(s_begin);
-  if (s_begin + 1 < s_end) issue(s_begin + 1);
+#pragma unroll
+  for (int d = 0; d < AHEAD; ++d)
+    if (s_begin + d < s_end) issue(s_begin + d);
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
   const h2 bias = {(_Float16)-1152.0f, (_Float16)-1152.0f};
   for (int st = s_begin; st < s_end; ++st) {
-    // own loads of step st landed (the batch of st + 1 may stay in flight), then everybody's
-    if (st + 1 < s_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NA) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // own loads of step st landed (the batches of the steps behind it - up to AHEAD - 1 - may stay in flight), then everybody's
+    {
+      const int younger = s_end - 1 - st < AHEAD - 1 ? s_end - 1 - st : AHEAD - 1;  // (workgroup-uniform)
+      static_assert(AHEAD >= 2 && AHEAD <= 4, "counted waits below");
+      if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (4 + NA)) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (4 + NA)) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     asm volatile("s_barrier" ::: "memory");  // (also: every wave has finished its reads of step st - 1, whose slot is filled next)
-    if (st + 2 < s_end) issue(st + 2);
-    const uint32_t so = (uint32_t)((st % 3) * SLOT);
+    if (st + AHEAD < s_end) issue(st + AHEAD);
+    const uint32_t so = (uint32_t)((st % NS) * SLOT);
     // (asm: hipcc would put vmcnt(0) in front of LDS reads it can see while an LDS-DMA is in flight; every read's result is
     // pinned behind the lgkmcnt(0) below by a "+v" operand)
     u32x4 xr[4];
