@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """Randomised parity sweep: LinearFlexibleLqer forward on the GPU vs the CPU oracle over random shapes, ranks, dtypes
 and quantizer configurations (MXINT blocks of 16, OPT-style bias blocks, the INT configuration, pass-through B_out,
-the INT templates as shipped = pass-through activations on the fp16 or the bf16-limb route, no side path).  Shapes are drawn to reach all three GEMM kernels (small-M, 128-row tiles, 256-row tiles).
+the INT templates as shipped = pass-through activations on the fp16 or the bf16-limb route, no side path; round 4: 4-bit
+`integer` weights, the int8 route with weight groups spread over several binades - every MODE of the int8 weight image -,
+the GEMM summing the partial tiles of x A itself, and at M <= 8 the q/k/v group launch against its members).  Shapes are
+drawn to reach every GEMM kernel (small-M / one-launch decode, 128- and 64-row tiles, 256-row tiles bf16 and int8).
 usage: python tools/fuzz_parity.py [cases] [seed]"""
 import os, random, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lqer_amd
-from bench import A16_Q, INT_Q, MXINT_Q, OPT_Q, make_case
+from bench import A16_Q, INT_Q, INTROW_Q, MXINT_Q, OPT_Q, make_case
 from oracle import lqer_oracle as O
 
 
 def one_case(rng):
-    kind = rng.choice(["small", "small", "tile", "tile", "tile", "m256"])
+    kind = rng.choice(["small", "small", "tile", "tile", "tile", "m256", "i8"])
+    if kind == "i8":  # the int8 tile kernel: M >= 512, per-token x, weight blocks of 128 (or whole rows) whose exponents spread
+        return (rng.choice([512, 768, 1024, 1300]), rng.choice([256, 384, 640, 1024]), rng.choice([256, 300, 512, 1024]),
+                rng.choice([0, 16, 32, 64]), rng.choice(["i8spread0", "i8spread2", "i8spread4", "i8spread7", "i8row"]), torch.float16)
     if kind == "small":
         M = rng.randint(1, 64)
     elif kind == "tile":
@@ -22,7 +28,7 @@ def one_case(rng):
     K = rng.choice([16, 48, 64, 100, 176, 256, 320, 520, 1000])
     N = rng.choice([16, 40, 160, 256, 300, 1024, 1500]) if kind != "m256" else rng.choice([8192, 16384 + 256])
     r = rng.choice([0, 8, 16, 32, 48, 64, 96, 128])
-    cfgname = rng.choice(["mxint", "opt", "int", "bout_pass", "a16", "a16", "a16mix", "tile"])
+    cfgname = rng.choice(["mxint", "opt", "int", "bout_pass", "a16", "a16", "a16mix", "tile", "intw", "xa_in_gemm", "group"])
     dtype = rng.choice([torch.float16, torch.float16, torch.bfloat16, torch.float32])
     if kind == "m256":
         K = rng.choice([64, 128, 200, 320, 520, 1000])
@@ -32,12 +38,25 @@ def one_case(rng):
 
 
 def run_case(M, K, N, r, cfgname, dtype, dev):
-    qc = {"mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q, "bout_pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"}),
+    i8 = cfgname.startswith("i8")
+    if cfgname == "group":
+        return run_group(M, K, N, r, dtype, dev)
+    qc = {"i8spread0": INT_Q, "i8spread2": INT_Q, "i8spread4": INT_Q, "i8spread7": INT_Q, "i8row": INTROW_Q, "xa_in_gemm": MXINT_Q,
+          "intw": dict(MXINT_Q, w_quantizer=dict(name="integer", width=4, frac_width=1 + (M + K) % 4, is_signed=True)),
+          "mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q, "bout_pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"}),
           "a16": A16_Q, "a16mix": dict(A16_Q, B_out_quantizer=MXINT_Q["x_quantizer"]),
           "tile": dict(MXINT_Q, w_quantizer=dict(MXINT_Q["w_quantizer"], block_size=[(M % 3 + 1) * 4, 16 * (K % 2 + 1)]))}[cfgname]
     bias = cfgname == "opt"
-    case = make_case(M, K, N, max(r, 1), seed=M * 7919 + K * 31 + N, bias=bias, quantize_ab=cfgname not in ("int", "a16", "a16mix"))
+    case = make_case(M, K, N, max(r, 1), seed=M * 7919 + K * 31 + N, bias=bias, quantize_ab=cfgname not in ("int", "a16", "a16mix") and not i8)
     x, W, A, B = case[:4]
+    if cfgname.startswith("i8spread"):  # per (row, 128-k group) scales 2^[0..spread]: PRESHIFT1 / PRESHIFT / FOLD tiles; some rows plain
+        spread = int(cfgname[-1])
+        g = torch.Generator().manual_seed(M + K + N)
+        e = torch.randint(0, spread + 1, (N, (K + 127) // 128), generator=g)
+        e[: N // 3] = 0
+        W = W * torch.pow(2.0, -e.float()).repeat_interleave(128, dim=1)[:, :K]
+    if cfgname == "intw":
+        W = W * 40.0  # (fixed point: the codes must leave zero)
     b = case[4] if bias else None
     if r == 0:
         cls, lc, qcm = lqer_amd.LinearFlexible, None, dict(qc, name="flexible")
@@ -52,6 +71,9 @@ def run_case(M, K, N, r, cfgname, dtype, dev):
     mod.load_state_dict(sd)
     mod = mod.to(dev).to(dtype)
     mod.a16_native = (M + K + N) % 3 != 0  # pass-through fp16 activations: mostly the fp16 route, sometimes bf16 limbs
+    if cfgname == "xa_in_gemm":
+        from lqer_amd import _lib
+        mod.tuning = _lib.TUNE_XA_REDUCE_IN_GEMM | (_lib.TUNE_TILE_ROWS_128 if M % 2 else 0)
     xin = x.to(dtype)
     y = mod(xin.to(dev)).float().cpu()
     cast = lambda t: None if t is None else t.to(dtype).float()
@@ -59,6 +81,38 @@ def run_case(M, K, N, r, cfgname, dtype, dev):
     err = float((y - ref).norm() / ref.norm().clamp_min(1e-30))
     tol = {torch.float16: 1e-3, torch.bfloat16: 6e-3, torch.float32: 3e-5}[dtype]
     return err, tol
+
+
+def run_group(M, K, N, r, dtype, dev):
+    """q/k/v handed the same tokens at a decode size: the group launch against the members one by one (bit-identical), and
+    member 0 against the oracle."""
+    from lqer_amd.linear import SharedActivation
+
+    M = 1 + M % 8
+    K = max(64, K // 16 * 16)
+    r = r if 0 < r <= 32 else 16
+    dtype = torch.float16 if dtype == torch.float32 else dtype
+    mods, cases = [], []
+    for i, n in enumerate((N, max(16, N // 2), N)):
+        case = make_case(M, K, n, r, seed=M * 7919 + K * 31 + n + i)
+        x, W, A, B = case[:4]
+        m = lqer_amd.LinearFlexibleLqer(K, n, bias=False, q_config=MXINT_Q, l_config={"rank": r})
+        m.load_state_dict({"weight": W, "A": A, "B": B})
+        mods.append(m.to(dev).to(dtype))
+        cases.append((W, A, B))
+    x = make_case(M, K, 16, r, seed=5)[0].to(dtype)
+    xd = x.to(dev)
+    alone = [m(xd).clone() for m in mods]
+    SharedActivation(mods)
+    together = [m(xd).clone() for m in mods]
+    for a, t in zip(alone, together):
+        if not torch.equal(a, t):
+            return float("inf"), 0.0
+    cast = lambda t: t.to(dtype).float()
+    W, A, B = cases[0]
+    ref = O.lqer_linear_forward(x.float(), cast(W), None, cast(A), cast(B), MXINT_Q)
+    err = float((together[0].float().cpu() - ref).norm() / ref.norm().clamp_min(1e-30))
+    return err, {torch.float16: 1e-3, torch.bfloat16: 6e-3}[dtype]
 
 
 def main():
