@@ -153,6 +153,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave;  // 8 waves side by side along n: each owns all 128 token rows x 32 output columns
   const int l31 = lane & 31, lh = lane >> 5;
+#ifdef LQER_CLOCKPROBE
+  unsigned long long cp_rin;  // diagnostic build: the chip-wide 100 MHz counter at the wave's entry
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_rin)::"memory");
+#endif
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD; give each XCD a contiguous tile range.
   const int nt = g.tiles_m * g.tiles_n;
@@ -610,6 +614,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     if (g_stamp_buf && lane == 0) {
       g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 0] = cp_c1 - cp_c0;
       g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 1] = cp_r1 - cp_r0;
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 2] = cp_rin;  // absolute ticks: entry, main loop start, main loop end
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 3] = cp_r0;
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 4] = cp_r1;
     }
   }
 #endif
@@ -690,6 +697,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       }
     }
   }
+#ifdef LQER_CLOCKPROBE
+  {
+    unsigned long long cp_r2, cp_r3;  // stores issued; stores acknowledged
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_r2)::"memory");
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_r3)::"memory");
+    if (g_stamp_buf && lane == 0) {
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 5] = cp_r2;
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 6] = cp_r3;
+    }
+  }
+#endif
 }
 
 // Pre-pass for B_out blocks other than 16 columns: max |xAq @ B| over every (token row, block of L columns),

@@ -33,3 +33,15 @@ steps = K // 64
 clk = (cyc / rt * 100e6).median().item()
 print(f"K={K}: kernel {e0.elapsed_time(e1) / 100 * 1e3:.2f} us; main loop {cyc.median().item():.0f} cycles = "
       f"{cyc.median().item() / steps:.0f} cycles per k-step, {rt.median().item() / 100:.2f} us; in-kernel clock {clk / 1e9:.3f} GHz")
+
+# timeline on the chip-wide 100 MHz counter (10 ns ticks), relative to the first wave's entry of the LAST launch
+ab = buf.cpu().view(256, 8, 8)[:, :, 2:7].double()
+t0 = ab[:, :, 0].min().item()
+us = lambda t: (t - t0) / 100.0
+q = lambda t, p: torch.quantile(t.flatten(), p).item()
+names = ["entry", "main loop starts", "main loop ends", "stores issued", "stores acknowledged"]
+for i, nm in enumerate(names):
+    col = ab[:, :, i]
+    print(f"  {nm:20s} median {us(q(col, 0.5)):7.2f} us   first {us(col.min().item()):7.2f}   last {us(col.max().item()):7.2f}")
+print(f"  per wave: prologue {q(ab[:, :, 1] - ab[:, :, 0], 0.5) / 100:.2f} us, main loop {q(ab[:, :, 2] - ab[:, :, 1], 0.5) / 100:.2f} us, "
+      f"convert + store issue {q(ab[:, :, 3] - ab[:, :, 2], 0.5) / 100:.2f} us, store drain {q(ab[:, :, 4] - ab[:, :, 3], 0.5) / 100:.2f} us")
