@@ -22,8 +22,14 @@ for i in range(n):
     g = torch.Generator().manual_seed(seed * 1000 + i)
     x = (torch.randn(b, S1, K, generator=g) * 2).to(dt).to(dev)
     y = (torch.randn(b, S2, K, generator=g).transpose(1, 2) if tr else torch.randn(b, K, S2, generator=g)).to(dt).to(dev)
-    got = lqer_amd.matmul_flexible(x, y, qc).float()
-    ref = torch.matmul(F._quantize(x, dict(qc["x_quantizer"])).float(), F._quantize(y, dict(qc["w_quantizer"])).float())
+    # (round 4) blocks other than 16 - 32, 64, 48 or the whole row, independently per operand - take the pre-quantized images
+    import copy
+    qcc = copy.deepcopy(qc)
+    bx, by = rng.choice([16, 16, 32, 64, 48, -1]), rng.choice([16, 16, 32, 64, -1])
+    qcc["x_quantizer"]["block_size"] = [1, bx]
+    qcc["w_quantizer"]["block_size"] = [1, by]
+    got = lqer_amd.matmul_flexible(x, y, qcc).float()
+    ref = torch.matmul(F._quantize(x, dict(qcc["x_quantizer"])).float(), F._quantize(y, dict(qcc["w_quantizer"])).float())
     err = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
     tol = {torch.float16: 1e-3, torch.bfloat16: 6e-3, torch.float32: 1e-6}[dt]
     ok = err <= tol
