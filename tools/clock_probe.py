@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel clock of the GEMM main loop: a -DLQER_CLOCKPROBE build stamps s_memtime (shader cycles) and
 s_memrealtime (100 MHz) around the loop of every wave.  Runs >= 2 s of back-to-back launches first (DVFS settles),
-then reports cycles per k-step and the sustained clock.  usage: clock_probe.py lib_CLOCKPROBE.so [K]"""
+then reports cycles per k-step, the sustained clock and the launch's timeline.  usage: clock_probe.py lib_CLOCKPROBE.so [K [rank]]"""
 import ctypes as C, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ from tools.ab_gemm import load
 L = load(sys.argv[1])
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 L.lqer_debug_set_stamp_buffer.argtypes = [C.c_void_p]
-M, N, r = 2048, 4096, 32
+M, N, r = 2048, 4096, (int(sys.argv[3]) if len(sys.argv) > 3 else 32)
 dev = torch.device("cuda:0")
 buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
 assert L.lqer_debug_set_stamp_buffer(buf.data_ptr()) == 0
