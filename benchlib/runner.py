@@ -411,7 +411,8 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     # decode workloads (M <= 8): the Linears a model hands the SAME token to - q/k/v - as ONE launch (lqer_linear_forward_group)
     group_fig = None
     if one_launch and layers == 1 and len(live) == 1 and world == 1 and graph is None and not shard_n:
-        group_fig = _decode_group_region(ctx, live[0], M, r, has_bias, rotate, warmup, steps, ev_flags)
+        group_fig = _decode_group_region(ctx, live[0], M, r, has_bias, rotate, warmup, steps, ev_flags,
+                                         n_members=int(os.environ.get("LQER_BENCH_GROUP_MEMBERS", "3")))  # (2..4: probe of the group size)
 
     # ---- gather (outside the timed regions): per-rank elapsed time, a checksum of the first unit's output
     ysum = float(live[0][5].float().sum().item()) if live else 0.0
