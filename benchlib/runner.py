@@ -551,7 +551,10 @@ def _shared_inputs_region(ctx, live, layers_here, warmup, steps, elapsed):
                     solo, solo_n = mod, cnt
             units.append((members, solo, solo_n, xd))
         if not any(members for members, _, _, _ in units):
-            return None
+            # (C5: q/k/v at rank 128 concatenate to a padded rank of 384 > the side GEMM's 256.  Measured in round 4 with the
+            # group cut into chunks that share one quantized image: 1.613 vs 1.581 ms per two layers - the side GEMM on the
+            # image costs what the fused quantizer + side GEMM costs, so such groups stay disabled)
+            return {"error": "no group applies (padded ranks of q/k/v sum to more than 256: sharing measured slower, NOTEBOOK.md section 9.2)"}
 
         def step_shared():
             for _ in range(layers_here):
