@@ -537,6 +537,7 @@ def _shared_inputs_region(ctx, live, layers_here, warmup, steps, elapsed):
 
     try:
         units = []  # per shape: (group members, solo module or None, solo calls per layer, x)
+        refused = False  # a shape with q/k/v or gate/up whose group is disabled
         for mod, xd, K, N, reps, _, _, _ in live:
             cnt = reps // layers_here
             gsz = 3 if (cnt >= 3 and K == N) else (2 if cnt == 2 else 0)
@@ -549,7 +550,10 @@ def _shared_inputs_region(ctx, live, layers_here, warmup, steps, elapsed):
                 members = grp.members if grp.enabled else []
                 if not grp.enabled:
                     solo, solo_n = mod, cnt
+                    refused = True
             units.append((members, solo, solo_n, xd))
+        if not any(members for members, _, _, _ in units) and not refused:
+            return None
         if not any(members for members, _, _, _ in units):
             # (C5: q/k/v at rank 128 concatenate to a padded rank of 384 > the side GEMM's 256.  Measured in round 4 with the
             # group cut into chunks that share one quantized image: 1.613 vs 1.581 ms per two layers - the side GEMM on the
