@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 10
+#define LQER_ABI_VERSION 11
 
 /* error codes */
 #define LQER_OK 0
@@ -62,8 +62,10 @@ extern "C" {
                         exp_width = is_signed (1 / 0); block is ignored.  Implemented for the x, b and A_out quantizers (width
                         <= 9 signed / 8 unsigned, so that every value is a bf16 number), for B_out (any width <= 24: applied to
                         the fp32 side product inside the tile kernels' prologues - the reference's fall-back when x_quantizer is
-                        integer, linear.py:115-119; decode sizes then take the tile kernel) and in lqer_quantize_mxint; a 4-bit
-                        integer WEIGHT (codes -8..7) does not fit the sign-magnitude weight image: LQER_E_UNSUPPORTED */
+                        integer, linear.py:115-119; decode sizes then take the tile kernel) and in lqer_quantize_mxint; as
+                        w_quantizer: signed, width 2..4 - the codes -8..7 travel as two's-complement nibbles in the same panels
+                        (lqer_pack_weight_mxint; the 128-row tile kernel at every token count); unsigned or wider integer
+                        weights: LQER_E_UNSUPPORTED */
 
 /* Geometry of the packed operands (fixed by the kernels; exported so callers can size buffers). */
 #define LQER_K_ALIGN 64     /* K is zero-padded to a multiple of this                        */
@@ -127,6 +129,13 @@ typedef struct lqer_linear_sizes {
 
 int lqer_version(void);
 const char* lqer_last_error(void);
+/* sizeof of the structs above as THIS library was compiled: a binding in another language asserts its own layouts against
+ * these once (the library reads sizeof(lqer_linear_desc_t) bytes behind a descriptor pointer - a shorter struct is undefined
+ * behaviour).  INTEGRATION.md section B's ctypes stub does; tests/test_abi_cpu.py executes that stub against the library. */
+size_t lqer_sizeof_qfmt(void);
+size_t lqer_sizeof_linear_desc(void);
+size_t lqer_sizeof_linear_sizes(void);
+size_t lqer_sizeof_group_member(void);
 
 /* Padded extents used by the packed buffers. */
 int64_t lqer_padded_k(int64_t K);

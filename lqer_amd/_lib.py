@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
@@ -60,6 +60,10 @@ _qp, _dp = C.POINTER(QFmt), C.POINTER(LinearDesc)
 SIGNATURES = {
     "lqer_version": (_i, []),
     "lqer_last_error": (C.c_char_p, []),
+    "lqer_sizeof_qfmt": (_sz, []),
+    "lqer_sizeof_linear_desc": (_sz, []),
+    "lqer_sizeof_linear_sizes": (_sz, []),
+    "lqer_sizeof_group_member": (_sz, []),
     "lqer_padded_k": (_i64, [_i64]),
     "lqer_padded_n": (_i64, [_i64]),
     "lqer_padded_m": (_i64, [_i64]),

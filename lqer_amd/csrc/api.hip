@@ -184,6 +184,10 @@ static bool tile_partials_ok(const lqer_linear_desc_t* d, int64_t M, int dtype) 
 }
 
 int lqer_version(void) { return LQER_ABI_VERSION; }
+size_t lqer_sizeof_qfmt(void) { return sizeof(lqer_qfmt_t); }
+size_t lqer_sizeof_linear_desc(void) { return sizeof(lqer_linear_desc_t); }
+size_t lqer_sizeof_linear_sizes(void) { return sizeof(lqer_linear_sizes_t); }
+size_t lqer_sizeof_group_member(void) { return sizeof(lqer_group_member_t); }
 const char* lqer_last_error(void) { return g_err; }
 
 int64_t lqer_padded_k(int64_t K) { return (K + LQER_K_ALIGN - 1) / LQER_K_ALIGN * LQER_K_ALIGN; }
@@ -666,6 +670,21 @@ int lqer_linear_forward_group(const lqer_group_member_t* members, int n_members,
             (ldx * esz) % 16 == 0 && ((uintptr_t)workspace & 15) == 0;
   DecodeMember mem[4];
   int64_t rp_all = 0;
+  // malformed members are errors, not "outside the route" (what lqer_linear_forward gets from lqer_linear_sizes / gemm_shape_args)
+  for (int i = 0; i < n_members && i < 4; ++i) {
+    const lqer_linear_desc_t* d = members[i].desc;
+    if (!d || d->in_features <= 0 || d->out_features <= 0 || d->rank < 0) {
+      set_error("linear_forward_group: member %d: bad descriptor", i);
+      return LQER_E_INVALID;
+    }
+    if (!fmt_ok(&d->w_fmt, "w_quantizer", 4) || !fmt_ok(&d->x_fmt, "x_quantizer", 9) || !fmt_ok(&d->a_out_fmt, "A_out_quantizer", 9) ||
+        !fmt_ok(&d->b_out_fmt, "B_out_quantizer", 24))
+      return LQER_E_UNSUPPORTED;
+    if (d->has_bias && !members[i].bias_q) {
+      set_error("linear_forward_group: member %d: has_bias = 1 but bias_q == NULL", i);
+      return LQER_E_INVALID;
+    }
+  }
   for (int i = 0; ok && i < n_members; ++i) {
     const lqer_group_member_t& m = members[i];
     const lqer_linear_desc_t* d = m.desc;

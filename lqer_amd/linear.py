@@ -363,19 +363,29 @@ class _LinearBase(nn.Linear):
                 return self._forward_on_current_device(x)
         return self._forward_on_current_device(x)
 
-    def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
-        if self._packed is not None and not self._packed_only:
+    def _written_in_place(self) -> bool:
+        """True (after dropping the images concerned) when `weight` / `bias` were written in place since their images were
+        built - the version check every forward runs; a decode group runs it for EVERY member before it launches."""
+        if self._packed is None or self._packed_only:
             # (images of a packed checkpoint are the only copy of the operands: its dense parameters are never consulted)
-            prm = self._parameters
-            bias_p = prm["bias"]
-            cur = (prm["weight"]._version, None if bias_p is None else bias_p._version)
-            if self._w_ver is None:  # first forward after copy.deepcopy / unpickling: the copied images belong to these parameters
-                self._w_ver = cur
-            elif cur != self._w_ver:  # the dense parameters were written in place since their images were built
-                # (a bias that was NOT written already holds b_quantizer(bias): it must not be quantized a second time)
-                keep_bias = self._bias_q if cur[1] == self._w_ver[1] else None
-                self.invalidate_packed(weight_changed=cur[0] != self._w_ver[0], bias_changed=cur[1] != self._w_ver[1])
-                self._bias_q = keep_bias
+            return False
+        prm = self._parameters
+        bias_p = prm["bias"]
+        cur = (prm["weight"]._version, None if bias_p is None else bias_p._version)
+        if self._w_ver is None:  # first forward after copy.deepcopy / unpickling: the copied images belong to these parameters
+            self._w_ver = cur
+            return False
+        if cur == self._w_ver:
+            return False
+        # the dense parameters were written in place since their images were built
+        # (a bias that was NOT written already holds b_quantizer(bias): it must not be quantized a second time)
+        keep_bias = self._bias_q if cur[1] == self._w_ver[1] else None
+        self.invalidate_packed(weight_changed=cur[0] != self._w_ver[0], bias_changed=cur[1] != self._w_ver[1])
+        self._bias_q = keep_bias
+        return True
+
+    def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
+        self._written_in_place()
         if self._packed is None or self.w_is_quantized is False:
             self._pack()
         K, N = self.in_features, self.out_features
@@ -475,6 +485,7 @@ class SharedActivation:
         # decode sizes (M <= 8): ONE launch for the whole group (lqer_linear_forward_group)
         self._dplans = {}     # (M, dtype) -> member table of the group launch, or None when the C ABI refuses the group
         self._dx, self._dver = None, -1   # the tensor the current outputs were computed from
+        self._dstream = None  # ... and the stream they were launched on
         self._dys = None      # outputs of the current round, one per member
         self._dserved = set()
         if self.enabled:
@@ -492,12 +503,14 @@ class SharedActivation:
         # pointers of THIS group's members and of the shared pool - the copy rebuilds them at its first call
         st = self.__dict__.copy()
         st.update(_cat=None, _x=None, _cur=None, _served=set(), _plans={}, _ver=-1, _dplans={}, _dx=None, _dys=None, _dserved=set(),
-                  _dver=-1)
+                  _dver=-1, _dstream=None)
         return st
 
     @classmethod
     def release_pool(cls):
-        """Free the shared image pools of every (device, stream) - they are grow-only and outlive the models that used them."""
+        """Free the shared image pools of every (device, stream) - they are grow-only and outlive the models that used them.
+        (A group's unfinished decode round keeps its activation and output tensors until the next round starts or
+        `invalidate()` runs.)"""
         cls._pool.clear()
 
     @torch.no_grad()
@@ -529,6 +542,10 @@ class SharedActivation:
         ys = self._dys
         if ys is None or (None if x.is_inference() else x._version) != self._dver:
             return None
+        # the outputs were written on the stream that launched the group: a member called on another stream takes the
+        # per-member route (no event, no wait - forward_member keys its pool by (device, stream) for the same reason)
+        if ops._stream(x.device) != self._dstream or not mod.is_ptq:
+            return None
         idx = mod._gidx
         served = self._dserved
         if idx in served:
@@ -551,6 +568,14 @@ class SharedActivation:
         idx = mod._gidx
         M, K = x2.shape
         dtc = ops.dtype_code(x2)
+        # the launch reads EVERY member's images: each member's own in-place-write check (the calling member has just run its
+        # own; a write to k_proj.weight must not leave k / v on the old images - ADVICE r4).  A member that was written drops
+        # its images and, through invalidate_packed, this group's plans.
+        for m in self.members:
+            if m is not mod:
+                if not m.is_ptq:
+                    return None
+                m._written_in_place()
         plan = self._dplans.get((M, dtc), False)
         if plan is None:
             return None
@@ -585,12 +610,12 @@ class SharedActivation:
         if x2.stride(0) < K or (x2.data_ptr() & 15) or (x2.stride(0) * x2.element_size()) % 16:
             return None
         Ns = plan["Ns"]
-        buf = torch.empty(M * sum(Ns), dtype=x.dtype, device=dev)  # one allocation: every member's [M, N_i] lies dense in it
-        ys, off, tab, base, esz, lead = [], 0, plan["tab"], buf.data_ptr(), buf.element_size(), x.shape[:-1]
+        # one tensor per member: a KV cache that keeps k or v must not keep q|k|v alive
+        ys, tab, lead = [], plan["tab"], x.shape[:-1]
         for i, N in enumerate(Ns):
-            ys.append(buf[off: off + M * N].view(*lead, N))
-            tab[i].y = base + off * esz
-            off += M * N
+            yi = torch.empty(*lead, N, dtype=x.dtype, device=dev)
+            ys.append(yi)
+            tab[i].y = yi.data_ptr()
         st = ops._stream(dev)
         ws = ops.workspace_on(dev, st, plan["ws"])
         rc = L.lqer_linear_forward_group(tab, plan["n"], x2.data_ptr(), dtc, M, x2.stride(0) if M > 1 else K, plan["a_t"], 1,
@@ -600,7 +625,7 @@ class SharedActivation:
             return None
         if rc:
             check(rc, "lqer_linear_forward_group")
-        self._dx, self._dver, self._dys, self._dserved = x, ver, ys, {idx}
+        self._dx, self._dver, self._dys, self._dserved, self._dstream = x, ver, ys, {idx}, st
         return ys[idx]
 
     @torch.no_grad()

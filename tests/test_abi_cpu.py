@@ -52,6 +52,40 @@ def test_abi_constants_and_padding(lib):
     assert _lib.LinearDesc(1, 1, 0, 0).tuning == 0  # positional construction without the knob field: defaults
 
 
+def test_struct_sizes_match_the_library(lib):
+    """ABI 11: the library says how large it compiled its structs; the package's binding agrees."""
+    from lqer_amd import _lib
+
+    assert lib.lqer_sizeof_qfmt() == C.sizeof(_lib.QFmt)
+    assert lib.lqer_sizeof_linear_desc() == C.sizeof(_lib.LinearDesc)
+    assert lib.lqer_sizeof_linear_sizes() == C.sizeof(_lib.LinearSizes)
+    assert lib.lqer_sizeof_group_member() == C.sizeof(_lib.GroupMember)
+
+
+def test_integration_stub_layouts_match_the_library(lib):
+    """INTEGRATION.md section B is a ctypes stub a reference maintainer would copy: EXECUTE its struct definitions (and the
+    group stub's) and hold them to the library's own sizeof - the document cannot drift from the header again."""
+    from lqer_amd import _lib
+
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", doc, flags=re.S)
+    stub = next(b for b in blocks if "class LinearDesc(C.Structure)" in b)
+    defs = stub[stub.index("class QFmt"): stub.index("# the library reads sizeof")]
+    ns = {"C": C}
+    exec(defs, ns)  # noqa: S102 - our own document
+    assert C.sizeof(ns["QFmt"]) == lib.lqer_sizeof_qfmt()
+    assert C.sizeof(ns["LinearDesc"]) == lib.lqer_sizeof_linear_desc()
+    assert C.sizeof(ns["LinearSizes"]) == lib.lqer_sizeof_linear_sizes()
+    assert [n for n, _ in ns["LinearDesc"]._fields_] == [n for n, _ in _lib.LinearDesc._fields_]
+    # the stub's own import-time assertion, run against the built library
+    check = stub[stub.index("for _cls, _fn in"): stub.index("def _check")]
+    exec(check, dict(ns, _lib=lib))  # noqa: S102
+    grp = next(b for b in blocks if "class GroupMember(C.Structure)" in b)
+    gdefs = grp[grp.index("class GroupMember"): grp.index("tab = ")]
+    exec(gdefs, ns)  # noqa: S102
+    assert C.sizeof(ns["GroupMember"]) == lib.lqer_sizeof_group_member()
+
+
 def test_sizes_and_argument_errors_without_gpu(lib):
     from lqer_amd import _lib, ops
 
