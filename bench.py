@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the LQER quantized-Linear hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|d1|d16|d1a16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|c2int|c2introw|c3int|d1|d16|d1a16]
                     [--sweep auto|weak|strong] [--shard none|n] [--no-configs] [--no-cpu-baseline] [--no-check] [--no-module]
                     [--graph G] [--prewarm-ms T] [--dry-run-cpu]
 
@@ -67,7 +67,7 @@ from benchlib.workloads import (A16_Q, BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, INT8
                                 make_case, make_weights, make_x)
 
 # one decoder layer of every other BASELINE configuration, carried by the default line: (workload, steps, warm-up steps)
-CONFIG_LAYERS = (("c3", 10, 3), ("c4", 3, 1), ("c5", 10, 3))
+CONFIG_LAYERS = (("c3", 10, 3), ("c3int", 10, 3), ("c4", 3, 1), ("c5", 10, 3))
 
 
 def parse_args(argv=None):

@@ -48,7 +48,7 @@ def _traffic(workload):
 
 def _kernel_names(routes, one_launch, _lib):
     kname = {_lib.ROUTE_SMALLM: "k_decode1 (whole forward)" if one_launch else "k_lqer_gemm_smallm", _lib.ROUTE_TILE128: "k_lqer_gemm",
-             _lib.ROUTE_TILE256: "k_lqer_gemm_m256", _lib.ROUTE_TILE256_I8: "k_lqer_gemm_i8"}
+             _lib.ROUTE_TILE256: "k_lqer_gemm_m256", _lib.ROUTE_I8: "k_lqer_gemm_i8"}
     return "+".join(kname.get(rt, str(rt)) for rt in routes)
 
 

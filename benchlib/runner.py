@@ -178,7 +178,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     ws = ops.workspace(dev, max([ops.linear_sizes(mod._desc(), M).workspace for mod, *_ in live] + [256]))  # one buffer for all
     for mod, xd, K, N, reps, y, _, _ in rot_mods:
         desc = mod._desc()
-        if mod._x_i8 and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) != _lib.ROUTE_TILE256_I8:
+        if mod._x_i8 and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) != _lib.ROUTE_I8:
             desc = mod._desc(plain=True)  # token counts the int8 tile kernel does not serve: the bf16 kernels, same buffers
         p = mod._packed
         Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
@@ -194,7 +194,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         if L.lqer_decode_partials(C.byref(desc), M):
             xaq, gscr = None, nscr  # decode route: the GEMM reduces the partial tiles of x A left in the scratch itself
         a_t, a_limbs = p["a_t"].data_ptr(), p["a_limbs"]
-        if mod._x_i8 and "a_t_f16" in p and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) == _lib.ROUTE_TILE256_I8:
+        if mod._x_i8 and "a_t_f16" in p and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) == _lib.ROUTE_I8:
             a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # the int8 route's side GEMM: A as one fp16 image (as the module passes it)
         # model sweeps: every Linear of the model owns its packed operands (same values, distinct addresses - layers differ
         # in values, not in cost, but a weight that is re-read from the Infinity Cache 32 times is not what a model does)
@@ -458,7 +458,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     cal_x = (live[0][1], live[0][2]) if live else None
     ev_overhead_ms = RL.event_pair_overhead_ms(L, _lib, ops, dev, stream, cal_x, new_pair, M) if live else 0.0
     routes = sorted({pl["route"] for pl in plans})
-    int8 = routes == [_lib.ROUTE_TILE256_I8]  # every GEMM of the step ran the int8 MFMA main loop
+    int8 = routes == [_lib.ROUTE_I8]  # every GEMM of the step ran the int8 MFMA main loop
     rl = RL.mfma_roofline(gemm_events, ev_overhead_ms, M, r, routes, int8, one_launch, _lib, o.workload, ev_flags)
     if M <= 64:
         rl = RL.hbm_roofline(gemm_events, ev_overhead_ms, M, r, has_bias, routes, one_launch, _lib, o.workload, ev_flags, rotate,

@@ -31,11 +31,21 @@ INT8_MFMA_PEAK_TOPS = 5000.0    # 2x bf16 per clock (same guide, "Matrix cores",
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md, HBM3E
 
 LLAMA13B = [(5120, 5120, 4), (5120, 13824, 2), (13824, 5120, 1)]
+LLAMA7B = [(4096, 4096, 4), (4096, 11008, 2), (11008, 4096, 1)]
 WORKLOADS = {
     # name: (description, M, rank, bias, q_config, [(K, N, count per layer)], decoder layers of the model)
     "c2": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=2048 (BASELINE configs[1])", 2048, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
     "c3": ("Llama-7B 7 projections x 32 layers rank32 W4A8-MXINT16 M=2048 (BASELINE configs[2])", 2048, 32, False, MXINT_Q,
            [(4096, 4096, 4), (4096, 11008, 2), (11008, 4096, 1)], 32),
+    # north_star's own shape on the instruction it names: the reference's Llama-7B INT configuration
+    # (sweep_lqer_act_int.sh:81-83: W4 blocks of 128, rank 32; llama-7b-int.toml:87: one block per row) with 8-bit per-token
+    # activations, on the int8 MFMA kernel's 128-row tiles
+    "c2int": ("LqerLinear 4096x4096 rank32 W4(block128)A8(per-token) M=2048 (north_star shape, int8 MFMA)", 2048, 32, False, INT_Q,
+              [(4096, 4096, 1)], 1),
+    "c2introw": ("LqerLinear 4096x4096 rank32 W4(one block per row, llama-7b-int.toml:87)A8(per-token) M=2048", 2048, 32, False,
+                 INTROW_Q, [(4096, 4096, 1)], 1),
+    "c3int": ("Llama-7B 7 projections x 32 layers rank32 W4(block128)A8(per-token) M=2048 (llama-7b-int.toml / "
+              "sweep_lqer_act_int.sh:81-83)", 2048, 32, False, INT_Q, LLAMA7B, 32),
     "c4": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A8(per-token) M=16384 (BASELINE configs[3])", 16384, 64, False,
            INT_Q, LLAMA13B, 40),
     "c4row": ("Llama-13B 7 projections x 40 layers rank64 W4(one block per row, llama-7b-int.toml:87)A8(per-token) M=16384", 16384, 64,

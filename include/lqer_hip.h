@@ -111,6 +111,9 @@ typedef struct lqer_linear_desc {
                                          128-row kernel instead of rows of weight tiles; applied only where the tile grid divides
                                          (16 x 16 tiles: 8, 4 or 16); measured +-0 (the weight stream through every XCD's L2 is
                                          served by the Infinity Cache)                                                        */
+#define LQER_TUNE_I8_ROWS_128 0x4      /* int8 kernel (LQER_ROUTE_I8): always 128-row tiles                                      */
+#define LQER_TUNE_I8_ROWS_256 0x8      /* ... always 256-row tiles; default: whichever takes fewer weighted rounds of one tile per
+                                         CU (lqer_gemm_tile_rows says which)                                                    */
 #define LQER_TUNE_XA_REDUCE_IN_GEMM 0x20000 /* lqer_linear_forward on 128-row tiles: no reduce launch between the quantizer and the
                                          GEMM - its workgroups sum the partial tiles of x A for their own rows (lqer_tile_partials).
                                          Off by default: measured slower (C2: the GEMM grows by 5.3 us, the launch it saves took
@@ -204,7 +207,7 @@ int lqer_pack_bias(const void* bias, int dtype, int64_t N, const lqer_qfmt_t* fm
  * a dense fp16 tensor on the LQER_Q_PASSTHROUGH_F16 route), a fixed-order reduce of the partials with the A_out
  * re-quantization (taken over by the GEMM at decode sizes, lqer_decode_partials), a pre-pass for B_out blocks other
  * than 16 columns, and the fused W4 GEMM with the B side GEMM, B_out re-quantization, bias and add in its prologue.
- * a_limbs = -1 (LQER_Q_MXINT_I8 descriptors at token counts of LQER_ROUTE_TILE256_I8 only; also lqer_quantize_act_xa and
+ * a_limbs = -1 (LQER_Q_MXINT_I8 descriptors at token counts of LQER_ROUTE_I8 only; also lqer_quantize_act_xa and
  * lqer_lowrank_xa): a_t is ONE fp16 image of A^T [padded rank][padded K] as lqer_f16_prepare writes it (its flag for A
  * clear: every element exact in fp16) - the side GEMM then multiplies the int8 mantissas with it on the fp16 MFMA, half
  * the A^T bytes and MFMAs of the two-limb image. */
@@ -253,8 +256,12 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
 #define LQER_ROUTE_SMALLM 0
 #define LQER_ROUTE_TILE128 1
 #define LQER_ROUTE_TILE256 2
-#define LQER_ROUTE_TILE256_I8 3 /* 256 x 256 tiles, int8 MFMA main loop (x_fmt.kind = LQER_Q_MXINT_I8 only) */
+#define LQER_ROUTE_I8 3 /* int8 MFMA main loop (x_fmt.kind = LQER_Q_MXINT_I8 only): 256 x 256 tiles, or 128 x 256 tiles where those
+                           take fewer weighted rounds of one tile per CU (Llama-7B projections at M = 2048) - lqer_gemm_tile_rows */
 int lqer_gemm_route(const lqer_linear_desc_t* desc, int64_t M, int dtype);
+/* Token rows of a tile of the kernel lqer_gemm_route names: 64 / 128 (LQER_ROUTE_TILE128 family), 256 (LQER_ROUTE_TILE256),
+ * 128 / 256 (LQER_ROUTE_I8); 0 for LQER_ROUTE_SMALLM; < 0: the error.  For tests and benchmarks that assert the variant. */
+int lqer_gemm_tile_rows(const lqer_linear_desc_t* desc, int64_t M, int dtype);
 
 /* Decode sizes (launch-bound: each kernel runs ~3 us).  Returns 1 when, for this descriptor and token count, the
  * re-quantized side product never has to be materialised: M <= 64, x and A_out block_fp in blocks of 16 (width <= 9),
@@ -346,8 +353,8 @@ int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t
  *  - the activation image xq is then int8: [Mp][K padded to 128] mantissas followed (256-byte aligned) by Mp fp32 row
  *    scales; never larger than the bf16 image (K >= 128 required), so the workspace carving does not change.
  *  - the split calls lqer_quantize_act_xa / lqer_lowrank_xa / lqer_linear_gemm[_ld] with this kind ALWAYS produce /
- *    consume the int8 images; lqer_gemm_route says whether that is possible for M tokens (LQER_ROUTE_TILE256_I8: M >= 512
- *    and 256-row tiles fill the chip, B_out pass-through or one block per row, padded rank x limbs of x A <= 128);
+ *    consume the int8 images; lqer_gemm_route says whether that is possible for M tokens (LQER_ROUTE_I8: M >= 128,
+ *    B_out pass-through or one block per row, padded rank x limbs of x A <= 128);
  *    otherwise call them with kind LQER_Q_MXINT on the same buffers.  lqer_linear_forward chooses by itself.
  * Requires x_fmt.width <= 8, x_fmt.block <= 0 or >= K, w_fmt.block <= 0, >= K or a multiple of 128. */
 int lqer_i8_prepare(void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* w_fmt, int32_t* flags, void* stream);

@@ -15,8 +15,9 @@ ABI_VERSION = 11
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
-ROUTE_SMALLM, ROUTE_TILE128, ROUTE_TILE256, ROUTE_TILE256_I8 = 0, 1, 2, 3
+ROUTE_SMALLM, ROUTE_TILE128, ROUTE_TILE256, ROUTE_I8 = 0, 1, 2, 3
 TUNE_TILE_ROWS_128, TUNE_TILE_ROWS_64, TUNE_DECODE_NO_POLL, TUNE_XA_REDUCE_IN_GEMM = 0x1, 0x2, 0x10000, 0x20000
+TUNE_I8_ROWS_128, TUNE_I8_ROWS_256 = 0x4, 0x8
 
 
 def tune_xcd_block(t: int) -> int:
@@ -90,6 +91,7 @@ SIGNATURES = {
     "lqer_group_workspace_bytes": (_sz, [_i64, _i64]),
     "lqer_linear_forward_group": (_i, [C.POINTER(GroupMember), _i, _vp, _i, _i64, _i64, _vp, _i, _vp, _sz, _vp]),
     "lqer_gemm_route": (_i, [_dp, _i64, _i]),
+    "lqer_gemm_tile_rows": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),
     "lqer_unpack_weight_i8": (_i, [_vp, _i64, _i64, _vp, _vp]),

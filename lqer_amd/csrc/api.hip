@@ -509,6 +509,25 @@ int lqer_gemm_route(const lqer_linear_desc_t* d, int64_t M, int dtype) {
   return gemm_route(g, d->rank > 0);
 }
 
+int lqer_gemm_tile_rows(const lqer_linear_desc_t* d, int64_t M, int dtype) {
+  if (!d || M < 0) {
+    set_error("gemm_tile_rows: bad argument");
+    return LQER_E_INVALID;
+  }
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  const int rc = gemm_shape_args(d, M, dtype, g);
+  if (rc) return rc;
+  const int route = gemm_route(g, d->rank > 0);
+  if (route < 0) return route;
+  switch (route) {
+    case LQER_ROUTE_SMALLM: return 0;
+    case LQER_ROUTE_TILE256: return 256;
+    case LQER_ROUTE_I8: return i8_tile_rows(g);
+    default: return gemm_tile_rows(g);
+  }
+}
+
 int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
                         int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy,
                         void* scratch, size_t scratch_bytes, void* stream) {
@@ -575,7 +594,7 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   if (rc) return rc;
   HT_MARK(0);
   lqer_linear_desc_t plain;
-  if (x_is_i8(d) && lqer_gemm_route(d, M, dtype) != LQER_ROUTE_TILE256_I8) {
+  if (x_is_i8(d) && lqer_gemm_route(d, M, dtype) != LQER_ROUTE_I8) {
     // token counts the int8 tile kernel does not serve run the bf16 kernels on the sign-magnitude image (same buffers)
     plain = *d;
     plain.x_fmt.kind = LQER_Q_MXINT;

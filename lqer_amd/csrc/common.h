@@ -481,6 +481,7 @@ bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) 
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 bool i8_eligible(const GemmArgs& g, int bout);     // gemm_w4a8_i8.hip: the int8 MFMA main loop (g.w8 set, large M)
 int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
+int i8_tile_rows(const GemmArgs& g);  // 256, or 128 where that takes fewer (weighted) rounds of one tile per CU
 int i8_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, int mbits, void* w_i8, int32_t* flags, hipStream_t st);
 int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16

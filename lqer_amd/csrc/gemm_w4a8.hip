@@ -1068,7 +1068,7 @@ int gemm_route(const GemmArgs& g, bool lowrank) {
       const int L = (g.bout.block <= 0 || g.bout.block >= g.N) ? g.Np : g.bout.block;
       t.bout_nblk = (g.Np + L - 1) / L;
     }
-    if (i8_eligible(t, bout)) return LQER_ROUTE_TILE256_I8;
+    if (i8_eligible(t, bout)) return LQER_ROUTE_I8;
     t.w8 = nullptr;
     return gemm_route(t, lowrank);
   }
@@ -1153,7 +1153,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   }
   if (g.w8) {  // LQER_Q_MXINT_I8: xq is the int8 image - only the int8 kernel can read it
     if (!i8_eligible(g, bout)) {
-      set_error("linear_gemm: LQER_Q_MXINT_I8 is not served for M=%d here (lqer_gemm_route != LQER_ROUTE_TILE256_I8): call with "
+      set_error("linear_gemm: LQER_Q_MXINT_I8 is not served for M=%d here (lqer_gemm_route != LQER_ROUTE_I8): call with "
                 "LQER_Q_MXINT", g.M);
       return LQER_E_UNSUPPORTED;
     }

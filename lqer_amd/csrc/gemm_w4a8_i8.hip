@@ -36,22 +36,38 @@ namespace lqer {
 
 namespace i8 {
 
-constexpr int BM = 256, BN = 256;
-constexpr int DEPTH = 2, NSLOT = DEPTH + 1;
-constexpr int A_SLOT = BM * I8_BK;   // 32 KiB  int8 activation tile
+constexpr int BN = 256;
 constexpr int W_SLOT = I8_WBLOCK;    // 16640 B nibbles + shift bytes
-constexpr int OFF_A = 0;
-constexpr int OFF_W = NSLOT * A_SLOT;
-constexpr int GEMM_LDS = OFF_W + NSLOT * W_SLOT;  // 148224 B
-// epilogue regions (the ring is free then)
-constexpr int EP_STAGE = 0;              // xAq tile: up to two 64-column panels of 32 KiB (filled by LDS-DMA)
-constexpr int EP_OUT = 65536;            // per wave: 64 rows x 80 B (32 fp16 columns + pad)
-constexpr int EP_OUT_WAVE = 64 * 80;
-static_assert(EP_OUT + 8 * EP_OUT_WAVE <= GEMM_LDS, "epilogue regions exceed the ring");
-// behind the ring, written at the start of the kernel: per-row constants of the epilogue - the x row scales, the B_out
-// scales 2^(mbits - e[m]) and 2^(e[m] - mbits) - fp32 [256] each
-constexpr int EP_TAB = GEMM_LDS;
-constexpr int KERNEL_LDS = GEMM_LDS + 4 * 1024;  // ... and 1e-9 * 2^(mbits - e[m]), the B_out quantizer's epsilon after scaling
+constexpr int EP_OUT_WAVE = 64 * 80;  // epilogue, per wave: 64 rows x 80 B (32 fp16 columns + pad)
+// Geometry by token tiles per workgroup (NT tiles of 32 rows).  NT = 8: 256 x 256 tiles, 3-slot ring two steps ahead (one
+// step = 2048 cycles of MFMA issue per SIMD).  NT = 4: 128 x 256 tiles for token counts whose 256-row grid leaves CUs idle
+// (Llama-7B projections at M = 2048: 128 tiles of 256 rows on 256 CUs) - a step is half as long, so the ring is one slot
+// deeper (three steps ahead: the same prefetch distance in time).
+template <int NT>
+struct Geo {
+  static constexpr int BM = 32 * NT;
+  static constexpr int DEPTH = NT == 8 ? 2 : 3, NSLOT = DEPTH + 1;
+  static constexpr int A_SLOT = BM * I8_BK;  // 32 / 16 KiB  int8 activation tile
+  static constexpr int NPA = NT / 2;         // 1-KiB activation pieces per wave and step
+  static constexpr int BATCH = NPA + 2;      // LDS-DMA loads per wave and step (wave 0: one more, the shift bytes)
+  static constexpr int OFF_A = 0;
+  static constexpr int OFF_W = NSLOT * A_SLOT;
+  static constexpr int GEMM_LDS = OFF_W + NSLOT * W_SLOT;  // 148224 B (NT 8) / 132096 B (NT 4)
+  // epilogue regions (the ring is free then)
+  static constexpr int PANEL = BM * 128;   // one 64-column panel of the xAq tile (filled by LDS-DMA)
+  static constexpr int EP_STAGE = 0;       // up to two panels
+  static constexpr int EP_OUT = 2 * PANEL;
+  static_assert(EP_OUT + 8 * EP_OUT_WAVE <= GEMM_LDS, "epilogue regions exceed the ring");
+  // behind the ring, written at the start of a tile: per-row constants of the epilogue - the x row scales, the B_out
+  // scales 2^(mbits - e[m]) and 2^(e[m] - mbits) - fp32 [256] each
+  static constexpr int EP_TAB = GEMM_LDS;
+  static constexpr int KERNEL_LDS = GEMM_LDS + 4 * 1024;  // ... and 1e-9 * 2^(mbits - e[m]), the B_out quantizer's epsilon after scaling
+  // one panel of xAq: the epilogue lives in ring slots 1.. (stage: activation slot 1; output transposes: the activation slots
+  // behind it, waves 6 and 7 in weight slot 2), so that slot 0 can take the next tile's first step meanwhile
+  static_assert(2 * A_SLOT + 6 * EP_OUT_WAVE <= NSLOT * A_SLOT && 2 * EP_OUT_WAVE <= W_SLOT && PANEL <= A_SLOT,
+                "epilogue regions of the persistent loop");
+  static_assert((NSLOT - 1) * A_SLOT + (NT - 1) * 4096 < 65536 || NT == 8, "activation fragment offsets fit the DS offset field");
+};
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
@@ -206,8 +222,11 @@ __global__ __launch_bounds__(256) void k_i8_unpack(const uint8_t* __restrict__ i
 // cw << (4 - q) carries them: 11 vector instructions per 8 weights - 7 when no row of the tile spreads over more than two
 // binades, PRESHIFT1 -, no folds), FOLD (one v_lshl_add_u32 per output element and group), or NONE.  The main loops live in one
 // kernel; the choice is uniform per tile.
-template <int DT, bool LOWRANK, int BOUT, bool SHIFT>
+template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT>
 __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
+  using G = Geo<NT>;
+  constexpr int BM = G::BM, DEPTH = G::DEPTH, NSLOT = G::NSLOT, A_SLOT = G::A_SLOT, NPA = G::NPA, OFF_A = G::OFF_A, OFF_W = G::OFF_W;
+  constexpr int PANEL = G::PANEL, EP_STAGE = G::EP_STAGE, EP_OUT = G::EP_OUT, EP_TAB = G::EP_TAB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane_k = threadIdx.x & 63;
   const int wave_k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -234,7 +253,6 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // activation slot 2, waves 6 and 7 in weight slot 2), so that slot 0 can take the next tile's first step meanwhile
   const bool one_panel = !LOWRANK || g.rp <= 64;  // (wave-uniform)
   const int ep_stage = one_panel ? A_SLOT : EP_STAGE;
-  static_assert(2 * A_SLOT + 6 * EP_OUT_WAVE <= 3 * A_SLOT && 2 * EP_OUT_WAVE <= W_SLOT, "epilogue regions of the persistent loop");
   float t_xs = 0.f, t_amax = 0.f;  // this lane's row constants of the tile whose tables are written next
   bool first = true;
 
@@ -247,11 +265,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int lane = lane_l, wave = wave_l, tid = wave * 64 + lane;
   const int l31 = lane & 31, lh = lane >> 5;
   // ---- staging addresses (per lane, fixed for the kernel) ------------------------------------------------------------
-  // activations: wave w stages rows [32w, 32w+32) of the tile as 4 pieces of 8 rows x 128 B, chunk-swizzled on the source side
-  int a_voff[4];
+  // activations: wave w stages rows [8 NPA w, 8 NPA (w + 1)) of the tile as NPA pieces of 8 rows x 128 B (NT = 8: 4 pieces, 32 rows;
+  // NT = 4: 2 pieces, 16 rows), chunk-swizzled on the source side
+  int a_voff[4] = {0, 0, 0, 0};  // (a fixed extent: a template-dependent one, captured by the lambdas below, loses hipcc the host stub)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
+  for (int i = 0; i < NPA; ++i) {
+    const int row = wave * (8 * NPA) + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_voff[i] = row * Kp8 + chunk * 16;
   }
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   };
   const u32x4 a_rs = make_rs(a_base, (uint32_t)(BM * Kp8)), w_rs = make_rs(w_base, (uint32_t)(nk * I8_WBLOCK));
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
-  const uint32_t m0_a = lds0 + OFF_A + wave * 32 * 128;    // + slot * A_SLOT + piece * 1024
+  const uint32_t m0_a = lds0 + OFF_A + wave * (8 * NPA) * 128;  // + slot * A_SLOT + piece * 1024
   const uint32_t m0_w = lds0 + OFF_W + (2 * wave) * 1024;  // + slot * W_SLOT (+ 1024: second piece)
   const uint32_t m0_s = lds0 + OFF_W + 256 * 64;           // + slot * W_SLOT
 
@@ -286,13 +305,13 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const uint32_t fw_b = lds0 + OFF_W + rw * 64 + (((2 * lh + 1) ^ ((rw >> 2) & 3)) << 4);  // slices 2, 3
   const uint32_t fs_addr = lds0 + OFF_W + 256 * 64 + rw;
 
-  // one LDS-DMA batch = the operands of one step: 6 loads per wave (wave 0: 7)
+  // one LDS-DMA batch = the operands of one step: NPA + 2 loads per wave (wave 0: one more)
   auto issue_step = [&](const uint8_t* ab, const uint8_t* wb, int kt, int slot) {
     const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, BM * Kp8, 0x00020000);
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, nk * I8_WBLOCK, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + OFF_A + slot * A_SLOT + wave * 32 * 128 + i * 1024), 16,
+    for (int i = 0; i < NPA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + OFF_A + slot * A_SLOT + wave * (8 * NPA) * 128 + i * 1024), 16,
                                                a_voff[i], kt * I8_BK, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + slot * W_SLOT + (2 * wave) * 1024), 16, w_voff0,
                                              kt * I8_WBLOCK, 0, 0);
@@ -305,13 +324,13 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // per-row constants of the epilogue: requested ahead, written to LDS (asm: invisible to hipcc's waitcnt pass, which would
   // drain the ring fill in front of a visible LDS store) once the ring fill has been issued
   auto load_tables = [&](int m0_) {
-    if (tid < 256) {
+    if (tid < BM) {
       t_xs = g.xscale[m0_ + tid];
       if constexpr (LOWRANK && BOUT == 2) t_amax = g.bout_amax[(int64_t)(m0_ + tid) * g.bout_nblk];
     }
   };
   auto write_tables = [&]() {
-    if (tid < 256) {
+    if (tid < BM) {
       const uint32_t ta = lds0 + EP_TAB + 4 * tid;
       asm volatile("ds_write_b32 %0, %1" ::"v"(ta), "v"(t_xs) : "memory");
       if constexpr (LOWRANK && BOUT == 2) {
@@ -332,11 +351,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   if (first) load_tables(m0);
   if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
   issue_step(a_base, w_base, 1, 1);
+  if constexpr (DEPTH == 3) issue_step(a_base, w_base, 2, 2);
   write_tables();
 
-  i32x16 R[8];
+  i32x16 R[NT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) R[i][j] = 0;
 
@@ -347,8 +367,11 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // half of the prefetch of step kt+2; LOAD(kt, 1): tiles 4-7, the other half.  A wave ends LOAD(kt, 1) with vmcnt(6): its own
   // batch of step kt+1 has landed (the batch of kt+2 - 6 loads, wave 0: 7 - may stay in flight), then passes a barrier before
   // anyone reads step kt+1.
+  // NT = 4 (128-row tiles): one phase per step - LOAD(kt) reads all 16 activation fragments of the 4 token tiles and issues the
+  // whole batch of step kt+3 (4 loads, wave 0: 5), ends with vmcnt(8): the batches of kt+2 and kt+3 may stay in flight.
   const bool late = wave >= 4;
-  asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // step 0 landed, the tables written
+  if constexpr (NT == 8) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // step 0 landed, the tables written
+  else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
   I8_STAMP(cp_c[1], cp_r[1]);
@@ -609,25 +632,152 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+
+  // ---- NT = 4 (128-row tiles): one phase per 128-k step.  LOAD: the 16 activation fragments of the 4 token tiles, the step's
+  // weight words and shift byte, the whole LDS-DMA batch of step kt + 3; COMPUTE: 16 MFMAs, three of the four weight slices
+  // expanded in their shadow (the first before the barrier) - half_step's first half, every phase.
+  auto step4 = [&](int kt, auto slot_c, auto mode_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int MODE = decltype(mode_c)::value;
+    constexpr int slot_new = (SLOT + DEPTH) % NSLOT;
+    constexpr int A_IMM = SLOT * A_SLOT;  // tile t: + 4096 t (every slot within the DS offset field)
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (MODE == I8_MODE_FOLD) {  // the previous step's last tile (sv still holds that step's shift: the asm below updates it)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) R[3][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[3][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
+    const int a_soff = ktn * I8_BK, w_soff = ktn * I8_WBLOCK;
+    const uint32_t m0a0 = m0_a + slot_new * A_SLOT, m0a1 = m0a0 + 1024;
+    const uint32_t m0w0 = m0_w + slot_new * W_SLOT, m0w1 = m0w0 + 1024, m0s = m0_s + slot_new * W_SLOT;
+    i32x4 xa[4][4];  // [token tile][slice]
+    u32x4 wr0, wr1;
+    asm volatile(
+        "ds_read_b128 %[x00], %[fa0] offset:%c[aimm]\n\tds_read_b128 %[x01], %[fa1] offset:%c[aimm]\n\t"
+        "ds_read_b128 %[x02], %[fa2] offset:%c[aimm]\n\tds_read_b128 %[x03], %[fa3] offset:%c[aimm]\n\t"
+        "ds_read_b128 %[x10], %[fa0] offset:%c[aimm]+4096\n\tds_read_b128 %[x11], %[fa1] offset:%c[aimm]+4096\n\t"
+        "ds_read_b128 %[x12], %[fa2] offset:%c[aimm]+4096\n\tds_read_b128 %[x13], %[fa3] offset:%c[aimm]+4096\n\t"
+        "ds_read_b128 %[x20], %[fa0] offset:%c[aimm]+8192\n\tds_read_b128 %[x21], %[fa1] offset:%c[aimm]+8192\n\t"
+        "ds_read_b128 %[x22], %[fa2] offset:%c[aimm]+8192\n\tds_read_b128 %[x23], %[fa3] offset:%c[aimm]+8192\n\t"
+        "ds_read_b128 %[x30], %[fa0] offset:%c[aimm]+12288\n\tds_read_b128 %[x31], %[fa1] offset:%c[aimm]+12288\n\t"
+        "ds_read_b128 %[x32], %[fa2] offset:%c[aimm]+12288\n\tds_read_b128 %[x33], %[fa3] offset:%c[aimm]+12288\n\t"
+        "ds_read_b128 %[wr0], %[fwa] offset:%c[wimm]\n\tds_read_b128 %[wr1], %[fwb] offset:%c[wimm]\n\t"
+        "ds_read_u8 %[sv], %[fs] offset:%c[wimm]\n\t"
+        "s_mov_b32 m0, %[m0a0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av0], %[ars], %[asoff] offen lds\n\t"
+        "s_mov_b32 m0, %[m0a1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av1], %[ars], %[asoff] offen lds\n\t"
+        "s_mov_b32 m0, %[m0w0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv0], %[wrs], %[wsoff] offen lds\n\t"
+        "s_mov_b32 m0, %[m0w1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv1], %[wrs], %[wsoff] offen lds\n\t"
+        "s_cmp_lg_u32 %[wave], 0\n\ts_cbranch_scc1 1f\n\t"
+        "s_mov_b32 m0, %[m0s]\n\ts_nop 0\n\tbuffer_load_dword %[sv4], %[wrs], %[wsoff] offen lds\n\t"
+        "1:\n\ts_waitcnt vmcnt(8) lgkmcnt(0)"
+        : [x00] "=&v"(xa[0][0]), [x01] "=&v"(xa[0][1]), [x02] "=&v"(xa[0][2]), [x03] "=&v"(xa[0][3]), [x10] "=&v"(xa[1][0]),
+          [x11] "=&v"(xa[1][1]), [x12] "=&v"(xa[1][2]), [x13] "=&v"(xa[1][3]), [x20] "=&v"(xa[2][0]), [x21] "=&v"(xa[2][1]),
+          [x22] "=&v"(xa[2][2]), [x23] "=&v"(xa[2][3]), [x30] "=&v"(xa[3][0]), [x31] "=&v"(xa[3][1]), [x32] "=&v"(xa[3][2]),
+          [x33] "=&v"(xa[3][3]), [wr0] "=&v"(wr0), [wr1] "=&v"(wr1), [sv] "=&v"(sv)
+        : [fa0] "v"(fa_lo[0]), [fa1] "v"(fa_lo[1]), [fa2] "v"(fa_lo[2]), [fa3] "v"(fa_lo[3]), [aimm] "i"(A_IMM), [fwa] "v"(fw_a),
+          [fwb] "v"(fw_b), [fs] "v"(fs_addr), [wimm] "i"(SLOT * W_SLOT), [av0] "v"(a_voff[0]), [av1] "v"(a_voff[1]),
+          [wv0] "v"(w_voff0), [wv1] "v"(w_voff1), [sv4] "v"(s_voff), [ars] "s"(a_rs), [wrs] "s"(w_rs), [m0a0] "s"(m0a0),
+          [m0a1] "s"(m0a1), [m0w0] "s"(m0w0), [m0w1] "s"(m0w1), [m0s] "s"(m0s), [asoff] "s"(a_soff), [wsoff] "s"(w_soff),
+          [wave] "s"(wave)
+        : "memory", "scc");
+    uint32_t hq4 = 0;  // PRESHIFT: per byte the q high bits (see half_step)
+    if constexpr (MODE == I8_MODE_PRESHIFT) hq4 = ((0xFF00u >> sv) & 0xFFu) * 0x01010101u;
+    auto expand = [&](uint32_t w0, uint32_t w1) {
+      if constexpr (MODE == I8_MODE_PRESHIFT1) {
+        const uint32_t a0 = (w0 << 4) & 0xF0F0F0F0u, b0 = w0 & 0xF0F0F0F0u, a1 = (w1 << 4) & 0xF0F0F0F0u, b1 = w1 & 0xF0F0F0F0u;
+        return (i32x4){(int)((a0 & 0x80808080u) | (a0 >> sv)), (int)((b0 & 0x80808080u) | (b0 >> sv)),
+                       (int)((a1 & 0x80808080u) | (a1 >> sv)), (int)((b1 & 0x80808080u) | (b1 >> sv))};
+      } else if constexpr (MODE == I8_MODE_PRESHIFT) {
+        auto one = [&](uint32_t w, uint32_t& lo, uint32_t& hi) {
+          const uint32_t t = w << 4;
+          const uint32_t m_hi = __builtin_amdgcn_perm(w, w << 8, 0x0B090A08u), m_lo = __builtin_amdgcn_perm(t, w << 12, 0x0B090A08u);
+          lo = (m_lo & hq4) | ((t & 0xF0F0F0F0u) >> sv);
+          hi = (m_hi & hq4) | ((w & 0xF0F0F0F0u) >> sv);
+        };
+        uint32_t l0, h0, l1, h1;
+        one(w0, l0, h0);
+        one(w1, l1, h1);
+        return (i32x4){(int)l0, (int)h0, (int)l1, (int)h1};
+      } else {
+        return (i32x4){(int)((w0 << 4) & 0xF0F0F0F0u), (int)(w0 & 0xF0F0F0F0u), (int)((w1 << 4) & 0xF0F0F0F0u), (int)(w1 & 0xF0F0F0F0u)};
+      }
+    };
+    wf[0] = expand(wr0[0], wr0[1]);
+    asm volatile("s_barrier" : "+v"(wf[0])::"memory");
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE
+    wf[1] = expand(wr0[2], wr0[3]);
+    wf[2] = expand(wr1[0], wr1[1]);
+    wf[3] = expand(wr1[2], wr1[3]);
+#define I8_SLOT(NV)                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+    if constexpr ((NV) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);
+    if constexpr (MODE != I8_MODE_FOLD) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) R[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][ks], wf[ks], R[t], 0, 0, 0);
+      if constexpr (MODE == I8_MODE_PRESHIFT || MODE == I8_MODE_PRESHIFT1) {
+        // issue order: the expand of slice ks + 1 (<= 22 vector instructions) in the shadow of the four MFMAs of slice ks
+        I8_SLOT(6) I8_SLOT(6) I8_SLOT(5) I8_SLOT(5)
+        I8_SLOT(6) I8_SLOT(6) I8_SLOT(5) I8_SLOT(5)
+        I8_SLOT(6) I8_SLOT(6) I8_SLOT(5) I8_SLOT(5)
+        I8_SLOT(0) I8_SLOT(0) I8_SLOT(0) I8_SLOT(0)
+      }
+    } else {
+      const i32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      i32x16 G4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        G4[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][0], wf[0], z, 0, 0, 0);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) G4[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][ks], wf[ks], G4[t], 0, 0, 0);
+        if (t > 0) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) R[t - 1][j] = (int)(((uint32_t)G4[t - 1][j] << sv) + (uint32_t)R[t - 1][j]);
+        }
+      }
+      Gd = G4[3];
+      I8_SLOT(6) I8_SLOT(6) I8_SLOT(6) I8_SLOT(0)
+      I8_SLOT(0) I8_SLOT(4) I8_SLOT(4) I8_SLOT(4)
+      I8_SLOT(4) I8_SLOT(4) I8_SLOT(4) I8_SLOT(4)
+      I8_SLOT(4) I8_SLOT(5) I8_SLOT(5) I8_SLOT(6)
+    }
+#undef I8_SLOT
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   using std::integral_constant;
 #ifndef LQER_I8_KSPLIT
 #define LQER_I8_KSPLIT 1  // 0: the token-tile split for every mode (A/B builds)
 #endif
   auto main_loop = [&](auto mode_c) {
-    auto hs = [&](int kt, auto slot_c, auto half_c) {
-      if constexpr (LQER_I8_KSPLIT && decltype(mode_c)::value != I8_MODE_FOLD) half_step_k(kt, slot_c, half_c, mode_c);
-      else half_step(kt, slot_c, half_c, mode_c);
-    };
-    for (int kt = 0; kt < nk; kt += NSLOT) {  // unrolled by the ring size: slots are compile-time constants
-      hs(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
-      hs(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
-      if (kt + 1 < nk) {
-        hs(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
-        hs(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+    if constexpr (NT == 4) {
+      for (int kt = 0; kt < nk; kt += NSLOT) {  // unrolled by the ring size: slots are compile-time constants
+        step4(kt, integral_constant<int, 0>{}, mode_c);
+        if (kt + 1 < nk) step4(kt + 1, integral_constant<int, 1>{}, mode_c);
+        if (kt + 2 < nk) step4(kt + 2, integral_constant<int, 2>{}, mode_c);
+        if (kt + 3 < nk) step4(kt + 3, integral_constant<int, 3 % NSLOT>{}, mode_c);
       }
-      if (kt + 2 < nk) {
-        hs(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 0>{});
-        hs(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    } else {
+      auto hs = [&](int kt, auto slot_c, auto half_c) {
+        if constexpr (LQER_I8_KSPLIT && decltype(mode_c)::value != I8_MODE_FOLD) half_step_k(kt, slot_c, half_c, mode_c);
+        else half_step(kt, slot_c, half_c, mode_c);
+      };
+      for (int kt = 0; kt < nk; kt += NSLOT) {  // unrolled by the ring size: slots are compile-time constants
+        hs(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+        hs(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+        if (kt + 1 < nk) {
+          hs(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+          hs(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+        }
+        if (kt + 2 < nk) {
+          hs(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 0>{});
+          hs(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+        }
       }
     }
   };
@@ -647,7 +797,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   if constexpr (SHIFT) {  // FOLD: the last half-step's last tile
     if (tile_mode == I8_MODE_FOLD) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) R[7][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[7][j]);
+      for (int j = 0; j < 16; ++j) R[NT - 1][j] = (int)(((uint32_t)Gd[j] << sv) + (uint32_t)R[NT - 1][j]);
     }
   }
   // every wave is past its last LDS read of the ring: the epilogue may overwrite it after one more barrier
@@ -700,10 +850,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     const int npanel = (g.rp + 63) >> 6;
     for (int pn = 0; pn < npanel; ++pn)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + (lane >> 3);
+      for (int i = 0; i < NPA; ++i) {
+        const int row = wave * (8 * NPA) + i * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + ep_stage + pn * 32768 + wave * 32 * 128 + i * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + ep_stage + pn * PANEL + wave * (8 * NPA) * 128 + i * 1024), 16,
                                                  row * g.xaq_ld * 2 + chunk * 16, pn * 128, 0, 0);
       }
   }
@@ -740,7 +890,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     const f2 ws2 = {ws, ws}, bv2 = {bv, bv};
     const uint32_t txs = lds0 + EP_TAB + 16 * lh;  // row 32 i + 8 q + 4 lh: + 128 i + 32 q bytes
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NT; ++i) {
       // (asm: a table read hipcc can see would be preceded by a vmcnt(0), i.e. wait for the DMA and the loads just issued)
       f32x4 xs[4];
       asm volatile("ds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c5+32\n\tds_read_b128 %2, %4 offset:%c5+64\n\t"
@@ -763,7 +913,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     }
   }
 #ifdef LQER_CLOCKPROBE
-  asm volatile("" ::"v"(R[0][0]), "v"(R[7][15]));
+  asm volatile("" ::"v"(R[0][0]), "v"(R[NT - 1][15]));
   I8_STAMP(cp_b, cp_x);
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -786,7 +936,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     for (int l = 0; l < NL; ++l)
 #pragma unroll
       for (int ks = 0; ks < NSL; ++ks) {
-        const bf16x8 xf = *(const bf16x8*)(smem + xaddr[ks & 3] + (ks >> 2) * 32768 + i * 4096);
+        const bf16x8 xf = *(const bf16x8*)(smem + xaddr[ks & 3] + (ks >> 2) * PANEL + i * 4096);
         if (l == 0 && ks == 0) {
           const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sb[0], z, 0, 0, 0);
@@ -812,7 +962,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     for (int l = 0; l < g.b_limbs; ++l)  // (the same order: limb-major, slices ascending)
       for (int ks = 0; ks < nslices; ++ks) {
         const bf16x8 bf = *(const bf16x8*)(bt_lane + l * bt_limb + ks * 16);
-        const bf16x8 xf = *(const bf16x8*)(smem + ep_stage + (ks >> 2) * 32768 + swz(l31 + 32 * i, 2 * (ks & 3) + lh));
+        const bf16x8 xf = *(const bf16x8*)(smem + ep_stage + (ks >> 2) * PANEL + swz(l31 + 32 * i, 2 * (ks & 3) + lh));
         sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, bf, sp, 0, 0, 0);
       }
     return sp;
@@ -832,7 +982,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const float mmax = g.bout.mmax;
   const f2 magic = {12582912.0f, 12582912.0f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < NT; ++i) {
     float yv[16];
     f32x16 sp;
     if constexpr (LOWRANK) sp = side(i);
@@ -955,8 +1105,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #endif
 }
 
-template <int DT>
+template <int DT, int NT>
 static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
+  constexpr int BM = Geo<NT>::BM, KERNEL_LDS = Geo<NT>::KERNEL_LDS;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
   // persistent: at most one workgroup per CU (the LDS ring leaves room for one), each walks tiles b, b + grid, ...
@@ -967,12 +1118,12 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
   do {                                                                                            \
     if (g.i8_shift) {                                                                             \
       static LdsLimitOnce lds_once;                                                               \
-      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, true>, KERNEL_LDS);                      \
-      k_lqer_gemm_i8<DT, LR, BO, true><<<grid, 512, KERNEL_LDS, st>>>(g);                           \
+      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, true, NT>, KERNEL_LDS);                  \
+      k_lqer_gemm_i8<DT, LR, BO, true, NT><<<grid, 512, KERNEL_LDS, st>>>(g);                       \
     } else {                                                                                      \
       static LdsLimitOnce lds_once;                                                               \
-      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false>, KERNEL_LDS);                     \
-      k_lqer_gemm_i8<DT, LR, BO, false><<<grid, 512, KERNEL_LDS, st>>>(g);                          \
+      lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false, NT>, KERNEL_LDS);                 \
+      k_lqer_gemm_i8<DT, LR, BO, false, NT><<<grid, 512, KERNEL_LDS, st>>>(g);                      \
     }                                                                                             \
   } while (0)
   if (!lowrank)
@@ -993,25 +1144,36 @@ extern "C" int lqer_debug_set_i8_stamp_buffer(void* p) {
 }
 #endif
 
-// The int8 main loop needs: the int8 images (g.w8 set by the caller for an LQER_Q_MXINT_I8 descriptor), M large enough for
-// 256-row tiles to fill the chip in rounds that beat the 128-row bf16 kernel (an int8 256 x 256 tile costs about 1.15
-// bf16 128 x 256 tiles), B_out pass-through or one block per row, at most two 64-column panels of xAq.
+// Rows of a tile of the int8 kernel: rounds of one tile per CU (the grid is persistent: a CU walks ceil(tiles / 256) tiles), a
+// 128-row tile priced at 0.56 of a 256-row one (half the main loop and epilogue, the same ring fill and launch ramp; the weight
+// expand per MFMA doubles).  Llama-7B projections at M = 2048: 4096 x 4096 fills 128 CUs with 256-row tiles and all 256 with
+// 128-row ones; N = 11008: 2 rounds of 256 rows against 3 x 0.56.  LQER_TUNE_I8_ROWS_* pins the choice (tests: same bits).
+int i8_tile_rows(const GemmArgs& g) {
+  if (g.tuning & LQER_TUNE_I8_ROWS_128) return 128;
+  if (g.tuning & LQER_TUNE_I8_ROWS_256) return 256;
+  constexpr int64_t CUS = 256;
+  const int64_t tn = g.Np / i8::BN;
+  const int64_t r256 = (((g.M + 255) / 256) * tn + CUS - 1) / CUS, r128 = (((g.M + 127) / 128) * tn + CUS - 1) / CUS;
+  return r128 * 56 < r256 * 100 ? 128 : 256;
+}
+
+// The int8 main loop needs: the int8 images (g.w8 set by the caller for an LQER_Q_MXINT_I8 descriptor), a token count of the
+// tile kernels (M >= 128; below, the sign-magnitude image serves the weight-streaming and 64-row kernels), B_out pass-through
+// or one block per row, at most two 64-column panels of xAq.  An int8 tile costs 0.58 (256 rows) / 0.65 (128 rows) of the bf16
+// kernel's tiles over the same rows, so there is no token count from which the bf16 tile kernel would be the better choice.
 bool i8_eligible(const GemmArgs& g, int bout) {
-  if (!g.w8 || g.M < 512) return false;
+  if (!g.w8 || g.M < 128) return false;
   if (!(bout == 0 || (bout == 2 && g.bout_nblk == 1))) return false;
   if (g.rp > 128) return false;
-  constexpr int64_t CUS = 256;
-  const int64_t t256 = (int64_t)((g.M + i8::BM - 1) / i8::BM) * (g.Np / i8::BN);
-  const int64_t t128 = (int64_t)((g.M + 127) / 128) * (g.Np / i8::BN);
-  const int64_t r256 = (t256 + CUS - 1) / CUS, r128 = (t128 + CUS - 1) / CUS;
-  return r256 * 23 <= r128 * 20;
+  return true;
 }
 
 int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st) {
+  const bool t128 = i8_tile_rows(g) == 128;
   switch (dtype) {
-    case LQER_F32: return i8::launch<LQER_F32>(g, lowrank, bout, st);
-    case LQER_F16: return i8::launch<LQER_F16>(g, lowrank, bout, st);
-    case LQER_BF16: return i8::launch<LQER_BF16>(g, lowrank, bout, st);
+    case LQER_F32: return t128 ? i8::launch<LQER_F32, 4>(g, lowrank, bout, st) : i8::launch<LQER_F32, 8>(g, lowrank, bout, st);
+    case LQER_F16: return t128 ? i8::launch<LQER_F16, 4>(g, lowrank, bout, st) : i8::launch<LQER_F16, 8>(g, lowrank, bout, st);
+    case LQER_BF16: return t128 ? i8::launch<LQER_BF16, 4>(g, lowrank, bout, st) : i8::launch<LQER_BF16, 8>(g, lowrank, bout, st);
   }
   set_error("unknown dtype %d", dtype);
   return LQER_E_INVALID;

@@ -418,7 +418,7 @@ class _LinearBase(nn.Linear):
             # (plain data only: the module must stay deep-copyable and picklable)
             a_t, a_limbs = ops._ptr(p.get("a_t")), p.get("a_limbs", 0)
             if self._x_i8 and "a_t_f16" in p and \
-                    _lib.lib().lqer_gemm_route(C.byref(desc), M, ops.dtype_code(x2)) == _lib.ROUTE_TILE256_I8:
+                    _lib.lib().lqer_gemm_route(C.byref(desc), M, ops.dtype_code(x2)) == _lib.ROUTE_I8:
                 a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # (the int8 kernel's token counts only: elsewhere the bf16 kernels run)
             ent = self._fw_cache[key] = (desc, ops.linear_sizes(desc, M).workspace, ops.dtype_code(x2),
                                          (p["w"].data_ptr(), a_t, ops._ptr(p.get("b_t")),
@@ -658,7 +658,7 @@ class SharedActivation:
         plan = self._plans.get((M, dtc))
         if plan is None:
             i8 = all(m._x_i8 for m in self.members) and \
-                all(L.lqer_gemm_route(C.byref(m._desc()), M, dtc) == _lib.ROUTE_TILE256_I8 for m in self.members)
+                all(L.lqer_gemm_route(C.byref(m._desc()), M, dtc) == _lib.ROUTE_I8 for m in self.members)
             gdesc = m0._desc(plain=not i8)
             gdesc.rank = self._cat["rp_total"]
             gdesc.a_out_fmt.block = self._aout_block  # (one block per member row -> blocks of a member's rank)

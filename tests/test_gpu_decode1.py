@@ -310,3 +310,104 @@ def test_group_forward_c_abi_refuses_what_it_does_not_serve(ops):
     for m, o in zip(mods, outs):
         m._group = None
         assert float((m(x16).float() - o.float()).norm() / o.float().norm()) <= 2e-3
+
+
+def test_group_decode_sees_an_in_place_write_to_any_member(ops):
+    """the group launch reads every member's images, so a write to a NON-leading member's parameters
+    (`k_proj.weight.copy_(W2)`, a bias write) must be noticed by the next decode step although only the leading member's
+    forward runs its own version check - the outputs equal those of FRESH ungrouped modules built from the new values."""
+    import lqer_amd
+    from bench import OPT_Q, make_case
+    from lqer_amd.linear import SharedActivation
+
+    K, r, Ns = 512, 32, (256, 384, 256)
+    cases = [make_case(8, K, N, r, seed=40 + i, bias=True) for i, N in enumerate(Ns)]
+
+    def build(i, W=None, b=None):
+        m = lqer_amd.LinearFlexibleLqer(K, Ns[i], bias=True, q_config=OPT_Q, l_config={"rank": r})
+        m.load_state_dict({"weight": cases[i][1] if W is None else W, "A": cases[i][2], "B": cases[i][3],
+                           "bias": cases[i][4] if b is None else b})
+        return m.to(DEV).half()
+
+    mods = [build(i) for i in range(3)]
+    xd = cases[0][0][:4].half().to(DEV)
+    grp = SharedActivation(mods)
+    assert grp.enabled
+    first = [m(xd).clone() for m in mods]
+    assert grp._dplans[(4, ops.dtype_code(xd))] is not None
+    g2 = torch.Generator().manual_seed(99)
+    W2 = 0.02 * torch.randn(Ns[1], K, generator=g2)
+    b2 = 0.01 * torch.randn(Ns[2], generator=g2)
+    with torch.no_grad():
+        mods[1].weight.copy_(W2.half().to(DEV))   # k: new unquantized weight
+        mods[2].bias.copy_(b2.half().to(DEV))     # v: new bias (its weight already holds w_quantizer(W): not quantized again)
+    x2 = (xd * 0.5).contiguous()                  # a new round, started by q
+    got = [m(x2) for m in mods]
+    assert grp._dplans[(4, ops.dtype_code(xd))] is not None  # (still one launch)
+    want = [build(0)(x2), build(1, W=W2)(x2), build(2, b=b2)(x2)]
+    for i in range(3):
+        assert torch.equal(got[i], want[i]), i
+    assert not torch.equal(got[1], (first[1].float() * 0.5).half())
+    for m in mods:
+        m._group = None
+
+
+def test_group_member_on_another_stream_takes_its_own_route(ops):
+    """A member that comes with the round's tensor on ANOTHER stream is not handed the output the group launch is still
+    writing on the first stream: it runs its own forward there (same bits)."""
+    from bench import MXINT_Q
+    from lqer_amd.linear import SharedActivation
+
+    mods, x = _group((256, 256), 512, 32, False, MXINT_Q, torch.float16)
+    xd = x[:2].half().to(DEV)
+    alone = [m(xd).clone() for m in mods]
+    grp = SharedActivation(mods)
+    y0 = mods[0](xd)
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        assert grp.take(mods[1], xd) is None
+        y1 = mods[1](xd)
+    side.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(y0, alone[0]) and torch.equal(y1, alone[1])
+    for m in mods:
+        m._group = None
+
+
+def test_group_forward_c_abi_rejects_malformed_members(ops):
+    """Every member's descriptor goes through the format checks of lqer_linear_forward (not members[0] alone): an 8-bit
+    w_quantizer in member 1 is LQER_E_UNSUPPORTED, has_bias without bias_q LQER_E_INVALID - nothing is launched."""
+    from bench import MXINT_Q
+    from lqer_amd import _lib
+    from lqer_amd.linear import SharedActivation
+
+    L = _lib.lib()
+    mods, x = _group((256, 256), 512, 32, False, MXINT_Q, torch.float16)
+    xd = x.half().to(DEV)
+    for m in mods:
+        m(xd)
+    descs = [m._desc() for m in mods]
+    tab = (_lib.GroupMember * 2)()
+    ys = [torch.full((8, 256), 7.0, dtype=torch.float16, device=DEV) for _ in mods]
+    for i, (m, d) in enumerate(zip(mods, descs)):
+        p = m._packed
+        tab[i].desc, tab[i].w_packed, tab[i].b_t, tab[i].b_limbs = C.pointer(d), p["w"].data_ptr(), p["b_t"].data_ptr(), p["b_limbs"]
+        tab[i].bias_q, tab[i].y, tab[i].ldy = None, ys[i].data_ptr(), 256
+    grp = SharedActivation(mods)
+    grp._pack_cat(torch.device(DEV))
+    ws = torch.empty(L.lqer_group_workspace_bytes(512, 64), dtype=torch.uint8, device=DEV)
+    call = lambda: L.lqer_linear_forward_group(tab, 2, xd.data_ptr(), _lib.F16, 8, 512, grp._cat["a_t"].data_ptr(), 1, ws.data_ptr(),
+                                               ws.numel(), None)
+    descs[1].w_fmt.width = 12
+    assert call() == -2 and b"w_quantizer" in L.lqer_last_error()
+    descs[1].w_fmt.width = 4
+    descs[1].has_bias = 1
+    assert call() == -1 and b"bias_q" in L.lqer_last_error()
+    descs[1].has_bias = 0
+    torch.cuda.synchronize()
+    assert all(bool((y == 7.0).all()) for y in ys)  # nothing was launched
+    assert call() == 0
+    torch.cuda.synchronize()
+    for m in mods:
+        m._group = None

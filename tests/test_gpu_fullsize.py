@@ -30,7 +30,7 @@ def _rows(M):
     return torch.tensor(sorted(set(i for i in idx if 0 <= i < M)))
 
 
-def _run(lq, M, K, N, r, qc, bias, quantize_ab, seed, tol=1e-3, route=None):
+def _run(lq, M, K, N, r, qc, bias, quantize_ab, seed, tol=1e-3, route=None, tile_rows=None):
     import ctypes as C
 
     from bench import make_case
@@ -49,9 +49,9 @@ def _run(lq, M, K, N, r, qc, bias, quantize_ab, seed, tol=1e-3, route=None):
     y = mod(xin.to(DEV))
     assert y.shape == (M, N) and torch.isfinite(y).all()
     if route is not None:  # the kernel the bench times at this shape
-        if mod._x_i8 and route == "TILE256":
-            route = "TILE256_I8"
         assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16) == getattr(_lib, "ROUTE_" + route)
+        if tile_rows is not None:
+            assert _lib.lib().lqer_gemm_tile_rows(C.byref(mod._desc()), M, _lib.F16) == tile_rows
     idx = _rows(M)
     got = y[idx.to(DEV)].float().cpu()
     ref = O.lqer_linear_forward(xin[idx].float(), W.half().float(), b.half().float() if bias else None, A.half().float(),
@@ -83,8 +83,27 @@ def test_c4_int_rank64_full_size(lq, K, N, wblock):
     from bench import INT_Q, _bfp
 
     qc = dict(INT_Q, w_quantizer=_bfp(4, [1, wblock], False))
-    mod, _ = _run(lq, 16384, K, N, 64, qc, False, False, seed=41, route="TILE256")
+    mod, _ = _run(lq, 16384, K, N, 64, qc, False, False, seed=41, route="I8", tile_rows=256)
     assert mod._x_i8  # the int8 main loop
+
+
+# c2int / c3int: the shapes north_star names - Llama-7B projections at M = 2048, rank 32 - with the
+# reference's Llama-7B INT template (experiments/configs/template/llama-7b-int.toml:70-93: W4 one block per row; the sweep
+# experiments/pipeline/sweep_lqer_act_int.sh:81-83: W4 blocks of 128, rank 32), 8-bit per-token activations, unquantized
+# fp16 A / B.  The int8 MFMA kernel on 128-row tiles: 256 x 256 tiles would leave half of the CUs idle at 4096 x 4096.
+@pytest.mark.parametrize("K,N,wblock", [(4096, 4096, 128), (4096, 11008, 128), (11008, 4096, 128), (4096, 4096, -1)])
+def test_c2int_c3int_llama7b_int_rank32_full_size(lq, K, N, wblock):
+    from bench import INT_Q, _bfp
+
+    qc = dict(INT_Q, w_quantizer=_bfp(4, [1, wblock], False))
+    mod, y = _run(lq, 2048, K, N, 32, qc, False, False, seed=61, route="I8", tile_rows=128)
+    assert mod._x_i8
+    # the 256-row tiles of the same kernel: the same bits
+    from lqer_amd import _lib
+
+    mod.tuning = _lib.TUNE_I8_ROWS_256
+    x = __import__("bench").make_case(2048, K, N, 32, seed=61, quantize_ab=False)[0].half().to(DEV)
+    assert torch.equal(mod(x), y)
 
 
 # C2 / C3: Llama-7B shapes at the bench's M = 2048, rank 32, MXINT blocks of 16.

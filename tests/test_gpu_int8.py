@@ -127,8 +127,8 @@ def test_int8_route_forward_vs_oracle_and_bf16_route(lq, dtype, tol, M, K, N, r,
     y = mod(xin.to(DEV))
     assert mod._x_i8 and y.dtype == dtype
     L = _lib.lib()
-    assert L.lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16 if dtype != torch.float32 else _lib.F32) == _lib.ROUTE_TILE256_I8
-    assert L.lqer_gemm_route(C.byref(mod._desc()), 40, _lib.F16) != _lib.ROUTE_TILE256_I8  # small token counts keep the bf16 kernels
+    assert L.lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16 if dtype != torch.float32 else _lib.F32) == _lib.ROUTE_I8
+    assert L.lqer_gemm_route(C.byref(mod._desc()), 40, _lib.F16) != _lib.ROUTE_I8  # small token counts keep the bf16 kernels
     cast = lambda t: None if t is None else t.to(dtype).float()
     ref = O.lqer_linear_forward(xin.float(), cast(W), cast(b), cast(A), cast(B), qc)
     err = float((y.float().cpu() - ref).norm() / ref.norm())
@@ -217,7 +217,7 @@ def test_int8_route_side_gemm_on_one_fp16_limb(lq):
         mod = mod.to(DEV).half()
         outs[f16] = mod(x.half().to(DEV)).float().cpu()
         assert mod._x_i8 and ("a_t_f16" in mod._packed) == f16
-        assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16) == _lib.ROUTE_TILE256_I8
+        assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16) == _lib.ROUTE_I8
     h = lambda t: t.half().float()
     ref = O.lqer_linear_forward(h(x), h(W), None, h(A), h(B), INT_Q)
     for f16 in (True, False):
@@ -279,7 +279,7 @@ def test_int8_route_tile_modes_forward(lq, dtype):
     xin = x.to(dtype).to(DEV)
     y = mod(xin).clone()
     assert mod._x_i8
-    assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16 if dtype != torch.float32 else _lib.F32) == _lib.ROUTE_TILE256_I8
+    assert _lib.lib().lqer_gemm_route(C.byref(mod._desc()), M, _lib.F16 if dtype != torch.float32 else _lib.F32) == _lib.ROUTE_I8
     for _ in range(5):
         assert torch.equal(mod(xin), y)
     cast = lambda t: t.to(dtype).float()
@@ -295,3 +295,64 @@ def test_int8_route_tile_modes_forward(lq, dtype):
         assert d <= (1e-5 if dtype == torch.float32 else tol / 4), (lo, d)
         if dtype != torch.float32:
             assert float((y[:, lo:hi] != y2[:, lo:hi]).float().mean()) <= 0.01, lo
+
+
+@pytest.mark.parametrize("M,K,N,r,dtype,bias", [(2048, 640, 1024, 64, torch.float16, False),    # all four tile modes, one panel of xAq
+                                                (300, 1000, 700, 32, torch.float16, True),     # ragged M (rows_left), K, N; bias
+                                                (129, 256, 512, 16, torch.bfloat16, False),    # two row tiles, the second with one row
+                                                (1024, 384, 768, 128, torch.float16, False),   # rank 128: two panels (no next-tile prefetch)
+                                                (640, 512, 2048, 64, torch.float32, False),    # fp32 in / out
+                                                (2048, 384, 8192, 64, torch.float16, False)])  # 512 tiles of 128 rows: two per workgroup
+def test_int8_tile_rows_128_and_256_give_the_same_bits(lq, M, K, N, r, dtype, bias):
+    """The 128-row tiles of the int8 kernel (Llama-7B projections at M = 2048 fill 256 CUs only with them)
+    against its 256-row tiles, pinned through the descriptor's tuning bits: the same integer sums, the same epilogue arithmetic
+    per element - bit-identical outputs in every tile mode (NONE / FOLD / PRESHIFT / PRESHIFT1), and both within the oracle's
+    tolerance; the last case walks two tiles per workgroup of the persistent grid (next tile's first step requested before the epilogue)."""
+    from bench import INT_Q, _bfp, make_case
+    from lqer_amd import _lib
+
+    qc = dict(INT_Q, b_quantizer=_bfp(8, [-1], False))
+    case = make_case(M, K, N, r, seed=M + N, bias=bias, quantize_ab=False)
+    x, _, A, B = case[:4]
+    W = _mode_weights(N, K, 5) if N >= 1024 else case[1]
+    mod = lq.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = case[4]
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).to(dtype)
+    xin = x.to(dtype).to(DEV)
+    L = _lib.lib()
+    dtc = _lib.F32 if dtype == torch.float32 else _lib.F16
+    outs = {}
+    for rows, bit in ((128, _lib.TUNE_I8_ROWS_128), (256, _lib.TUNE_I8_ROWS_256)):
+        mod.tuning = bit
+        y = mod(xin).clone()
+        assert mod._x_i8
+        assert L.lqer_gemm_route(C.byref(mod._desc()), M, dtc) == _lib.ROUTE_I8
+        assert L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, dtc) == rows
+        for _ in range(3):
+            assert torch.equal(mod(xin), y)
+        outs[rows] = y
+    assert torch.equal(outs[128], outs[256])
+    mod.tuning = 0
+    assert torch.equal(mod(xin), outs[128])
+    cast = lambda t: None if t is None else t.to(dtype).float()
+    ref = O.lqer_linear_forward(cast(x), cast(W), cast(case[4]) if bias else None, cast(A), cast(B), qc)
+    tol = {torch.float32: 2e-5, torch.float16: 1e-3, torch.bfloat16: 5e-3}[dtype]
+    assert float((outs[128].float().cpu() - ref).norm() / ref.norm()) <= tol
+
+
+def test_int8_tile_rows_default_choice(lq):
+    """lqer_gemm_tile_rows for the int8 route: 128-row tiles where they take fewer weighted rounds of one tile per CU (the
+    Llama-7B projections at M = 2048), 256-row tiles at the C4 shapes (M = 16384)."""
+    from lqer_amd import _lib
+
+    L = _lib.lib()
+    mk = lambda K, N: _lib.LinearDesc(K, N, 32, 0, _lib.QFmt(_lib.Q_MXINT_I8, 8, -1, 8, 127), _lib.QFmt(_lib.Q_MXINT, 4, 128, 8, 127),
+                                      _lib.QFmt(0, 0, 0, 8, 127), _lib.QFmt(_lib.Q_MXINT, 8, -1, 8, 127), _lib.QFmt(_lib.Q_MXINT, 8, -1, 8, 127), 0)
+    rows = lambda K, N, M: L.lqer_gemm_tile_rows(C.byref(mk(K, N)), M, _lib.F16)
+    assert rows(4096, 4096, 2048) == 128 and rows(4096, 11008, 2048) == 128 and rows(11008, 4096, 2048) == 128
+    assert rows(5120, 5120, 16384) == 256 and rows(5120, 13824, 16384) == 256 and rows(13824, 5120, 16384) == 256
+    assert L.lqer_gemm_route(C.byref(mk(4096, 4096)), 2048, _lib.F16) == _lib.ROUTE_I8
+    assert L.lqer_gemm_route(C.byref(mk(4096, 4096)), 100, _lib.F16) != _lib.ROUTE_I8  # below 128 tokens: the bf16 kernels

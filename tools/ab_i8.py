@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--lib", default=None, help="path of another build of liblqer_hip.so")
+    ap.add_argument("--rows", action="store_true", help="compare the int8 kernel's 128-row and 256-row tiles (pinned) and the bf16 route")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, K, N, r = a.M, a.K, a.N, a.r
@@ -46,7 +47,12 @@ def main():
     p = mod._packed
     Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
     routes = {}
-    for name, desc in (("int8", mod._desc()), ("bf16", mod._desc(plain=True))):
+    variants = [("int8", mod._desc()), ("bf16", mod._desc(plain=True))]
+    if a.rows:  # the int8 kernel's two tile heights, pinned (same bits)
+        d128, d256 = mod._desc(), mod._desc()
+        d128.tuning, d256.tuning = _lib.TUNE_I8_ROWS_128, _lib.TUNE_I8_ROWS_256
+        variants = [("i8r128", d128), ("i8r256", d256), ("bf16", mod._desc(plain=True))]
+    for name, desc in variants:
         ws = torch.empty(ops.linear_sizes(desc, M).workspace, dtype=torch.uint8, device=dev)
         xq = ws.data_ptr()
         xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256
@@ -70,8 +76,12 @@ def main():
         gemm(rt)
         torch.cuda.synchronize()
         outs[name] = y.clone()
-    d = (outs["int8"].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
-    print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs['int8'] != outs['bf16']).float().mean()):.2e}")
+    i8n = "i8r128" if a.rows else "int8"
+    d = (outs[i8n].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
+    print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs[i8n] != outs['bf16']).float().mean()):.2e}")
+    if a.rows:
+        print("128-row vs 256-row int8 tiles bit-identical:", bool(torch.equal(outs["i8r128"], outs["i8r256"])),
+              " default tile rows:", L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, _lib.F16))
     fl = 2.0 * M * K * N + 2.0 * M * r * N
     for what, fn in (("GEMM alone (incl. B_out pre-pass)", lambda rt: gemm(rt)), ("whole forward", lambda rt: (quant(rt), gemm(rt)))):
         times = {k: [] for k in routes}
