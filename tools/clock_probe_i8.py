@@ -32,7 +32,9 @@ mod = mod.to(dev).half()
 xd = x.half().to(dev)
 y = mod(xd)
 assert mod._x_i8
-tiles = (-(-M // 256)) * (-(-N // 256))
+L.lqer_gemm_tile_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+BMt = L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, _lib.F16)  # 128- or 256-row tiles of the int8 kernel
+tiles = (-(-M // BMt)) * (-(-N // 256))
 buf = torch.zeros(tiles * 8 * 8, dtype=torch.int64, device=dev)
 assert L.lqer_debug_set_i8_stamp_buffer(buf.data_ptr()) == 0
 desc = mod._desc()
@@ -59,8 +61,8 @@ steps = -(-K // 128)
 cyc, rt = b[:, :, 0], b[:, :, 1]
 clk = (cyc / rt * 100e6).median().item()
 med = lambda t: t.median().item()
-print(f"M={M} K={K} N={N} r={r} wblock={a.wblock}: call (pre-pass + GEMM) {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, {tiles} tiles = {tiles / 256:.2f} rounds")
-print(f"  main loop   {med(cyc):9.0f} cycles = {med(cyc) / steps:6.0f} per 128-k step (2048 = MFMA-bound), {med(rt) / 100:7.2f} us; clock {clk / 1e9:.3f} GHz")
+print(f"M={M} K={K} N={N} r={r} wblock={a.wblock} tile rows {BMt}: call (pre-pass + GEMM) {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, {tiles} tiles = {tiles / 256:.2f} rounds")
+print(f"  main loop   {med(cyc):9.0f} cycles = {med(cyc) / steps:6.0f} per 128-k step ({BMt * 8} = MFMA-bound), {med(rt) / 100:7.2f} us; clock {clk / 1e9:.3f} GHz")
 print(f"  ring fill   {med(b[:, :, 2]):9.0f} cycles")
 pk = buf.cpu().view(tiles, 8, 8)[:nb, :, 3]
 parts = [((pk >> (16 * i)) & 0xffff).double() for i in range(4)]
@@ -68,4 +70,4 @@ for w in (0, 4):
     print(f"  wave {w}: issue of DMA + loads {parts[0][:, w].median().item():.0f}, conversion pass {parts[1][:, w].median().item():.0f}, "
           f"vmcnt(0) {parts[2][:, w].median().item():.0f}, barrier {parts[3][:, w].median().item():.0f} cycles")
 print(f"  epilogue    {med(b[:, :, 4]):9.0f} cycles, {med(b[:, :, 5]) / 100:7.2f} us")
-print(f"     of which staging + barrier {med(b[:, :, 6]):7.0f} cycles, math of the first two of eight tiles {med(b[:, :, 7]):7.0f} cycles")
+print(f"     of which staging + barrier {med(b[:, :, 6]):7.0f} cycles, math of the first two token tiles {med(b[:, :, 7]):7.0f} cycles")
