@@ -114,6 +114,10 @@ typedef struct lqer_linear_desc {
 #define LQER_TUNE_I8_ROWS_128 0x4      /* int8 kernel (LQER_ROUTE_I8): always 128-row tiles                                      */
 #define LQER_TUNE_I8_ROWS_256 0x8      /* ... always 256-row tiles; default: whichever takes fewer weighted rounds of one tile per
                                          CU (lqer_gemm_tile_rows says which)                                                    */
+#define LQER_TUNE_AMAX_ATOMIC 0x40000  /* int8 route, B_out with one block per row: the pre-pass of row maxima with one atomicMax cell per
+                                         row behind a zero-fill launch (the round-4 form) instead of per-segment partial maxima in plain
+                                         stores that the GEMM folds (no zero-fill launch); max is order-independent: same bits         */
+#define LQER_TUNE_AMAX_PARTS 0x80000   /* ... the segment partials at every N (default: up to N = 4096, where they are faster)     */
 #define LQER_TUNE_XA_REDUCE_IN_GEMM 0x20000 /* lqer_linear_forward on 128-row tiles: no reduce launch between the quantizer and the
                                          GEMM - its workgroups sum the partial tiles of x A for their own rows (lqer_tile_partials).
                                          Off by default: measured slower (C2: the GEMM grows by 5.3 us, the launch it saves took

@@ -405,6 +405,10 @@ __host__ inline size_t i8_weight_image_bytes(int64_t N, int64_t K) {
   return i8_weight_mode_offset(Np, padded_k8(K) / I8_BK) + (size_t)((Np / 256 + 255) / 256 * 256);
 }
 
+#ifndef LQER_AMAX_NSEG
+#define LQER_AMAX_NSEG 16  // column-segment partials per row of a one-block-per-row B_out (int8 route: k_bout_amax -> k_lqer_gemm_i8)
+#endif
+
 // ---- cross-file declarations ----------------------------------------------------------------------
 struct QuantOut {
   float* deq;      // [rows, cols] or null
@@ -445,6 +449,7 @@ struct GemmArgs {
   int xcd_bm;           // > 0: an XCD's tiles form a block of xcd_bm token tiles x (tiles / 8 / xcd_bm) weight tiles (128-row kernel)
   float* bout_amax;     // [Mp][bout_nblk] row-block maxima of xAq @ B (B_out blocks other than 16), else null
   int bout_L, bout_nblk;
+  int bout_nseg;        // > 0 (int8 route, one block per row): bout_amax holds [bout_nseg][Mp] column-segment partials (no atomics)
   // int8 route: xq holds the int8 activation image (+ row scales), w8 the two's-complement weight image
   const uint8_t* w8;
   const float* xscale;  // [Mp] row scales 2^(e - mbits) of the int8 activation image

@@ -757,8 +757,10 @@ __global__ __launch_bounds__(256) void k_bout_amax(GemmArgs g, int tiles_n32, in
 #pragma unroll
     for (int u = 0; u < RG; ++u) {
       const float m = pair32_max(cur[u]);  // lanes l and l ^ 32 hold the two column halves of the same token row
-      if (lh == 0 && rowv[u] >= 0)
-        atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(m));
+      if (lh == 0 && rowv[u] >= 0) {
+        if (g.bout_nseg > 0) g.bout_amax[(int64_t)sg * Mp + rowv[u]] = m;  // one block per row: this segment's partial (plain store)
+        else atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(m));
+      }
     }
   };
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -858,8 +860,10 @@ __global__ __launch_bounds__(256) void k_bout_amax_lds(GemmArgs g, int tiles_n32
 #pragma unroll
     for (int u = 0; u < RG; ++u) {
       const float m = pair32_max(cur[u]);
-      if (lh == 0 && rowv[u] >= 0)
-        atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(m));
+      if (lh == 0 && rowv[u] >= 0) {
+        if (g.bout_nseg > 0) g.bout_amax[(int64_t)sg * Mp + rowv[u]] = m;
+        else atomicMax((unsigned int*)g.bout_amax + (int64_t)rowv[u] * g.bout_nblk + cur_blk, __float_as_uint(m));
+      }
     }
   };
   const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1033,7 +1037,9 @@ size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
   if (bout.kind != LQER_Q_MXINT || bout.block == 16) return 0;
   const int64_t Np = lqer_padded_n(N);
   const int64_t L = (bout.block <= 0 || bout.block >= N) ? Np : bout.block;
-  return (size_t)lqer_padded_m(m_max) * ((Np + L - 1) / L) * sizeof(float);
+  const int64_t nblk = (Np + L - 1) / L;
+  // (one block per row on the int8 route: up to LQER_AMAX_NSEG column-segment partials per row instead of one atomic cell)
+  return (size_t)lqer_padded_m(m_max) * (nblk == 1 ? LQER_AMAX_NSEG : nblk) * sizeof(float);
 }
 
 // B_out handling of a launch: 0 pass-through, 1 blocks of 16 (maxima in registers), 2 other blocks (pre-pass); < 0 error
@@ -1102,32 +1108,62 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
   } else if (bout == 2) {
       g.bout_L = L;
       g.bout_nblk = (g.Np + L - 1) / L;
-      const size_t need = (size_t)lqer_padded_m(g.M) * g.bout_nblk * sizeof(float);
+      const int tiles_n32 = g.Np / 32;
+      // One block per row, consumed by the int8 kernel: every wave of the pre-pass leaves the maximum of ITS column segment in its
+      // own cell [segment][row] (plain stores; at most LQER_AMAX_NSEG segments, the GEMM folds them when it reads a row's
+      // constants) - no atomics, so no zero-fill launch in front (4.7 us of a 62-us step at M = 2048).  Other block lengths and
+      // the bf16 kernels: one atomicMax cell per (row, block), zeroed first.
+      // (up to 8 column tiles per segment: beyond N = 4096 the wider segments re-read too much of B^T per wave - 2048 x 11008,
+      // rank 32: 111.9 us with partials against 104.4 with cells, where 4096 x 4096 gains 2 us; tools/ab_i8.py --rows --amax)
+      const bool parts = g.w8 && g.bout_nblk == 1 && !(g.tuning & LQER_TUNE_AMAX_ATOMIC) &&
+                         (tiles_n32 <= 8 * LQER_AMAX_NSEG || (g.tuning & LQER_TUNE_AMAX_PARTS));
+      const size_t need = (size_t)lqer_padded_m(g.M) * (parts ? LQER_AMAX_NSEG : g.bout_nblk) * sizeof(float);
       if (!scratch || scratch_bytes < need) {
         set_error("linear_gemm: scratch %zu B < %zu B for the B_out row-block maxima", scratch_bytes, need);
         return LQER_E_WORKSPACE;
       }
       g.bout_amax = (float*)scratch;
-      (void)hipMemsetAsync(scratch, 0, need, st);
-      const int tiles_n32 = g.Np / 32;
+      g.bout_nseg = 0;
+      if (!parts) (void)hipMemsetAsync(scratch, 0, need, st);
       // padded rank (x limbs of x A) -> 16-deep slices (a template parameter: exact, no per-slice branch) and row groups per wave
       const int nks = g.rp / 16;
-      const int RG = g.rp <= 64 ? 4 : (g.rp <= 128 ? 2 : 1);
+      int RG = g.rp <= 64 ? 4 : (g.rp <= 128 ? 2 : 1);
+      const int nseg_cap = parts ? LQER_AMAX_NSEG : tiles_n32;
+      // (segment partials cap the column split: fewer row groups per wave keep the grid at about a thousand waves)
+      if (parts && nks <= 4)
+        while (RG > 1 && (((g.M + 31) / 32 + RG - 1) / RG) * nseg_cap < 1024) RG >>= 1;
       const int64_t groups = ((g.M + 31) / 32 + RG - 1) / RG;
       int nseg = (int)(LQER_AMAX_WAVES / groups);  // one round of two waves per SIMD (the kernel holds 184-256 registers)
       nseg = nseg < 1 ? 1 : (nseg > tiles_n32 ? tiles_n32 : nseg);
+      nseg = nseg > nseg_cap ? nseg_cap : nseg;
       const int seg_tiles = (tiles_n32 + nseg - 1) / nseg;
-      const int64_t waves = groups * ((tiles_n32 + seg_tiles - 1) / seg_tiles);
+      const int nseg_used = (tiles_n32 + seg_tiles - 1) / seg_tiles;
+      const int64_t waves = groups * nseg_used;
       const unsigned grid = (unsigned)((waves + 3) / 4);
+      if (parts) g.bout_nseg = nseg_used;
 #define LQER_AMAX(RGv, NKSv) k_bout_amax<RGv, NKSv><<<grid, 256, 0, st>>>(g, tiles_n32, seg_tiles)
 #ifndef LQER_AMAX_NO_LDS
-      if (nks == 4 && g.rp == 64) {  // rank 64: the B^T run through LDS, four row groups per workgroup
-        const int64_t wgroups = (groups + 3) / 4;
-        int ns = (int)((LQER_AMAX_WAVES / 4) / wgroups);
+      const int64_t wgroups4 = ((((g.M + 31) / 32 + 3) / 4) + 3) / 4;  // workgroups of the LDS variant along the rows (4 waves x 4 row groups)
+      if (nks == 4 && g.rp == 64 && (!parts || wgroups4 * LQER_AMAX_NSEG >= 256)) {  // rank 64: the B^T run through LDS, four row groups per workgroup
+        int ns = (int)((LQER_AMAX_WAVES / 4) / wgroups4);
         ns = ns < 1 ? 1 : (ns > tiles_n32 ? tiles_n32 : ns);
+        ns = ns > nseg_cap ? nseg_cap : ns;
         const int st_l = (tiles_n32 + ns - 1) / ns;
-        const int64_t wgs = wgroups * ((tiles_n32 + st_l - 1) / st_l);
+        const int ns_used = (tiles_n32 + st_l - 1) / st_l;
+        const int64_t wgs = wgroups4 * ns_used;
+        if (parts) g.bout_nseg = ns_used;
         k_bout_amax_lds<<<(unsigned)wgs, 256, 0, st>>>(g, tiles_n32, st_l);
+      } else if (nks <= 4 && RG < 4) {
+        switch (nks * 4 + RG) {
+          case 4 + 1: LQER_AMAX(1, 1); break;
+          case 4 + 2: LQER_AMAX(2, 1); break;
+          case 8 + 1: LQER_AMAX(1, 2); break;
+          case 8 + 2: LQER_AMAX(2, 2); break;
+          case 12 + 1: LQER_AMAX(1, 3); break;
+          case 12 + 2: LQER_AMAX(2, 3); break;
+          case 16 + 1: LQER_AMAX(1, 4); break;
+          default: LQER_AMAX(2, 4); break;
+        }
       } else
 #endif
       switch (nks) {

@@ -326,7 +326,24 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   auto load_tables = [&](int m0_) {
     if (tid < BM) {
       t_xs = g.xscale[m0_ + tid];
-      if constexpr (LOWRANK && BOUT == 2) t_amax = g.bout_amax[(int64_t)(m0_ + tid) * g.bout_nblk];
+      if constexpr (LOWRANK && BOUT == 2) {
+        if (g.bout_nseg > 0) {  // the pre-pass left one partial per column segment (no atomics, no zero-fill): fold them
+          const int64_t Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
+          // (all cells requested at once - a runtime loop waits for every load in turn, 16 round trips in front of the ring
+          // fill; segments past the last one re-read it: max does not mind)
+          const float* const cell = g.bout_amax + m0_ + tid;
+          const int last = g.bout_nseg - 1;
+          float v[LQER_AMAX_NSEG];
+#pragma unroll
+          for (int sgi = 0; sgi < LQER_AMAX_NSEG; ++sgi) v[sgi] = cell[(int64_t)(sgi < last ? sgi : last) * Mp];
+          float m = v[0];
+#pragma unroll
+          for (int sgi = 1; sgi < LQER_AMAX_NSEG; ++sgi) m = fmaxf(m, v[sgi]);
+          t_amax = m;
+        } else {
+          t_amax = g.bout_amax[(int64_t)(m0_ + tid) * g.bout_nblk];
+        }
+      }
     }
   };
   auto write_tables = [&]() {

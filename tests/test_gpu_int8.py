@@ -356,3 +356,31 @@ def test_int8_tile_rows_default_choice(lq):
     assert rows(5120, 5120, 16384) == 256 and rows(5120, 13824, 16384) == 256 and rows(13824, 5120, 16384) == 256
     assert L.lqer_gemm_route(C.byref(mk(4096, 4096)), 2048, _lib.F16) == _lib.ROUTE_I8
     assert L.lqer_gemm_route(C.byref(mk(4096, 4096)), 100, _lib.F16) != _lib.ROUTE_I8  # below 128 tokens: the bf16 kernels
+
+
+@pytest.mark.parametrize("M,K,N,r", [(2048, 512, 4096, 32), (300, 256, 1000, 16), (4096, 384, 2048, 64), (16384, 256, 1024, 64),
+                                     (640, 256, 512, 128)])
+def test_int8_bout_row_maxima_as_segment_partials(lq, M, K, N, r):
+    """B_out with one block per row on the int8 route: the pre-pass leaves per-column-segment partial maxima in plain stores and
+    the GEMM folds them (round 5: no atomics, no zero-fill launch) - against the atomicMax cells behind a memset (descriptor tuning
+    LQER_TUNE_AMAX_ATOMIC): max is order-independent, so the outputs are bit-identical; stale scratch contents must not matter."""
+    from bench import INT_Q, make_case
+    from lqer_amd import _lib, ops
+
+    x, W, A, B = make_case(M, K, N, r, seed=N + r, quantize_ab=False)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=INT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).half()
+    xd = x.half().to(DEV)
+    mod.tuning = _lib.TUNE_AMAX_PARTS  # (the partials at every N; by default up to N = 4096)
+    y = mod(xd).clone()
+    assert mod._x_i8
+    ws = ops.workspace(torch.device(DEV), 16)
+    ws.fill_(0x7F)  # garbage (large positive floats) in the shared workspace: partial cells are written before they are read
+    assert torch.equal(mod(xd), y)
+    mod.tuning = _lib.TUNE_AMAX_ATOMIC
+    assert torch.equal(mod(xd), y)
+    mod.tuning = _lib.TUNE_AMAX_ATOMIC | _lib.TUNE_I8_ROWS_256
+    assert torch.equal(mod(xd), y)
+    mod.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_PARTS
+    assert torch.equal(mod(xd), y)

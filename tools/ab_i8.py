@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--lib", default=None, help="path of another build of liblqer_hip.so")
+    ap.add_argument("--amax", action="store_true", help="with --rows: 128-row tiles with segment-partial row maxima against atomicMax cells + memset")
     ap.add_argument("--rows", action="store_true", help="compare the int8 kernel's 128-row and 256-row tiles (pinned) and the bf16 route")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -52,6 +53,10 @@ def main():
         d128, d256 = mod._desc(), mod._desc()
         d128.tuning, d256.tuning = _lib.TUNE_I8_ROWS_128, _lib.TUNE_I8_ROWS_256
         variants = [("i8r128", d128), ("i8r256", d256), ("bf16", mod._desc(plain=True))]
+        if a.amax:  # ... and the round-4 form of the B_out pre-pass (atomicMax cells behind a zero-fill launch)
+            d128a = mod._desc()
+            d128a.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_ATOMIC
+            variants = [("i8r128", d128), ("r128at", d128a)]
     for name, desc in variants:
         ws = torch.empty(ops.linear_sizes(desc, M).workspace, dtype=torch.uint8, device=dev)
         xq = ws.data_ptr()
@@ -77,9 +82,12 @@ def main():
         torch.cuda.synchronize()
         outs[name] = y.clone()
     i8n = "i8r128" if a.rows else "int8"
-    d = (outs[i8n].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
-    print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs[i8n] != outs['bf16']).float().mean()):.2e}")
-    if a.rows:
+    if "bf16" in outs:
+        d = (outs[i8n].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
+        print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs[i8n] != outs['bf16']).float().mean()):.2e}")
+    if a.rows and a.amax:
+        print("segment partials vs atomic cells bit-identical:", bool(torch.equal(outs["i8r128"], outs["r128at"])))
+    elif a.rows:
         print("128-row vs 256-row int8 tiles bit-identical:", bool(torch.equal(outs["i8r128"], outs["i8r256"])),
               " default tile rows:", L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, _lib.F16))
     fl = 2.0 * M * K * N + 2.0 * M * r * N
