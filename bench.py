@@ -8,10 +8,12 @@
 A step = one pass of the hot path (x fp16 in -> activation quantize -> rank-r side GEMM -> fused W4A8 GEMM -> y fp16
 out) over one batch of synthetic tokens for every Linear unit this rank owns, inputs resident in HBM.  Default
 workload = BASELINE.json configs[1]: one LqerLinear 4096 -> 4096, rank 32, W4A8 MXINT (block 16), M = 2048 tokens.
-On the default line (one GPU, workload c2) the JSON also carries `configs`: ONE decoder layer of each other BASELINE
-configuration at its full token count - c3 (Llama-7B, 7 projections), c4 (Llama-13B W4A8-INT rank 64, M = 16384, 7
-projections), c5 (OPT-6.7B rank 128, 6 projections) - each with its own packed images, timed region, per-shape dominant-kernel
-time / fraction of peak and oracle parity, so that every BASELINE configuration is under the driver's clock.
+On the default line (one GPU, workload c2) the JSON also carries `configs`: every other BASELINE configuration at its full token
+count - c3 (Llama-7B, all 32 layers x 7 projections), c3int (the same shapes with the reference's INT template: int8 MFMA), c4
+(Llama-13B W4A8-INT rank 64, M = 16384: 8 of its 40 layers), c5 (OPT-6.7B rank 128, all 32 layers x 6 projections) - each with its
+own packed images per Linear, timed region, per-shape dominant-kernel time / fraction of peak, the sustained shader clock and
+oracle parity, so that every BASELINE configuration is under the driver's clock.  With --gpus N > 1 and no --workload the
+headline is BASELINE's multi-GPU configuration (c4, layers split over the ranks) and `replicas_c2` the N independent C2 Linears.
 
 Multi-GPU (one rank per GPU).  Either the driver launches the ranks (`python -m torch.distributed.run
 --nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or a plain `python bench.py
@@ -66,8 +68,10 @@ from benchlib.workloads import (A16_Q, BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, INT8
                                 LLAMA13B, MXINT_Q, OPT_Q, UNQUANTIZED_AB, WORKLOADS, _bfp, _snap_mxint8_dim0, check_rows, flops,
                                 make_case, make_weights, make_x)
 
-# one decoder layer of every other BASELINE configuration, carried by the default line: (workload, steps, warm-up steps)
-CONFIG_LAYERS = (("c3", 10, 3), ("c3int", 10, 3), ("c4", 3, 1), ("c5", 10, 3))
+# every other BASELINE configuration, carried by the default line: (workload, steps, warm-up steps, decoder layers: 0 = the whole
+# model).  c3 / c3int / c5 run at FULL depth (32 layers, own packed images per Linear: ~25 ms per step), c4 (M = 16384: 5 ms per
+# layer) at 8 of its 40 layers - VERDICT r4 item 5
+CONFIG_LAYERS = (("c3", 10, 3, 0), ("c3int", 10, 3, 0), ("c4", 5, 1, 8), ("c5", 10, 3, 0))
 
 
 def parse_args(argv=None):
@@ -75,7 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; 4 for the M=16384 model sweeps)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 10; 1 for the M=16384 sweeps)")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 (BASELINE configs[1]) on one GPU; on several GPUs c4 - BASELINE's multi-GPU configuration (configs[3]: "
+                         "Llama-13B, layers split over the ranks, strong scaling) - with the c2 replicas as the secondary `replicas_c2`")
     ap.add_argument("--sweep", default="auto", choices=["auto", "weak", "strong"],
                     help="multi-GPU: strong = the model's layers split over the ranks (default for c3/c4/c5), weak = every "
                          "rank runs the full unit list (default for single-Linear workloads)")
@@ -115,10 +121,10 @@ def config_layers(ctx, args):
     from benchlib.runner import Opts, run_workload
 
     out = {}
-    for name, steps, warm in CONFIG_LAYERS:
+    for name, steps, warm, nlayers in CONFIG_LAYERS:
         t0 = time.perf_counter()
         try:
-            rec = run_workload(ctx, Opts(workload=name, steps=steps, warmup=warm, layers=1, check=not args.no_check, module=False,
+            rec = run_workload(ctx, Opts(workload=name, steps=steps, warmup=warm, layers=nlayers, check=not args.no_check, module=False,
                                          two_streams=False, cpu_base=False, prewarm_ms=100.0, uninstrumented=False))
             rl = rec["roofline"]
             out[name] = {"workload": rec["config"]["workload"], "value": rec["value"], "unit": rec["unit"],
@@ -126,6 +132,8 @@ def config_layers(ctx, args):
                          "tokens_per_step": rec["config"]["tokens_per_step"], "kernel": rl["kernel"], "frac": rl["frac"],
                          "peak": rl["peak"], "achieved": rl["achieved"], "roofline_unit": rl["unit"],
                          "avg_launch_us": rl["avg_launch_us"], "launches": rl["launches"], "per_shape": rl["per_shape"],
+                         "sustained_mhz": rl.get("sustained_mhz"), "frac_at_sustained_clock": rl.get("frac_at_sustained_clock"),
+                         "layers": rec["config"]["layers_per_rank"][0], "weights": rec["config"]["weights"],
                          "parity_rel_l2": rec["parity_rel_l2"], "parity_rows": rec["parity_rows"]}
         except (Exception, SystemExit) as e:  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -147,6 +155,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
+    # no --workload: one GPU -> c2 (BASELINE configs[1]); several -> BASELINE's own multi-GPU configuration, c4 (configs[3]: layers
+    # split over the ranks by infer_device_map.py:29-37, strong scaling), the c2 replicas (weak scaling: comparable with the
+    # one-GPU headline) as a secondary record
+    default_workload = args.workload is None
+    if default_workload:
+        args.workload = "c2" if (world == 1 or args.shard != "none") else "c4"  # (--shard n splits ONE Linear: c2)
     if args.dry_run_cpu:
         return dry_run_cpu(args, rank, world)
     if not torch.cuda.is_available():
@@ -179,9 +193,21 @@ def main():
     out = run_workload(ctx, opts)
     default_line = (world == 1 and args.workload == "c2" and args.layers == 0 and args.shard == "none" and not args.graph
                     and not args.no_configs)
+    replicas = None
+    if world > 1 and default_workload and args.shard == "none" and not args.graph:
+        # every rank its own C2 Linear on the broadcast batch (N independent units): the weak-scaling figure next to the headline
+        rep = run_workload(ctx, Opts(workload="c2", steps=None, warmup=None, check=not args.no_check, module=False, two_streams=False,
+                                     cpu_base=False, prewarm_ms=100.0, uninstrumented=False))
+        if rank == 0:
+            replicas = {k: rep[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "tokens_per_s", "parity_rel_l2",
+                                            "rank_ms_per_step")}
+            replicas["workload"] = rep["config"]["workload"]
+            replicas["frac"] = rep["roofline"]["frac"]
     if rank == 0:
         if default_line:
             out["configs"] = config_layers(ctx, args)
+        if replicas is not None:
+            out["replicas_c2"] = replicas
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -356,6 +356,10 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         ev_on[0] = True
         uninstrumented = el_u
 
+    # the shader clock the chip holds under this very load: a few one-wave probe workgroups on a side stream
+    # (lqer_clock_probe: s_memtime / s_memrealtime) in the shadow of the same steps, right behind the timed regions
+    sustained_mhz = _sustained_clock(ctx, L, run_abi, steps, elapsed / steps) if (M > 64 and layers_here > 0 and graph is None) else None
+
     # decode workloads: the same steps once more on ONE resident weight (what rounds 1-2 reported: an upper bound)
     resident_fig = None
     if rotate > 1 and graph is None:
@@ -460,6 +464,14 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     routes = sorted({pl["route"] for pl in plans})
     int8 = routes == [_lib.ROUTE_I8]  # every GEMM of the step ran the int8 MFMA main loop
     rl = RL.mfma_roofline(gemm_events, ev_overhead_ms, M, r, routes, int8, one_launch, _lib, o.workload, ev_flags)
+    if sustained_mhz is not None and rank == 0:
+        # peaks are priced at the 2.4 GHz the data sheet quotes; at the clock the chip actually holds under this load the same
+        # kernel can reach peak x sustained / 2400 at most: frac_at_sustained_clock = loop efficiency x everything but the clock
+        rl["sustained_mhz"] = round(sustained_mhz["median_mhz"], 1)
+        rl["sustained_clock"] = sustained_mhz
+        rl["frac_at_sustained_clock"] = round(rl["frac"] * RL.NOMINAL_MHZ / sustained_mhz["median_mhz"], 4)
+        for ps in rl.get("per_shape", []):
+            ps["frac_at_sustained_clock"] = round(ps["frac"] * RL.NOMINAL_MHZ / sustained_mhz["median_mhz"], 4)
     if M <= 64:
         rl = RL.hbm_roofline(gemm_events, ev_overhead_ms, M, r, has_bias, routes, one_launch, _lib, o.workload, ev_flags, rotate,
                              ms_per_step, resident_fig)
@@ -527,6 +539,46 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     if parity is not None:
         assert parity <= 1e-3, f"[{o.workload}] parity of the timed outputs vs the CPU oracle: rel-L2 {parity:.3e} > 1e-3"
     return out
+
+
+def _sustained_clock(ctx, L, run_abi, steps, s_per_step):
+    """Median shader clock (MHz) over 4 probe waves while `run_abi` keeps the chip under the workload's own load.  The probe goes
+    FIRST, on a side stream (a workgroup that comes second would wait for a free register file until the load has drained), the
+    steps follow at once on the launch stream and outlast it; the probe counts the last three quarters of its window.  Events on
+    both streams say whether the window lay inside the load (`inside_load`)."""
+    dev = ctx.dev
+    try:
+        n = max(2, min(steps, int(4e-3 / max(s_per_step, 1e-6)) + 1))
+        dur_us = int(min(max(0.6 * n * s_per_step * 1e6, 200.0), 20000.0))
+        n = max(n, int(dur_us * 1e-6 / max(s_per_step, 1e-6) * 1.4) + 1)  # (the load outlasts the probe)
+        side = torch.cuda.Stream(dev)
+        main = torch.cuda.current_stream(dev)
+        buf = torch.zeros(8, dtype=torch.int64, device=dev)
+        run_abi(min(n, 4))  # (the clock the load holds, not the ramp from idle)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record(side)
+        rc = L.lqer_clock_probe(buf.data_ptr(), 4, dur_us, side.cuda_stream)
+        ev[1].record(side)
+        if rc:
+            return None
+        ev[2].record(main)
+        run_abi(n)
+        ev[3].record(main)
+        torch.cuda.synchronize()
+        pairs = buf.cpu().view(4, 2).double()
+        mhz = sorted(float(c / t * 100.0) for c, t in pairs.tolist() if t > 0)
+        if not mhz:
+            return None
+        load_ms, probe_end_to_load_end = ev[2].elapsed_time(ev[3]), ev[1].elapsed_time(ev[3])
+        return {"median_mhz": round((mhz[(len(mhz) - 1) // 2] + mhz[len(mhz) // 2]) / 2, 1), "min_mhz": round(mhz[0], 1),
+                "max_mhz": round(mhz[-1], 1), "probe_us": dur_us, "steps_under_probe": n, "load_ms": round(load_ms, 3),
+                "inside_load": bool(probe_end_to_load_end >= 0.0 and load_ms * 1e3 >= dur_us),
+                "how": "lqer_clock_probe: 4 one-wave workgroups on a side stream, d(s_memtime) / d(s_memrealtime) x 100 MHz over the last "
+                       "3/4 of the probe window, the same steps running beside it right behind the timed region"}
+    except Exception as e:  # noqa: BLE001 (a diagnostic must not cost the bench line)
+        print(f"# sustained clock probe failed: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
 
 
 def _shared_inputs_region(ctx, live, layers_here, warmup, steps, elapsed):

@@ -389,6 +389,12 @@ int lqer_matmul_q(const void* x, const void* y, void* out, int dtype, int64_t ba
                   int64_t x_bs, int64_t x_rs, int64_t y_bs, int64_t y_ks, int64_t y_js, const lqer_qfmt_t* x_fmt,
                   const lqer_qfmt_t* y_fmt, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- measurement aid ---------------------------------------------------------------------------------------------------
+ * The shader clock the chip holds while other work runs: `nblocks` (1..64) one-wave workgroups on `stream` (a stream of its
+ * own, beside the kernels under study) each write {shader cycles, 100 MHz ticks} elapsed over the last three quarters of about `duration_us` of real time to
+ * out_pairs[2 b], out_pairs[2 b + 1] (device uint64).  MHz = cycles / ticks x 100.  bench.py: roofline.sustained_mhz. */
+int lqer_clock_probe(unsigned long long* out_pairs, int nblocks, int64_t duration_us, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

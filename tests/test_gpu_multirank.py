@@ -65,3 +65,41 @@ def test_column_parallel_linear_is_bit_identical_to_the_unsharded_forward():
     for n0, n1 in ranges:
         assert torch.equal(build(n0, n1)(xd), full[:, n0:n1]), (n0, n1)
     # (OPT_Q's bias blocks are 16 wide: a shard boundary at a multiple of 16 keeps them whole as well)
+
+
+def _bench(cmd_extra, env_extra, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + cmd_extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_multi_gpu_line_is_c4_with_c2_replicas_rehearsed():
+    """`bench.py --gpus 2` with NO --workload (the driver's multi-GPU command), rehearsed on one GPU over gloo: the headline is
+    BASELINE's multi-GPU configuration (c4: layers split over the ranks, strong scaling; --layers 2 keeps the rehearsal short)
+    and `replicas_c2` carries the N independent C2 Linears (weak scaling), both oracle-checked."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _bench(["--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-module"], {"LQER_BENCH_REHEARSE": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["layers_per_rank"] == [1, 1] and "Llama-13B" in d["config"]["workload"]
+    assert d["dtype"] == "int8" and d["parity_rel_l2"] <= 1e-3 and d["value"] > 0
+    r = d["replicas_c2"]
+    assert r["scaling"] == "weak" and r["value"] > 0 and r["parity_rel_l2"] <= 1e-3 and len(r["rank_ms_per_step"]) == 2
+
+
+def test_two_gpus_over_rccl():
+    """The first box with two GPUs that runs this suite exercises RCCL: `bench.py --gpus 2 --workload c4 --layers 4` over the nccl
+    backend - broadcast of the token batch over xGMI, barrier-bracketed timed region, gathers.  Skipped on the
+    one-GPU boxes of this pool."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL)")
+    d = _bench(["--gpus", "2", "--workload", "c4", "--layers", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-module"],
+               {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["layers_per_rank"] == [2, 2]
+    assert d["parity_rel_l2"] <= 1e-3 and d["value"] > 0 and d["broadcast_ms"] > 0
+    assert len(d["rank_ms_per_step"]) == 2 and all(t > 0 for t in d["rank_ms_per_step"])

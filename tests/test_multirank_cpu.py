@@ -270,3 +270,26 @@ def test_dry_run_column_shard_line():
     assert res.returncode == 0, res.stderr[-2000:]
     d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["column_shard"] == {"4096": [0, 2048]}
+
+
+def test_bench_default_workload_on_several_gpus_is_the_baseline_multi_gpu_config():
+    """`python bench.py --gpus 2` with no --workload (the driver's multi-GPU command): the headline is BASELINE's multi-GPU
+    configuration - c4, Llama-13B's 40 layers split 20 / 20 by the reference's rule, strong scaling; with
+    `--gpus 1` the default stays c2 (BASELINE configs[1])."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["layers_per_rank"] == [20, 20]
+    assert "Llama-13B" in out["config"]["workload"]
+    res1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run-cpu"], env=env, capture_output=True,
+                          text=True, timeout=300)
+    assert res1.returncode == 0, res1.stderr[-2000:]
+    out1 = json.loads([ln for ln in res1.stdout.splitlines() if ln.startswith("{")][0])
+    assert out1["n_gpus"] == 1 and "4096x4096" in out1["config"]["workload"]
