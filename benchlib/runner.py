@@ -184,7 +184,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         Kp, Mp = L.lqer_padded_k(K), L.lqer_padded_m(M)
         xl, al = ops.desc_limbs(desc)  # bf16 limbs of the activation / x A images (1, 1 unless pass-through)
         xq = ws.data_ptr()
-        xaq = xq + ((Mp * Kp * 2 * xl + 255) // 256) * 256
+        xaq = xq + L.lqer_act_image_bytes(C.byref(desc), M)  # (the image buffer: wider for weights of 5..8 bits)
         if mod._x_f16 and K % 64 == 0 and (M % 256 == 0 or M <= 64):
             xq = xd.data_ptr()  # fp16 route: a dense, aligned fp16 tensor is its own activation image (include/lqer_hip.h)
         rp = L.lqer_padded_r(r)

@@ -94,7 +94,7 @@ typedef struct lqer_linear_desc {
   int32_t rank;          /* r; 0 = no side path (LinearFlexible, linear.py:88-109) */
   int32_t has_bias;
   lqer_qfmt_t x_fmt;     /* linear.py:148   x_quantizer                        */
-  lqer_qfmt_t w_fmt;     /* linear.py:150   w_quantizer (width must be <= 4)   */
+  lqer_qfmt_t w_fmt;     /* linear.py:150   w_quantizer (block_fp width <= 8: 5..8 bits see "weights of 5..8 bits"; integer <= 4) */
   lqer_qfmt_t b_fmt;     /* linear.py:152   b_quantizer                        */
   lqer_qfmt_t a_out_fmt; /* linear.py:154   A_out_quantizer                    */
   lqer_qfmt_t b_out_fmt; /* linear.py:155   B_out_quantizer                    */
@@ -240,6 +240,10 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* desc, const void* x, int dtyp
                          int64_t ldx, const void* a_t, int a_limbs, void* xq_bf16, void* xaq_bf16,
                          void* scratch, size_t scratch_bytes, void* stream);
 size_t lqer_lowrank_xa_scratch_bytes(const lqer_linear_desc_t* desc, int64_t m_max);
+/* Bytes of the activation image buffer `xq_bf16` of the split calls for up to m_max tokens (what lqer_linear_sizes counts inside
+ * `workspace`): [padded M][padded K x activation limbs x weight limbs] bf16, plus - for weights of 5..8 bits - the single-copy
+ * image behind it.  xaq and the scratch follow at 256-byte aligned offsets in lqer_linear_forward's own carving. */
+size_t lqer_act_image_bytes(const lqer_linear_desc_t* desc, int64_t m_max);
 int lqer_lowrank_xa(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
                     const void* a_t, int a_limbs, void* xaq_bf16, void* scratch,
                     size_t scratch_bytes, void* stream);
@@ -342,6 +346,20 @@ int lqer_desc_limbs(const lqer_linear_desc_t* desc, int* act_limbs, int* xa_limb
  * then skips the copy, and the split API accepts xq == x in lqer_quantize_act_xa / lqer_linear_gemm. */
 int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r,
                      void* a_t_f16, int32_t* flags, void* stream);
+
+/* ---- weights of 5..8 bits (the reference's no-LQER baseline: W8A8 block_fp with one block per row and per token,
+ * experiments/pipeline/sweep_baseline_no_lqer.sh:73-76, through LinearFlexible, quantized_layers/linear.py:50-64) ---------------
+ * The packed image holds 4-bit codes, so a mantissa m of up to 8 bits (|m| <= 127) travels as three signed base-8 digits,
+ * m = 64 a + 8 b + c (a in [-2, 2]; b, c in [-4, 3]): three 4-bit sign-magnitude LIMB images with block exponents e - mbits + 6,
+ * + 3, + 0, side by side along k - w_packed is [Np / 16][3][Kp / 64] panels (lqer_linear_sizes: three times the 4-bit size) - and
+ * the activation image is repeated three times along k to match (the dual of the pass-through activation limbs below).  Every
+ * kernel of the 4-bit path then multiplies the 8-bit weight EXACTLY (digits x powers of two; fp32 accumulation of exact products)
+ * at three times the MFMA work and 13.5 bits per weight: the universal route, at every token count and for every x format.
+ * lqer_pack_weight_mxint writes the three limbs for w_fmt.width in 5..8; lqer_quantize_act_xa writes the single-copy image behind
+ * the wide one (lqer_act_image_bytes) and repeats it; the side path (x A, A_out) works on the single copy.  The one-launch decode
+ * route and the shared-input groups do not take such weights (lqer_decode_partials = 0): decode sizes run the two-launch route.
+ * The FAST route for the reference's own W8A8 configuration - per-token 8-bit activations, one weight block per row - is the
+ * int8 MFMA kernel on an int8 image of the codes themselves (no expand at all): see "int8 route". */
 
 /* ---- int8 route (the "W4A8 INT" configurations: x_quantizer block_fp with block_size [1,-1], i.e. one exponent per token,
  * reference experiments/pipeline/sweep_lqer_act_int.sh:83; w_quantizer blocks of 128 k or one block per row,

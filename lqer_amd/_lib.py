@@ -80,6 +80,7 @@ SIGNATURES = {
     "lqer_linear_forward": (_i, [_dp, _vp, _i, _i64, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _sz, _vp]),
     "lqer_quantize_act_xa": (_i, [_dp, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "lqer_lowrank_xa_scratch_bytes": (_sz, [_dp, _i64]),
+    "lqer_act_image_bytes": (_sz, [_dp, _i64]),
     "lqer_lowrank_xa": (_i, [_dp, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),
     "lqer_linear_gemm_scratch_bytes": (_sz, [_dp, _i64]),
     "lqer_linear_gemm": (_i, [_dp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),

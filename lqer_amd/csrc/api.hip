@@ -78,6 +78,22 @@ static int limbs_of(const lqer_qfmt_t& f) {
   return f.width <= 8 ? 1 : (f.width <= 16 ? 2 : 3);
 }
 static int act_limbs(const lqer_linear_desc_t* d) { return limbs_of(d->x_fmt); }
+// 4-bit limbs of the packed weight: block_fp weights of 5..8 bits travel as three signed base-8 digits side by side along k (pack.hip),
+// the activation image is repeated to match (include/lqer_hip.h "weights of 5..8 bits")
+static int w_limbs(const lqer_linear_desc_t* d) { return (d->w_fmt.kind == LQER_Q_MXINT && d->w_fmt.width > 4) ? 3 : 1; }
+// bytes of the activation image buffer `xq` of the split calls: [Mp][act limbs x weight limbs x Kp] bf16 and, when the weight has
+// limbs, the single-copy image behind it (256-byte aligned) - the quantizer and the side GEMM work on that one, the GEMM on the wide one
+static size_t act_image_bytes(const lqer_linear_desc_t* d, int64_t m_max) {
+  const size_t one = align_up((size_t)lqer_padded_m(m_max) * lqer_padded_k(d->in_features) * 2 * act_limbs(d), 256);
+  const int wl = w_limbs(d);
+  return wl > 1 ? align_up(one * wl, 256) + one : one;
+}
+static void* act_single_copy(const lqer_linear_desc_t* d, void* xq, int64_t M) {
+  const int wl = w_limbs(d);
+  if (wl == 1) return xq;
+  const size_t one = align_up((size_t)lqer_padded_m(M) * lqer_padded_k(d->in_features) * 2 * act_limbs(d), 256);
+  return (unsigned char*)xq + align_up(one * wl, 256);
+}
 static bool x_is_f16(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_PASSTHROUGH_F16; }
 static bool x_is_i8(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_MXINT_I8; }
 // byte offset of the int8 weight image inside w_packed (behind the sign-magnitude panels)
@@ -111,13 +127,14 @@ static bool f16_image_is_input(const lqer_linear_desc_t* d, const void* x, int64
   // decode-size call to the tile kernel, whose buffer range covers whole row tiles)
   const bool smallm = M <= 64 && x_is_f16(d) && lqer_gemm_route(d, M, LQER_F16) == LQER_ROUTE_SMALLM;
   return x_is_f16(d) && ldx == d->in_features && d->in_features % LQER_K_ALIGN == 0 && (M % LQER_M_ALIGN == 0 || smallm) &&
-         ((uintptr_t)x & 15) == 0;
+         ((uintptr_t)x & 15) == 0 && w_limbs(d) == 1;
 }
 // Decode sizes with the fused-quantizer formats: the small-M GEMM reduces the split-K partial tiles of x A itself
 // (lqer_quantize_act_xa / lqer_linear_gemm with xaq == NULL), one launch less on a launch-bound path.
 static bool decode_partials_ok(const lqer_linear_desc_t* d, int64_t M) {
   if (!d || d->rank <= 0 || M <= 0 || M > 64) return false;
   if (d->w_fmt.kind != LQER_Q_MXINT) return false;  // (integer weights: two's-complement nibbles - the tile kernel at every M)
+  if (w_limbs(d) != 1) return false;  // (5..8-bit weights: the GEMM walks three limb images over a repeated activation image)
   if (d->x_fmt.kind != LQER_Q_MXINT || d->a_out_fmt.kind != LQER_Q_MXINT) return false;
   if (!xa_fused_partials_ok(make_qp(d->x_fmt), make_qp(d->a_out_fmt), d->rank)) return false;
   const lqer_qfmt_t& bo = d->b_out_fmt;  // the small-M kernel: B_out pass-through or blocks of 16
@@ -173,7 +190,7 @@ static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, Ge
 // side product's LDS stage (k_lqer_gemm XAPART) - the reduce launch between the quantizer and the GEMM is skipped
 static bool tile_partials_ok(const lqer_linear_desc_t* d, int64_t M, int dtype) {
   if (!d || d->rank <= 0 || M <= 64 || (dtype != LQER_F16 && dtype != LQER_BF16) || !(d->tuning & LQER_TUNE_XA_REDUCE_IN_GEMM)) return false;
-  if (d->w_fmt.kind != LQER_Q_MXINT || d->x_fmt.kind != LQER_Q_MXINT || d->a_out_fmt.kind != LQER_Q_MXINT) return false;
+  if (d->w_fmt.kind != LQER_Q_MXINT || d->x_fmt.kind != LQER_Q_MXINT || d->a_out_fmt.kind != LQER_Q_MXINT || w_limbs(d) != 1) return false;
   if (!xa_fused_partials_ok(make_qp(d->x_fmt), make_qp(d->a_out_fmt), d->rank)) return false;
   const lqer_qfmt_t& bo = d->b_out_fmt;  // (other B_out blocks: the pre-pass reads xAq)
   if (!(bo.kind == LQER_Q_PASSTHROUGH || (bo.kind == LQER_Q_MXINT && bo.block == 16))) return false;
@@ -302,7 +319,9 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
   if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (d->rank > 0 && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
     return LQER_E_INVALID;
   const size_t xl = act_limbs(d), al = xa_limbs(d);  // pass-through activations: images repeated per limb
-  out->w_packed = (Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES * xl;
+  const size_t wl = w_limbs(d);
+  if (!fmt_ok(&d->w_fmt, "w_quantizer", 8)) return LQER_E_UNSUPPORTED;
+  out->w_packed = (Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES * xl * wl;
   if (x_is_i8(d)) {
     if (!i8_formats_ok(d)) return LQER_E_UNSUPPORTED;
     out->w_packed = i8_image_offset(d) + i8_weight_image_bytes(d->out_features, d->in_features);
@@ -317,7 +336,8 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
     side = align_up(a > b ? a : b, 256);  // the two scratch uses never overlap in time
   }
   // (the int8 activation image + row scales of LQER_Q_MXINT_I8 fit the bf16 image's slot: K >= 128)
-  const size_t act = align_up(Mp * Kp * 2 * xl, 256);
+  const size_t act = act_image_bytes(d, m_max);
+  (void)wl;
   if (x_is_i8(d) && i8_act_image_bytes(m_max, d->in_features) + Mp * sizeof(float) > act) {
     set_error("linear_sizes: int8 activation image larger than the bf16 one (K %d)", d->in_features);
     return LQER_E_UNSUPPORTED;
@@ -332,7 +352,7 @@ int lqer_pack_weight_mxint(const void* W, int dtype, int64_t N, int64_t K, int64
     set_error("pack_weight: bad argument");
     return LQER_E_INVALID;
   }
-  if (!fmt_ok(fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
+  if (!fmt_ok(fmt, "w_quantizer", 8)) return LQER_E_UNSUPPORTED;
   if (fmt->kind != LQER_Q_MXINT && fmt->kind != LQER_Q_INT) {
     set_error("w_quantizer: only block_fp and integer weights can be packed");
     return LQER_E_UNSUPPORTED;
@@ -346,7 +366,7 @@ int lqer_pack_weight_mxint_2d(const void* W, int dtype, int64_t N, int64_t K, in
     set_error("pack_weight: bad argument");
     return LQER_E_INVALID;
   }
-  if (!fmt_ok(fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
+  if (!fmt_ok(fmt, "w_quantizer", 8)) return LQER_E_UNSUPPORTED;
   if (fmt->kind != LQER_Q_MXINT) {
     set_error("w_quantizer: only block_fp weights can be packed");
     return LQER_E_UNSUPPORTED;
@@ -407,12 +427,29 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
                              (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+static int quantize_act_xa_single(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
+                                  int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream);
+
 int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
                          int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream) {
   if (!d || (!x && M > 0) || !xq || M < 0 || ldx < d->in_features) {
     set_error("quantize_act_xa: bad argument");
     return LQER_E_INVALID;
   }
+  if (!fmt_ok(&d->w_fmt, "w_quantizer", 8)) return LQER_E_UNSUPPORTED;
+  const int wl = w_limbs(d);
+  if (wl == 1) return quantize_act_xa_single(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, scratch, scratch_bytes, stream);
+  // a weight of three 4-bit limbs: the quantizer and the side GEMM work on the single-copy image behind the wide one, which is
+  // then written as three copies side by side along k (one per weight limb) for the GEMM
+  if (!passthrough_width_ok(d->x_fmt, "x_quantizer")) return LQER_E_INVALID;
+  void* const one = act_single_copy(d, xq, M);
+  const int rc = quantize_act_xa_single(d, x, dtype, M, ldx, a_t, a_limbs, one, xaq, scratch, scratch_bytes, stream);
+  if (rc || M == 0) return rc;
+  return lqer_replicate_rows(one, xq, M, lqer_padded_k(d->in_features) * 2 * act_limbs(d), wl, stream);
+}
+
+static int quantize_act_xa_single(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
+                                  int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream) {
   if (d->rank > 0 && a_t && !xaq) {  // partial tiles only: the GEMM reduces them (decode sizes)
     if (!decode_partials_ok(d, M) && !tile_partials_ok(d, M, dtype)) {
       set_error("quantize_act_xa: xaq == NULL needs M <= 64 or the 128-row tile kernel's token counts with fp16 / bf16 tensors, "
@@ -457,6 +494,10 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
   return lqer_lowrank_xa(d, xq, M, a_t, a_limbs, xaq, scratch, scratch_bytes, stream);
 }
 
+size_t lqer_act_image_bytes(const lqer_linear_desc_t* d, int64_t m_max) {
+  return (d && m_max >= 0 && d->in_features > 0) ? act_image_bytes(d, m_max) : 0;
+}
+
 size_t lqer_linear_gemm_scratch_bytes(const lqer_linear_desc_t* d, int64_t m_max) {
   if (!d || d->rank <= 0 || d->b_out_fmt.kind != LQER_Q_MXINT) return 0;
   return gemm_scratch_bytes(m_max, d->out_features, make_qp(d->b_out_fmt));
@@ -472,7 +513,7 @@ int lqer_linear_gemm(const lqer_linear_desc_t* d, const void* xq, int64_t M, con
 // fills the kernel arguments that depend on the descriptor and the token count alone (shapes, formats, limb counts)
 static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, GemmArgs& g) {
   const bool lowrank = d->rank > 0;
-  if (!fmt_ok(&d->w_fmt, "w_quantizer", 4)) return LQER_E_UNSUPPORTED;
+  if (!fmt_ok(&d->w_fmt, "w_quantizer", 8)) return LQER_E_UNSUPPORTED;
   if (lowrank && !fmt_ok(&d->b_out_fmt, "B_out_quantizer", 24)) return LQER_E_UNSUPPORTED;
   if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (lowrank && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
     return LQER_E_INVALID;
@@ -482,9 +523,11 @@ static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, Ge
   g.N = d->out_features;
   g.Np = (int)lqer_padded_n(d->out_features);
   g.x_f16 = x_is_f16(d) ? 1 : 0;
-  g.Kp = (int)lqer_padded_k(d->in_features) * xl;  // limbs side by side along k, weight image repeated to match
+  // activation limbs side by side along k with the weight image repeated to match - and the other way round for the three
+  // 4-bit limbs of a 5..8-bit weight
+  g.Kp = (int)lqer_padded_k(d->in_features) * xl * w_limbs(d);
   g.rp = (int)lqer_padded_r(d->rank) * al;
-  g.w_mbits = d->w_fmt.width - 1;
+  g.w_mbits = w_limbs(d) > 1 ? 3 : d->w_fmt.width - 1;
   g.tuning = d->tuning;
   g.w_twos = d->w_fmt.kind == LQER_Q_INT ? 1 : 0;
   if (lowrank) g.bout = make_qp(d->b_out_fmt);
@@ -613,8 +656,10 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
   HT_MARK(1);
   if (dtype == LQER_F16 && f16_image_is_input(d, x, M, ldx)) xq = const_cast<void*>(x);  // no copy (never written)
   HT_MARK(2);
-  void* xaq = ws + align_up(Mp * Kp * 2 * xl, 256);
-  void* xa_scratch = ws + align_up(Mp * Kp * 2 * xl, 256) + align_up(Mp * rp * 2 * al, 256);
+  const size_t act = act_image_bytes(d, M);
+  void* xaq = ws + act;
+  void* xa_scratch = ws + act + align_up(Mp * rp * 2 * al, 256);
+  (void)Kp, (void)xl;
   if (decode_partials_ok(d, M) && a_t && b_t) {
     HT_MARK(3);
     const size_t nscr = lqer_lowrank_xa_scratch_bytes(d, M);

@@ -44,6 +44,60 @@ __global__ __launch_bounds__(256) void k_w_exps_rows(int8_t* __restrict__ scratc
   }
 }
 
+// Weights of 5..8 bits (the reference's W8A8 baseline: sweep_baseline_no_lqer.sh:73-76, block_fp width 8): the mantissa m,
+// |m| <= 127, is written in signed base-8 digits, m = 64 a + 8 b + c with a in [-2, 2], b, c in [-4, 3] - three 4-bit sign-magnitude
+// LIMBS with block exponents e - mbits + 6, + 3, + 0.  The image holds them side by side along k (panel (pn, l Kp/64 + pk): limb l),
+// the activation image is repeated three times to match (include/lqer_hip.h "weights of 5..8 bits"): every 4-bit kernel multiplies
+// such a weight exactly, at three times the work - the universal route; the int8 MFMA kernel has an image of its own.
+__device__ __forceinline__ void w8_digits(int m, int (&d)[3]) {
+  const int c = ((m + 4) & 7) - 4;
+  const int m1 = (m - c) >> 3;  // (exact: m - c is a multiple of 8)
+  const int b = ((m1 + 4) & 7) - 4;
+  d[0] = (m1 - b) >> 3, d[1] = b, d[2] = c;
+}
+
+// pass 2 for those: one lane per (padded row, 16-k segment), three panels
+template <int DT>
+__global__ __launch_bounds__(256) void k_w_pack8(const void* __restrict__ W, int64_t N, int64_t K, int64_t ld, QP q,
+                                                 int64_t L, int64_t nblk, const int8_t* __restrict__ scratch,
+                                                 int64_t Np, int64_t Kp, uint8_t* __restrict__ out) {
+  const int64_t segs = Kp / 16, npk = Kp / 64;
+  const int64_t total = Np * segs;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t row = idx / segs, seg = idx - row * segs, k0 = seg * 16;
+    uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    int e = 0;
+    if (row < N && k0 < K) {
+      const int es = scratch[row * nblk + k0 / L];
+      if (es != -128) {
+        e = es;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float w = (k0 + i < K) ? load_elem<DT>(W, row * ld + k0 + i) : 0.0f;
+          int d[3];
+          w8_digits((int)mxint_mantissa(w, e, q), d);
+          const int j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
+#pragma unroll
+          for (int l = 0; l < 3; ++l) {
+            const uint32_t c = (uint32_t)(d[l] < 0 ? (8 - d[l]) : d[l]);  // sign-magnitude, +0 canonical
+            if (i < 8) lo[l] |= c << (4 * pos);
+            else hi[l] |= c << (4 * pos);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      uint8_t* panel = out + ((row / 16) * (3 * npk) + l * npk + seg / 4) * LQER_PANEL_BYTES;
+      *(uint32_t*)(panel + (row % 16) * 32 + (seg % 4) * 4) = lo[l];
+      *(uint32_t*)(panel + (row % 16) * 32 + 16 + (seg % 4) * 4) = hi[l];
+      int eb = e - q.mbits + 3 * (2 - l) + 127;
+      eb = eb < 1 ? 1 : (eb > 254 ? 254 : eb);
+      panel[512 + (row % 16) * 4 + (seg % 4)] = (uint8_t)eb;
+    }
+  }
+}
+
 // pass 2: one lane per (padded row, 16-k segment)
 template <int DT>
 __global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int64_t N, int64_t K, int64_t ld, QP q,
@@ -83,25 +137,34 @@ __global__ __launch_bounds__(256) void k_w_pack(const void* __restrict__ W, int6
   }
 }
 
+// (limbs = 3: the image of a 5..8-bit weight - the value is the sum of its three limbs, each digit x 2^(exponent byte - 127))
 __global__ __launch_bounds__(256) void k_w_unpack(const uint8_t* __restrict__ in, int64_t N, int64_t K, int64_t Kp,
-                                                  int mbits, bool twos, float* __restrict__ out) {
-  const int64_t segs = Kp / 16;
+                                                  int mbits, bool twos, int limbs, float* __restrict__ out) {
+  const int64_t segs = Kp / 16, npk = Kp / 64;
   const int64_t total = N * segs;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t row = idx / segs, seg = idx - row * segs, k0 = seg * 16;
-    const uint8_t* panel = in + ((row / 16) * (Kp / 64) + seg / 4) * LQER_PANEL_BYTES;
-    uint2 c;
-    c.x = *(const uint32_t*)(panel + (row % 16) * 32 + (seg % 4) * 4);
-    c.y = *(const uint32_t*)(panel + (row % 16) * 32 + 16 + (seg % 4) * 4);
-    const int e = (int)panel[512 + (row % 16) * 4 + (seg % 4)] - 127 + mbits;
+    float acc[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const uint32_t word = i < 8 ? c.x : c.y;
-      const int j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
-      const uint32_t nib = (word >> (4 * pos)) & 0xfu;
-      const int v = twos ? ((int)nib >= 8 ? (int)nib - 16 : (int)nib) : ((nib & 8u) ? -(int)(nib & 7u) : (int)nib);
-      if (k0 + i < K) out[row * K + k0 + i] = ldexpf((float)v, e - mbits);
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int l = 0; l < limbs; ++l) {
+      const uint8_t* panel = in + ((row / 16) * (limbs * npk) + l * npk + seg / 4) * LQER_PANEL_BYTES;
+      uint2 c;
+      c.x = *(const uint32_t*)(panel + (row % 16) * 32 + (seg % 4) * 4);
+      c.y = *(const uint32_t*)(panel + (row % 16) * 32 + 16 + (seg % 4) * 4);
+      const int e = (int)panel[512 + (row % 16) * 4 + (seg % 4)] - 127 + mbits;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t word = i < 8 ? c.x : c.y;
+        const int j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
+        const uint32_t nib = (word >> (4 * pos)) & 0xfu;
+        const int v = twos ? ((int)nib >= 8 ? (int)nib - 16 : (int)nib) : ((nib & 8u) ? -(int)(nib & 7u) : (int)nib);
+        acc[i] += ldexpf((float)v, e - mbits);  // (limbs of one value: digits x powers of two - the partial sums are exact)
+      }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (k0 + i < K) out[row * K + k0 + i] = acc[i];
   }
 }
 
@@ -153,15 +216,16 @@ static int pack_w(const void* W, int64_t N, int64_t K, int64_t ld, const QP& q, 
   {
     const int64_t total = Np * (Kp / 16);
     const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    k_w_pack<DT><<<grid, 256, 0, st>>>(W, N, K, ld, q, L, nblk, scratch, Np, Kp, out);
+    if (q.width > 4) k_w_pack8<DT><<<grid, 256, 0, st>>>(W, N, K, ld, q, L, nblk, scratch, Np, Kp, out);
+    else k_w_pack<DT><<<grid, 256, 0, st>>>(W, N, K, ld, q, L, nblk, scratch, Np, Kp, out);
   }
   return check_launch("pack_weight");
 }
 
 int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, int64_t block_rows, void* out,
                          void* scratch, hipStream_t st) {
-  if (q.width < 2 || q.width > 4) {
-    set_error("packed weights hold 4-bit codes: w_quantizer width must be 2..4, got %d", q.width);
+  if (q.width < 2 || q.width > 8 || (q.kind == LQER_Q_INT && q.width > 4)) {
+    set_error("packed weights hold 4-bit codes (block_fp widths 5..8: three 4-bit limbs): w_quantizer width must be 2..8 (integer: 2..4), got %d", q.width);
     return LQER_E_UNSUPPORTED;
   }
   if (!(q.block <= 0 || q.block >= K || q.block % 16 == 0)) {
@@ -182,7 +246,7 @@ int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, bool
   const int64_t total = N * (Kp / 16);
   if (total == 0) return LQER_OK;
   const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-  k_w_unpack<<<grid, 256, 0, st>>>((const uint8_t*)in, N, K, Kp, mbits, twos, out);
+  k_w_unpack<<<grid, 256, 0, st>>>((const uint8_t*)in, N, K, Kp, mbits, twos, mbits > 3 ? 3 : 1, out);
   return check_launch("unpack_weight");
 }
 

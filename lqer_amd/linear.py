@@ -115,7 +115,7 @@ class _LinearBase(nn.Linear):
         self._fw_cache = {}
         fx, fw, K = self._fmt["x"], self._fmt["w"], self.in_features
         if (self.a8_native and fx.kind == _lib.Q_MXINT and fw.kind == _lib.Q_MXINT and fx.width <= 8 and (fx.block <= 0 or fx.block >= K)
-                and K >= 128 and (fw.block <= 0 or fw.block >= K or fw.block % 128 == 0)):
+                and K >= 128 and (fw.block <= 0 or fw.block >= K or fw.block % 128 == 0) and fw.width <= 4):
             # one activation exponent per token, weight blocks of 128 k or more (the W4A8 INT configurations): integer
             # accumulation is exact - the int8 MFMA route, if every weight row's sums provably stay inside i32
             ok, w2 = ops.i8_prepare(p["w"], self.out_features, K, fw)
@@ -130,7 +130,9 @@ class _LinearBase(nn.Linear):
                     if ok16:
                         p["a_t_f16"] = a16
         if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native
-                and fw.kind == _lib.Q_MXINT):  # (integer weights - two's-complement nibbles - have no fp16 main loop: the limb route)
+                and fw.kind == _lib.Q_MXINT and fw.width <= 4):
+            # (integer weights - two's-complement nibbles - have no fp16 main loop, weights of 5..8 bits travel as three 4-bit limbs
+            # over a repeated activation image: the limb route)
             ok, a16 = ops.f16_prepare(p["w"], self.out_features, self.in_features, p.get("a_t"), int(p.get("a_limbs", 0)), self.rank)
             if ok:
                 self._x_f16 = True
@@ -143,7 +145,7 @@ class _LinearBase(nn.Linear):
         L = _lib.lib()
         Kp, Np = L.lqer_padded_k(self.in_features), L.lqer_padded_n(self.out_features)
         q = dict(p)
-        q["w"] = ops.replicate_rows(p["w"], Np // 16, (Kp // 64) * 576, xl)
+        q["w"] = ops.replicate_rows(p["w"], (Np // 16) * ops.w_limbs(fw), (Kp // 64) * 576, xl)  # (every weight limb once per activation limb)
         if self.rank > 0:
             rp = L.lqer_padded_r(self.rank)
             q["a_t"] = ops.replicate_rows(p["a_t"], 3 * rp, Kp * 2, xl)
@@ -156,7 +158,8 @@ class _LinearBase(nn.Linear):
         L = _lib.lib()
         Kp, Np = L.lqer_padded_k(self.in_features), L.lqer_padded_n(self.out_features)
         rp = L.lqer_padded_r(self.rank) if self.rank > 0 else 0
-        rows, rb, c = {"w": (Np // 16, (Kp // 64) * 576, xl), "a_t": (3 * rp, Kp * 2, xl), "b_t": (3 * Np, rp * 2, al)}[name]
+        rows, rb, c = {"w": ((Np // 16) * ops.w_limbs(self._fmt["w"]), (Kp // 64) * 576, xl), "a_t": (3 * rp, Kp * 2, xl),
+                       "b_t": (3 * Np, rp * 2, al)}[name]
         if name == "a_t" and "a_t_limbs" in self._packed:  # fp16 route: the limb image is kept next to the fp16 one
             return self._packed["a_t_limbs"].reshape(-1).view(torch.uint8)
         flat = self._packed[name].reshape(-1).view(torch.uint8)
@@ -474,6 +477,8 @@ class SharedActivation:
         # in one concatenation - such a group stays disabled and its members run one by one
         ok = ok and sum((m.rank + 15) // 16 * 16 for m in self.members) <= 256
         ok = ok and m0._fmt["x"].kind == _lib.Q_MXINT  # (pass-through activations: every member splits x itself)
+        # (weights of 5..8 bits read a three-times repeated activation image: every member makes its own)
+        ok = ok and all(ops.w_limbs(m._fmt["w"]) == 1 for m in self.members)
         self.enabled = bool(ok)
         self._cat = None      # concatenated A^T limb image + member offsets
         self._x = None        # the tensor the images below were made from (strong reference: its address stays taken)

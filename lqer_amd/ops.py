@@ -159,6 +159,11 @@ def quantize_act(x2: torch.Tensor, fmt: QFmt, out: Optional[torch.Tensor] = None
     return out
 
 
+def w_limbs(fmt: QFmt) -> int:
+    """4-bit limb images of a packed weight: 3 for block_fp weights of 5..8 bits (include/lqer_hip.h "weights of 5..8 bits"), else 1."""
+    return 3 if (fmt.kind == _lib.Q_MXINT and fmt.width > 4) else 1
+
+
 def linear_sizes(desc: LinearDesc, m_max: int) -> LinearSizes:
     sz = LinearSizes()
     check(_lib.lib().lqer_linear_sizes(C.byref(desc), m_max, C.byref(sz)), "lqer_linear_sizes")
@@ -174,7 +179,7 @@ def pack_weight(W: torch.Tensor, fmt: QFmt) -> torch.Tensor:
         W = W.contiguous()
     L = _lib.lib()
     Np, Kp = L.lqer_padded_n(N), L.lqer_padded_k(K)
-    packed = torch.empty((Np // 16) * (Kp // 64) * 576, dtype=torch.uint8, device=W.device)
+    packed = torch.empty((Np // 16) * (Kp // 64) * 576 * w_limbs(fmt), dtype=torch.uint8, device=W.device)
     scratch = torch.empty(N * (-(-K // 16)), dtype=torch.int8, device=W.device)
     rows = int(getattr(fmt, "block_rows", 1))
     if rows == 1:

@@ -211,6 +211,12 @@ def main():
         # fixed-point WEIGHTS (round 4): 4-bit `integer`, frac_width 7 - sigma 0.02 is 2.56 steps, both clamps (-8, +7) occur
         ("intw", (12, 192), 192, 112, 32, True, dict(mxint_q, w_quantizer=dict(name="integer", width=4, frac_width=7)), abq, False),
         ("intxw", (2, 35, 128), 128, 160, 16, False, dict(intx5_q, w_quantizer=dict(name="integer", width=4, frac_width=7)), None, True),
+        # weights of 5..8 bits (round 5): the reference's W8A8 formats (sweep_baseline_no_lqer.sh:73-76: block_fp width 8, one block
+        # per row / per token) with a side path, blocks of 128, blocks of 16 beside block-16 activations, and a 6-bit weight
+        ("w8row", (9, 256), 256, 96, 32, True, dict(int_q, w_quantizer=bfp_cfg(8, [1, -1], False), b_quantizer=bfp_cfg(8, [1, -1], False)), abq, False),
+        ("w8g128", (9, 256), 256, 96, 32, False, dict(int_q, w_quantizer=bfp_cfg(8, [1, 128], False)), None, True),
+        ("w8b16", (7, 176), 176, 160, 32, True, dict(mxint_q, w_quantizer=bfp_cfg(8, [1, 16], False)), abq, False),
+        ("w6b32", (2, 5, 192), 192, 64, 16, False, dict(mxint_q, w_quantizer=bfp_cfg(6, [1, 32], False)), abq, True),
     ]
     f = {}
     for name, xs, K, N, r, has_b, qc, abc, use_s in cases:
@@ -258,11 +264,31 @@ def main():
     with torch.no_grad():
         y = mod(x)
     f["flex/x"], f["flex/W"], f["flex/bias"], f["flex/y"] = x.numpy(), W.numpy(), b.numpy(), y.numpy()
+    # LinearFlexible in the configuration the reference runs it with (round 5): W8A8, one block per weight row and per token, the
+    # bias in the activations' format (experiments/pipeline/sweep_baseline_no_lqer.sh:50-58, :73-76); and with weight blocks of 128
+    w8a8 = dict(name="flexible", is_ptq=True, default=False, x_quantizer=bfp_cfg(8, [1, -1], True), w_quantizer=bfp_cfg(8, [1, -1], False),
+                b_quantizer=bfp_cfg(8, [1, -1], False))
+    flex_cfgs = {"flex": qc}
+    for fname, fq, shape, K_, N_, seed in (("flex_w8a8_row", w8a8, (2, 9, 320), 320, 144, 78),
+                                           ("flex_w8a8_g128", dict(w8a8, w_quantizer=bfp_cfg(8, [1, 128], False)), (11, 256), 256, 96, 79)):
+        cls = get_cls("linear", fq)
+        torch.manual_seed(seed)
+        x = outliers(torch.randn(*shape), (7, 33))
+        mod = cls(K_, N_, bias=True, q_config=fq, l_config=None)
+        with torch.no_grad():
+            mod.weight.mul_(3.0)  # (the default init is +-1/sqrt(K): spread it over more binades)
+            mod.bias.mul_(0.5)
+        W, b = mod.weight.detach().clone(), mod.bias.detach().clone()
+        with torch.no_grad():
+            y = mod(x)
+        f[f"{fname}/x"], f[f"{fname}/W"], f[f"{fname}/bias"], f[f"{fname}/y"] = x.numpy(), W.numpy(), b.numpy(), y.numpy()
+        f[f"{fname}/wq"], f[f"{fname}/bq"] = mod.weight.detach().numpy(), mod.bias.detach().numpy()
+        flex_cfgs[fname] = fq
     np.savez_compressed(os.path.join(HERE, "forward.npz"), **f)
     import json
 
     cfgs = {c[0]: c[6] for c in cases}
-    cfgs["flex"] = qc
+    cfgs.update(flex_cfgs)
     with open(os.path.join(HERE, "forward_configs.json"), "w") as fh:
         json.dump(cfgs, fh, indent=1)
     print("forward.npz:", len(f), "arrays")

@@ -173,7 +173,8 @@ def _module_from_case(g, cfgs, name, dtype=torch.float32):
     return mod.to(DEV).to(dtype), t
 
 
-FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw", "a16", "a16row", "a16mix", "tile8", "tileall"]
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw", "a16", "a16row", "a16mix", "tile8", "tileall",
+             "w8row", "w8g128", "w8b16", "w6b32"]  # (w8*: weights of 5..8 bits as three 4-bit limbs, round 5)
 
 
 @pytest.mark.parametrize("name", FWD_CASES)
@@ -237,6 +238,42 @@ def test_forward_no_side_path(ops, golden_fwd):
     mod.load_state_dict({"weight": t("W"), "bias": t("bias")})
     y = mod.to(DEV)(t("x").to(DEV)).cpu()
     assert (y - t("y")).norm() / t("y").norm() <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["flex_w8a8_row", "flex_w8a8_g128"])
+def test_forward_no_side_path_w8a8(ops, golden_fwd, name):
+    """SURVEY row a11 in the configuration the reference runs LinearFlexible with (sweep_baseline_no_lqer.sh:73-76: W8A8, one block
+    per weight row and per token) and with weight blocks of 128, against the reference's own outputs; the parameters hold the
+    quantized values afterwards; the packed image gives the quantized weight back bit for bit."""
+    import lqer_amd
+    from lqer_amd import ops as O_
+
+    g, cfgs = golden_fwd
+    t = lambda k: torch.from_numpy(g[f"{name}/{k}"])
+    qc = cfgs[name]
+    N, K = t("W").shape
+    mod = lqer_amd.get_quantized_layer_cls("linear", qc)(K, N, bias=True, q_config=qc, l_config=None)
+    assert type(mod).__name__ == "LinearFlexible"
+    mod.load_state_dict({"weight": t("W"), "bias": t("bias")})
+    mod = mod.to(DEV)
+    y = mod(t("x").to(DEV)).cpu()
+    assert y.shape == t("y").shape
+    assert (y - t("y")).norm() / t("y").norm() <= 1e-5
+    assert torch.equal(mod.weight.detach().cpu(), t("wq")) and torch.equal(mod.bias.detach().cpu(), t("bq"))
+    w_img = mod._single_copy("w")
+    assert w_img.numel() == 3 * (-(-N // 256) * 256 // 16) * (-(-K // 64)) * 576  # three 4-bit limb images
+    assert torch.equal(O_.unpack_weight(w_img, N, K, mod._fmt["w"]).cpu(), t("wq"))
+    # decode sizes and a few rows: the same module at other token counts (other kernels of the 4-bit path), same values
+    x2 = t("x").reshape(-1, K)
+    for rows in (1, 5, x2.shape[0]):
+        yr = mod(x2[:rows].to(DEV)).cpu()
+        ref = t("y").reshape(-1, N)[:rows]
+        assert (yr - ref).norm() / ref.norm() <= 1e-5, rows
+    # 16-bit tensors
+    yh = mod.half()(x2.half().to(DEV)).float().cpu()
+    ref_h = O.lqer_linear_forward(x2.half().float(), t("wq").half().float(), t("bq").half().float(), None, None,
+                                  dict(qc, w_quantizer=dict(name="passthrough"), b_quantizer=dict(name="passthrough")))
+    assert (yh - ref_h).norm() / ref_h.norm() <= 1e-3
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 5e-3), (torch.float32, 1e-5)])

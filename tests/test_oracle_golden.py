@@ -76,7 +76,8 @@ def test_integer_quantizer(golden_q):
         assert torch.equal(got, torch.from_numpy(golden_q[f"int/{tag}/y"]))
 
 
-FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "int128", "introw", "ragged", "a16", "a16row", "a16mix", "intx", "intx70", "tile8", "tileall"]
+FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "int128", "introw", "ragged", "a16", "a16row", "a16mix", "intx", "intx70", "tile8", "tileall",
+             "w8row", "w8g128", "w8b16", "w6b32"]  # (w8*: weights of 5..8 bits, round 5)
 
 
 @pytest.mark.parametrize("name", FWD_CASES)
@@ -104,6 +105,17 @@ def test_forward_no_side_path(golden_fwd):
     t = lambda k: torch.from_numpy(g[f"flex/{k}"])
     y = O.lqer_linear_forward(t("x"), t("W"), t("bias"), None, None, cfgs["flex"])
     assert (y - t("y")).norm() / t("y").norm() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["flex_w8a8_row", "flex_w8a8_g128"])
+def test_forward_no_side_path_w8a8(golden_fwd, name):
+    """LinearFlexible in the configuration the reference runs it with (sweep_baseline_no_lqer.sh:73-76: W8A8, one block per weight
+    row and per token, bias in the activations' format) and with weight blocks of 128: y, the quantized weight and bias."""
+    g, cfgs = golden_fwd
+    t = lambda k: torch.from_numpy(g[f"{name}/{k}"])
+    out = O.lqer_linear_forward(t("x"), t("W"), t("bias"), None, None, cfgs[name], intermediates=True)
+    assert torch.equal(out["wq"], t("wq")) and torch.equal(out["bq"], t("bq"))
+    assert (out["y"] - t("y")).norm() / t("y").norm() <= 1e-6
 
 
 def test_pack_unpack_roundtrip(golden_q):
