@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the LQER quantized-Linear hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|c2int|c2introw|c3int|d1|d16|d1a16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|c2int|c2introw|c3int|c2w8a8|c2w8a8m8k|d1|d16|d1a16]
                     [--sweep auto|weak|strong] [--shard none|n] [--no-configs] [--no-cpu-baseline] [--no-check] [--no-module]
                     [--graph G] [--prewarm-ms T] [--dry-run-cpu]
 
@@ -65,7 +65,7 @@ from benchlib.cpu_baseline import cpu_baseline  # noqa: E402,F401
 from benchlib.hipevents import HipEvent  # noqa: E402,F401
 from benchlib.launcher import dry_run_cpu, launch_ranks  # noqa: E402
 from benchlib.workloads import (A16_Q, BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, INT8_MFMA_PEAK_TOPS, INT_Q, INTROW_Q,  # noqa: E402,F401
-                                LLAMA13B, MXINT_Q, OPT_Q, UNQUANTIZED_AB, WORKLOADS, _bfp, _snap_mxint8_dim0, check_rows, flops,
+                                LLAMA13B, MXINT_Q, OPT_Q, UNQUANTIZED_AB, W8A8_Q, WORKLOADS, _bfp, _snap_mxint8_dim0, check_rows, flops,
                                 make_case, make_weights, make_x)
 
 # every other BASELINE configuration, carried by the default line: (workload, steps, warm-up steps, decoder layers: 0 = the whole

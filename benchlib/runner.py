@@ -492,7 +492,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         "data": "synthetic",
         "config": {"workload": desc_txt + (f" [{rotate} distinct packed weights walked round robin: {rotate * 9.4:.0f} MB > the 256 MB "
                                             "Infinity Cache]" if rotate > 1 else ""), "tokens_per_step": M, "rank": r,
-                   "formats": "x %s, W MXINT4/%s, A_out,B_out as x, y fp16" % (
+                   "formats": ("x %%s, W MXINT%d/%%s, A_out,B_out as x, y fp16" % qc["w_quantizer"].get("width", 4)) % (
                        "MXINT8/%s" % qc["x_quantizer"]["block_size"][-1] if qc["x_quantizer"]["name"] == "block_fp"
                        else ("fp16 pass-through (fp16 MFMA main loop)" if f16x else "fp16 pass-through (2 bf16 limbs)"),
                        qc["w_quantizer"]["block_size"][-1]),

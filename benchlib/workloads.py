@@ -21,10 +21,14 @@ INT_Q = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=_bfp(
 # the same with one weight block per row (llama-7b-int.toml:87, block_size [1, -1])
 INTROW_Q = dict(INT_Q, w_quantizer=_bfp(4, [1, -1], False))
 
+# 8-bit weights, one block per row, 8-bit per-token activations: the reference's W8A8 format (experiments/pipeline/
+# sweep_baseline_no_lqer.sh:73-76 runs it through LinearFlexible; here with the rank-32 side path of the INT sweeps, unquantized A / B)
+W8A8_Q = dict(INT_Q, w_quantizer=_bfp(8, [1, -1], False))
+
 # the INT templates as shipped (llama-7b-int.toml q_config.linear): pass-through fp16 activations ("W4A16"), A_out and
 # B_out falling back to the same pass-through (linear.py:115-124), A/B unquantized
 A16_Q = dict(INT_Q, x_quantizer=dict(name="passthrough", width=16, frac_width=12))
-UNQUANTIZED_AB = (INT_Q, INTROW_Q, A16_Q)
+UNQUANTIZED_AB = (INT_Q, INTROW_Q, A16_Q, W8A8_Q)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 INT8_MFMA_PEAK_TOPS = 5000.0    # 2x bf16 per clock (same guide, "Matrix cores", I8 row)
@@ -46,6 +50,12 @@ WORKLOADS = {
                  INTROW_Q, [(4096, 4096, 1)], 1),
     "c3int": ("Llama-7B 7 projections x 32 layers rank32 W4(block128)A8(per-token) M=2048 (llama-7b-int.toml / "
               "sweep_lqer_act_int.sh:81-83)", 2048, 32, False, INT_Q, LLAMA7B, 32),
+    # 8-bit weights on the int8 MFMA kernel's code image (no expand in the main loop); 256-row tiles: M = 2048 fills half of the CUs
+    # at 4096 x 4096, M = 8192 two full rounds
+    "c2w8a8": ("LqerLinear 4096x4096 rank32 W8(one block per row)A8(per-token) M=2048 (sweep_baseline_no_lqer.sh:73-76 format, int8 MFMA)",
+               2048, 32, False, W8A8_Q, [(4096, 4096, 1)], 1),
+    "c2w8a8m8k": ("LqerLinear 4096x4096 rank32 W8(one block per row)A8(per-token) M=8192 (512 tiles of 256 x 256: two full rounds)",
+                  8192, 32, False, W8A8_Q, [(4096, 4096, 1)], 1),
     "c4": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A8(per-token) M=16384 (BASELINE configs[3])", 16384, 64, False,
            INT_Q, LLAMA13B, 40),
     "c4row": ("Llama-13B 7 projections x 40 layers rank64 W4(one block per row, llama-7b-int.toml:87)A8(per-token) M=16384", 16384, 64,

@@ -378,10 +378,17 @@ int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t
  *    consume the int8 images; lqer_gemm_route says whether that is possible for M tokens (LQER_ROUTE_I8: M >= 128,
  *    B_out pass-through or one block per row, padded rank x limbs of x A <= 128);
  *    otherwise call them with kind LQER_Q_MXINT on the same buffers.  lqer_linear_forward chooses by itself.
- * Requires x_fmt.width <= 8, x_fmt.block <= 0 or >= K, w_fmt.block <= 0, >= K or a multiple of 128. */
+ * Requires x_fmt.width <= 8, x_fmt.block <= 0 or >= K, w_fmt.block <= 0, >= K or a multiple of 128.
+ *  - weights of 5..8 bits (the reference's W8A8 baseline, sweep_baseline_no_lqer.sh:73-76): the second image holds the int8 CODES
+ *    themselves - per (256-row tile, 64-k half-step) 256 rows x 64 B, then one scale per row - and the main loop is LDS-DMA, one
+ *    16-byte LDS read per weight fragment and the MFMA: no expand.  It needs ONE exponent per weight row (block_size [1,-1], or
+ *    coarser blocks whose exponents happen to agree): lqer_i8_prepare sets flags[0] otherwise, and such a weight keeps the limb
+ *    route (exact, three times the work).  256-row tiles only (lqer_gemm_tile_rows). */
 int lqer_i8_prepare(void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* w_fmt, int32_t* flags, void* stream);
 /* Test hooks: the int8 weight image (inside w_packed) -> dequantized fp32 [N,K]; x [M,K] -> the int8 activation image. */
 int lqer_unpack_weight_i8(const void* w_packed, int64_t N, int64_t K, float* w_f32, void* stream);
+int lqer_unpack_weight_i8_fmt(const void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* w_fmt, float* w_f32, void* stream); /* ... of
+   a weight of any width (5..8 bits: the image of codes behind the three limb images) */
 int lqer_quantize_act_i8(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const lqer_qfmt_t* fmt, void* xq_i8,
                          void* stream);
 /* dst[row] = src[row] repeated `copies` times (device to device, stream-ordered; dst != src). */

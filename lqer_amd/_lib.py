@@ -96,6 +96,7 @@ SIGNATURES = {
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),
     "lqer_unpack_weight_i8": (_i, [_vp, _i64, _i64, _vp, _vp]),
+    "lqer_unpack_weight_i8_fmt": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),
     "lqer_quantize_act_i8": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp]),
     "lqer_clock_probe": (_i, [_vp, _i, _i64, _vp]),
     "lqer_matmul_q_workspace_bytes": (_sz, [_i64, _i64, _i64]),

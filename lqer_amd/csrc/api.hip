@@ -80,12 +80,17 @@ static int limbs_of(const lqer_qfmt_t& f) {
 static int act_limbs(const lqer_linear_desc_t* d) { return limbs_of(d->x_fmt); }
 // 4-bit limbs of the packed weight: block_fp weights of 5..8 bits travel as three signed base-8 digits side by side along k (pack.hip),
 // the activation image is repeated to match (include/lqer_hip.h "weights of 5..8 bits")
-static int w_limbs(const lqer_linear_desc_t* d) { return (d->w_fmt.kind == LQER_Q_MXINT && d->w_fmt.width > 4) ? 3 : 1; }
+static int w_panel_limbs(const lqer_linear_desc_t* d) { return (d->w_fmt.kind == LQER_Q_MXINT && d->w_fmt.width > 4) ? 3 : 1; }
+// ... and the copies of the activation image that go with them: none on the int8 route (its kernel multiplies the int8 CODES of such
+// a weight, one image of its own behind the limb panels)
+static int w_limbs(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_Q_MXINT_I8 ? 1 : w_panel_limbs(d); }
 // bytes of the activation image buffer `xq` of the split calls: [Mp][act limbs x weight limbs x Kp] bf16 and, when the weight has
 // limbs, the single-copy image behind it (256-byte aligned) - the quantizer and the side GEMM work on that one, the GEMM on the wide one
 static size_t act_image_bytes(const lqer_linear_desc_t* d, int64_t m_max) {
   const size_t one = align_up((size_t)lqer_padded_m(m_max) * lqer_padded_k(d->in_features) * 2 * act_limbs(d), 256);
-  const int wl = w_limbs(d);
+  // (an LQER_Q_MXINT_I8 descriptor sizes for the bf16 kernels too: token counts the int8 kernel does not serve run them on the
+  // same buffers - lqer_linear_forward switches the kind)
+  const int wl = d->x_fmt.kind == LQER_Q_MXINT_I8 ? w_panel_limbs(d) : w_limbs(d);
   return wl > 1 ? align_up(one * wl, 256) + one : one;
 }
 static void* act_single_copy(const lqer_linear_desc_t* d, void* xq, int64_t M) {
@@ -99,7 +104,7 @@ static bool x_is_i8(const lqer_linear_desc_t* d) { return d->x_fmt.kind == LQER_
 // byte offset of the int8 weight image inside w_packed (behind the sign-magnitude panels)
 static size_t i8_image_offset(const lqer_linear_desc_t* d) {
   const size_t Kp = lqer_padded_k(d->in_features), Np = lqer_padded_n(d->out_features);
-  return align_up((Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES, 256);
+  return align_up((Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES * w_panel_limbs(d), 256);
 }
 // static requirements of the int8 route (include/lqer_hip.h "int8 route")
 static bool i8_formats_ok(const lqer_linear_desc_t* d) {
@@ -109,7 +114,7 @@ static bool i8_formats_ok(const lqer_linear_desc_t* d) {
     set_error("LQER_Q_MXINT_I8: x_quantizer must be block_fp with width <= 8 and one block per row (got width %d block %d)", x.width, x.block);
     return false;
   }
-  if (w.kind != LQER_Q_MXINT || w.width > 4 || !(w.block <= 0 || w.block >= K || w.block % I8_BK == 0)) {
+  if (w.kind != LQER_Q_MXINT || w.width > 8 || !(w.block <= 0 || w.block >= K || w.block % I8_BK == 0)) {
     set_error("LQER_Q_MXINT_I8: w_quantizer blocks must span a multiple of 128 k or the whole row (got block %d)", w.block);
     return false;
   }
@@ -309,6 +314,18 @@ int lqer_unpack_weight_i8(const void* w_packed, int64_t N, int64_t K, float* w_f
   return i8_unpack_dispatch((const unsigned char*)w_packed + i8_image_offset(&d), N, K, w_f32, (hipStream_t)stream);
 }
 
+int lqer_unpack_weight_i8_fmt(const void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* w_fmt, float* w_f32, void* stream) {
+  if (!w_packed || !w_f32 || !w_fmt || N <= 0 || K <= 0) {
+    set_error("unpack_weight_i8: bad argument");
+    return LQER_E_INVALID;
+  }
+  lqer_linear_desc_t d;
+  memset(&d, 0, sizeof(d));
+  d.in_features = (int32_t)K, d.out_features = (int32_t)N;
+  d.w_fmt = *w_fmt;
+  return i8_unpack_dispatch((const unsigned char*)w_packed + i8_image_offset(&d), N, K, w_f32, (hipStream_t)stream, w_panel_limbs(&d) > 1);
+}
+
 int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_sizes_t* out) {
   if (!d || !out || d->in_features <= 0 || d->out_features <= 0 || d->rank < 0 || m_max < 0) {
     set_error("linear_sizes: bad descriptor");
@@ -319,12 +336,13 @@ int lqer_linear_sizes(const lqer_linear_desc_t* d, int64_t m_max, lqer_linear_si
   if (!passthrough_width_ok(d->x_fmt, "x_quantizer") || (d->rank > 0 && !passthrough_width_ok(d->a_out_fmt, "A_out_quantizer")))
     return LQER_E_INVALID;
   const size_t xl = act_limbs(d), al = xa_limbs(d);  // pass-through activations: images repeated per limb
-  const size_t wl = w_limbs(d);
+  const size_t wl = w_panel_limbs(d);
   if (!fmt_ok(&d->w_fmt, "w_quantizer", 8)) return LQER_E_UNSUPPORTED;
   out->w_packed = (Np / LQER_PANEL_ROWS) * (Kp / 64) * LQER_PANEL_BYTES * xl * wl;
   if (x_is_i8(d)) {
     if (!i8_formats_ok(d)) return LQER_E_UNSUPPORTED;
-    out->w_packed = i8_image_offset(d) + i8_weight_image_bytes(d->out_features, d->in_features);
+    out->w_packed = i8_image_offset(d) + (wl > 1 ? i8_weight8_image_bytes(d->out_features, d->in_features)
+                                                 : i8_weight_image_bytes(d->out_features, d->in_features));
   }
   out->a_t = 3 * rp * Kp * 2 * xl;
   out->b_t = 3 * Np * rp * 2 * al;
@@ -535,6 +553,8 @@ static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, Ge
     if (!i8_formats_ok(d)) return LQER_E_UNSUPPORTED;
     g.Kp = (int)padded_k8(d->in_features);  // row stride of the int8 activation image
     g.i8_shift = !(d->w_fmt.block <= 0 || d->w_fmt.block >= d->in_features);  // one weight block per row: no shifts at all
+    g.w_i8codes = w_panel_limbs(d) > 1 ? 1 : 0;  // weights of 5..8 bits: the image holds the codes, one exponent per row (lqer_i8_prepare checked)
+    if (g.w_i8codes) g.i8_shift = 0;
     g.w8 = (const uint8_t*)(uintptr_t)1;  // (route query: "the image exists"; lqer_linear_gemm sets the real pointer)
   }
   return LQER_OK;

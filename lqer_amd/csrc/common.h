@@ -404,6 +404,11 @@ __host__ inline size_t i8_weight_image_bytes(int64_t N, int64_t K) {
   const int64_t Np = lqer_padded_n(N);
   return i8_weight_mode_offset(Np, padded_k8(K) / I8_BK) + (size_t)((Np / 256 + 255) / 256 * 256);
 }
+// ... of 8-bit codes (weights of 5..8 bits): per (n tile, 64-k half-step) 256 rows x 64 B, then the row scales fp32 [Np]
+__host__ inline size_t i8_weight8_image_bytes(int64_t N, int64_t K) {
+  const int64_t Np = lqer_padded_n(N);
+  return (size_t)(Np / 256) * (padded_k8(K) / 64) * (256 * 64) + (size_t)Np * sizeof(float);
+}
 
 #ifndef LQER_AMAX_NSEG
 #define LQER_AMAX_NSEG 16  // column-segment partials per row of a one-block-per-row B_out (int8 route: k_bout_amax -> k_lqer_gemm_i8)
@@ -456,6 +461,7 @@ struct GemmArgs {
   int i8_shift;         // some weight group carries a non-zero shift (blocks of 128 with differing exponents)
   int tuning;           // lqer_linear_desc_t.tuning of the call (LQER_TUNE_*: kernel-variant knobs of tests, same bits)
   int w_twos;           // the packed weight holds two's-complement nibbles (w_quantizer = integer): the 128-row tile kernel only
+  int w_i8codes;        // int8 route: w8 holds 8-bit CODES (weights of 5..8 bits, one exponent per row), half-step layout
 };
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
@@ -488,7 +494,7 @@ bool i8_eligible(const GemmArgs& g, int bout);     // gemm_w4a8_i8.hip: the int8
 int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 int i8_tile_rows(const GemmArgs& g);  // 256, or 128 where that takes fewer (weighted) rounds of one tile per CU
 int i8_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, int mbits, void* w_i8, int32_t* flags, hipStream_t st);
-int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st);
+int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st, bool codes8 = false);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16
 int smallm_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 

@@ -216,14 +216,107 @@ __global__ __launch_bounds__(256) void k_i8_unpack(const uint8_t* __restrict__ i
   out[idx] = (float)((mode == I8_MODE_PRESHIFT || mode == I8_MODE_PRESHIFT1) ? c * (1 << (4 - sh)) : 16 * c * (1 << sh)) * wscale[n];
 }
 
+
+// ---- 8-bit weights (W8): the int8 image holds the CODES ------------------------------------------------------------------------
+// Source: the three 4-bit limb images of lqer_pack_weight_mxint (pack.hip: m = 64 a + 8 b + c, limb l at panel column l Kp/64 + pk,
+// limb 2's exponent byte = e - mbits + 127).  Image: per (n tile of 256 rows, half-step of 64 k) 256 rows x 64 B of int8 codes - a
+// row's four 16-byte chunks (16 k each, natural order) XOR-ed with (row >> 2) & 3 - then the row scales 2^(e[n] - mbits) fp32 [Np].
+__device__ __forceinline__ int w8_code(const uint8_t* wp, int64_t n, int nk, int k) {  // k < 64 nk
+  const int kp = k >> 6, kk = k & 63, seg = kk >> 4, i = kk & 15, j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
+  int m = 0;
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    const uint8_t* pnl = wp + ((n / 16) * (3 * (int64_t)nk) + (int64_t)l * nk + kp) * LQER_PANEL_BYTES;
+    const uint32_t word = *(const uint32_t*)(pnl + (n & 15) * 32 + (i < 8 ? 0 : 16) + seg * 4);
+    const uint32_t nib = (word >> (4 * pos)) & 0xfu;
+    const int d = (nib & 8u) ? -(int)(nib & 7u) : (int)nib;
+    m = m * 8 + d;
+  }
+  return m;
+}
+
+// per weight row: one exponent for the whole row (else flags[0]: not eligible - a row with several block exponents keeps the
+// limb route), the i32 bound sum_k |code| 127 < 2^31, the row scale
+__global__ __launch_bounds__(256) void k_i8_rows8(const uint8_t* __restrict__ wp, int64_t N, int64_t Np, int nk, int nk8,
+                                                   uint8_t* __restrict__ img, int32_t* __restrict__ flags) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float* wscale = (float*)(img + (size_t)(Np / 256) * nk8 * 2 * (256 * 64));
+  int bb = 0;
+  bool bad = false;
+  unsigned long long asum = 0;
+  if (n < N) {
+    for (int kp = 0; kp < nk; ++kp) {
+      const uint8_t* p2 = wp + ((n / 16) * (3 * (int64_t)nk) + 2 * (int64_t)nk + kp) * LQER_PANEL_BYTES;  // limb 2: exponent e - mbits
+      for (int seg = 0; seg < 4; ++seg) {
+        unsigned a16 = 0;
+        for (int i = 0; i < 16; ++i) {
+          const int c = w8_code(wp, n, nk, kp * 64 + seg * 16 + i);
+          a16 += (unsigned)(c < 0 ? -c : c);
+        }
+        if (!a16) continue;
+        asum += a16;
+        const int eb = p2[512 + (n & 15) * 4 + seg];
+        if (bb == 0) bb = eb;
+        else if (bb != eb) bad = true;
+      }
+    }
+  }
+  if (asum * 127ull >= (1ull << 31)) bad = true;
+  if (bb && bb < 2) bad = true;  // (the scale must be a normal float)
+  wscale[n] = bb ? __uint_as_float((uint32_t)bb << 23) : 0.0f;
+  if (bad) atomicOr(flags, 1);
+}
+
+// one thread per (row, 16-k chunk): 16 codes -> 16 bytes
+__global__ __launch_bounds__(256) void k_i8_codes8(const uint8_t* __restrict__ wp, int64_t N, int64_t Np, int nk, int nk8,
+                                                    uint8_t* __restrict__ img) {
+  const int nh = 2 * nk8;  // half-steps of 64 k in the image (>= nk: the image is padded to 128 k)
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Np * nh * 4) return;
+  const int64_t n = idx / (nh * 4);
+  const int rem = (int)(idx - n * (nh * 4)), h = rem >> 2, c = rem & 3;
+  const int64_t tn = n / 256;
+  const int rl = (int)(n - tn * 256);
+  u32x4 out = {0, 0, 0, 0};
+  if (n < N && h < nk) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t b = (uint32_t)(uint8_t)(int8_t)w8_code(wp, n, nk, h * 64 + c * 16 + i);
+      out[i >> 2] |= b << (8 * (i & 3));
+    }
+  }
+  *(u32x4*)(img + ((size_t)tn * nh + h) * (256 * 64) + rl * 64 + ((c ^ ((rl >> 2) & 3)) << 4)) = out;
+}
+
+// test hook: the image back to dequantized fp32 [N,K]
+__global__ __launch_bounds__(256) void k_i8_unpack8(const uint8_t* __restrict__ img, int64_t N, int64_t K, int64_t Np, int nk8,
+                                                     float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K) return;
+  const int64_t n = idx / K, k = idx - n * K;
+  const int nh = 2 * nk8;
+  const float* wscale = (const float*)(img + (size_t)(Np / 256) * nh * (256 * 64));
+  const int64_t tn = n / 256;
+  const int rl = (int)(n - tn * 256), h = (int)(k >> 6), c = (int)((k & 63) >> 4), i = (int)(k & 15);
+  const int8_t code = (int8_t)img[((size_t)tn * nh + h) * (256 * 64) + rl * 64 + ((c ^ ((rl >> 2) & 3)) << 4) + i];
+  out[idx] = (float)code * wscale[n];
+}
+
 // ---- the GEMM -----------------------------------------------------------------------------------------------------------
 // BOUT: 0 pass-through, 2 one block per row (exponent from the k_bout_amax pre-pass).  SHIFT: the weight's blocks are shorter
 // than its rows - every n tile then says in its MODE byte how its group exponents travel (k_i8_rows): PRESHIFT (the lane
 // cw << (4 - q) carries them: 11 vector instructions per 8 weights - 7 when no row of the tile spreads over more than two
 // binades, PRESHIFT1 -, no folds), FOLD (one v_lshl_add_u32 per output element and group), or NONE.  The main loops live in one
 // kernel; the choice is uniform per tile.
-template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT>
+// W8 (NT = 8, no SHIFT): 8-bit weights (the reference's W8A8 baseline, sweep_baseline_no_lqer.sh:73-76) - the image holds the
+// int8 codes themselves, one exponent per row: the weight fragment of a slice is ONE 16-byte LDS read, no expand at all.  A
+// 128-k step of codes is 32 KiB per tile - twice the nibbles - so the weight ring runs at HALF-step granularity: three slots of
+// 256 rows x 64 k (16 KiB, in the 48 KiB the nibble ring occupies), the half-step h = 2 kt + P in slot h % 3, requested two
+// half-steps ahead; the activation ring stays as it is (three 128-k slots, two steps ahead).
+template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT, bool W8 = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
+  static_assert(!W8 || (NT == 8 && !SHIFT), "8-bit weight codes: 256-row tiles, one exponent per weight row");
+  constexpr int W8_SLOT = 256 * 64;  // one half-step of int8 codes
   using G = Geo<NT>;
   constexpr int BM = G::BM, DEPTH = G::DEPTH, NSLOT = G::NSLOT, A_SLOT = G::A_SLOT, NPA = G::NPA, OFF_A = G::OFF_A, OFF_W = G::OFF_W;
   constexpr int PANEL = G::PANEL, EP_STAGE = G::EP_STAGE, EP_OUT = G::EP_OUT, EP_TAB = G::EP_TAB;
@@ -278,7 +371,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // 256 shift bytes (4 B per lane)
   const int w_voff0 = (2 * wave) * 1024 + lane * 16, w_voff1 = w_voff0 + 1024, s_voff = 256 * 64 + lane * 4;
   const uint8_t* const a_base = xq8 + (int64_t)m0 * Kp8;
-  const uint8_t* const w_base = g.w8 + (size_t)tn * nk * I8_WBLOCK;
+  const uint8_t* const w_base = g.w8 + (size_t)tn * nk * (W8 ? 2 * W8_SLOT : I8_WBLOCK);
   int tile_mode = I8_MODE_NONE;  // (workgroup-uniform)
   if constexpr (SHIFT) tile_mode = __builtin_amdgcn_readfirstlane((int)g.w8[i8_weight_mode_offset(g.Np, nk) + tn]);
   auto make_rs = [](const uint8_t* base, uint32_t range) {
@@ -286,7 +379,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64),
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b64 >> 32)) & 0xffffu, range, 0x00020000u};
   };
-  const u32x4 a_rs = make_rs(a_base, (uint32_t)(BM * Kp8)), w_rs = make_rs(w_base, (uint32_t)(nk * I8_WBLOCK));
+  const u32x4 a_rs = make_rs(a_base, (uint32_t)(BM * Kp8)), w_rs = make_rs(w_base, (uint32_t)(nk * (W8 ? 2 * W8_SLOT : I8_WBLOCK)));
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)smem;
   const uint32_t m0_a = lds0 + OFF_A + wave * (8 * NPA) * 128;  // + slot * A_SLOT + piece * 1024
   const uint32_t m0_w = lds0 + OFF_W + (2 * wave) * 1024;  // + slot * W_SLOT (+ 1024: second piece)
@@ -304,6 +397,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const uint32_t fw_a = lds0 + OFF_W + rw * 64 + (((2 * lh) ^ ((rw >> 2) & 3)) << 4);      // slices 0, 1
   const uint32_t fw_b = lds0 + OFF_W + rw * 64 + (((2 * lh + 1) ^ ((rw >> 2) & 3)) << 4);  // slices 2, 3
   const uint32_t fs_addr = lds0 + OFF_W + 256 * 64 + rw;
+  // W8: the row's 64 bytes of a half-step = 4 chunks of 16 k; slice s of the half, lane half lh -> chunk 2 s + lh (XOR-ed as above)
+  const uint32_t fw8_0 = lds0 + OFF_W + rw * 64 + ((lh ^ ((rw >> 2) & 3)) << 4);
+  const uint32_t fw8_1 = lds0 + OFF_W + rw * 64 + (((2 + lh) ^ ((rw >> 2) & 3)) << 4);
 
   // one LDS-DMA batch = the operands of one step: NPA + 2 loads per wave (wave 0: one more)
   auto issue_step = [&](const uint8_t* ab, const uint8_t* wb, int kt, int slot) {
@@ -320,6 +416,20 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + slot * W_SLOT + 256 * 64), 4, s_voff, kt * I8_WBLOCK,
                                                0, 0);
+  };
+  // W8: the two operands have their own cadence
+  auto issue_a8 = [&](const uint8_t* ab, int kt, int slot) {
+    const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ab, 0, BM * Kp8, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + OFF_A + slot * A_SLOT + wave * (8 * NPA) * 128 + i * 1024), 16,
+                                               a_voff[i], kt * I8_BK, 0, 0);
+  };
+  auto issue_w8 = [&](const uint8_t* wb, int h, int ws) {  // half-step h of the tile's codes -> weight slot ws
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, nk * 2 * W8_SLOT, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + ws * W8_SLOT + (2 * wave) * 1024), 16, w_voff0, h * W8_SLOT, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + ws * W8_SLOT + (2 * wave + 1) * 1024), 16, w_voff1, h * W8_SLOT, 0,
+                                             0);
   };
   // per-row constants of the epilogue: requested ahead, written to LDS (asm: invisible to hipcc's waitcnt pass, which would
   // drain the ring fill in front of a visible LDS store) once the ring fill has been issued
@@ -366,9 +476,20 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // the tile's first two steps (past the end of K: dropped by the buffer range check).  A later tile's step 0 is already in
   // slot 0 when the epilogue before it kept out of that slot (one panel of xAq); its row constants were requested there too
   if (first) load_tables(m0);
-  if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
-  issue_step(a_base, w_base, 1, 1);
-  if constexpr (DEPTH == 3) issue_step(a_base, w_base, 2, 2);
+  if constexpr (W8) {
+    // request order [A(0) x 4, W(0) x 2, W(1) x 2, A(1) x 4]: the vmcnt(6) below leaves W(1) and A(1) in flight; the first LOAD's
+    // vmcnt(6) - its own four requests and two more - then retires W(1), which the second LOAD reads
+    if (first || !one_panel) {
+      issue_a8(a_base, 0, 0);
+      issue_w8(w_base, 0, 0);
+    }
+    issue_w8(w_base, 1, 1);
+    issue_a8(a_base, 1, 1);
+  } else {
+    if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
+    issue_step(a_base, w_base, 1, 1);
+    if constexpr (DEPTH == 3) issue_step(a_base, w_base, 2, 2);
+  }
   write_tables();
 
   i32x16 R[NT];
@@ -767,12 +888,80 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+
+  // ---- W8: half-step h = 2 kt + P - the 32-k slices 2 P and 2 P + 1 of all 8 token tiles against this wave's two 16-byte weight
+  // fragments from weight slot h % 3.  LOAD: 16 activation fragments + 2 weight fragments, then the requests: the codes of half-step
+  // h + 2 FIRST, then this half's share of the activations of step kt + 2 - so that vmcnt(6) (this LOAD's four requests and the
+  // previous LOAD's two activation pieces may stay in flight) retires the codes of half-step h + 1 and, at P = 1, every piece of
+  // step kt + 1.  COMPUTE: 16 MFMAs, nothing else.
+  auto half_step_w8 = [&](int kt, auto slot_c, auto half_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int P = decltype(half_c)::value;
+    constexpr int slot_new = (SLOT + DEPTH) % NSLOT;
+    constexpr int WS = (2 * SLOT + P) % 3, WS_NEW = (2 * SLOT + P + 2) % 3;
+    constexpr int A_IMM = (SLOT == 2 ? 0 : SLOT * A_SLOT);  // tile t: + 4096 t
+    __builtin_amdgcn_s_setprio(1);
+    const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
+    const int a_soff = ktn * I8_BK, w_soff = (2 * (kt + 1) + P) * W8_SLOT;
+    const uint32_t m0a0 = m0_a + slot_new * A_SLOT + (2 * P) * 1024, m0a1 = m0a0 + 1024;
+    const uint32_t m0w0 = m0_w + WS_NEW * W8_SLOT, m0w1 = m0w0 + 1024;
+    i32x4 xk[8][2];  // [token tile][slice of this half]
+    i32x4 w0, w1;    // the half's weight fragments: slices 2P, 2P + 1
+    asm volatile(
+        "ds_read_b128 %[x00], %[fa0] offset:%c[aimm]\n\tds_read_b128 %[x01], %[fa1] offset:%c[aimm]\n\t"
+        "ds_read_b128 %[x10], %[fa0] offset:%c[aimm]+4096\n\tds_read_b128 %[x11], %[fa1] offset:%c[aimm]+4096\n\t"
+        "ds_read_b128 %[x20], %[fa0] offset:%c[aimm]+8192\n\tds_read_b128 %[x21], %[fa1] offset:%c[aimm]+8192\n\t"
+        "ds_read_b128 %[x30], %[fa0] offset:%c[aimm]+12288\n\tds_read_b128 %[x31], %[fa1] offset:%c[aimm]+12288\n\t"
+        "ds_read_b128 %[x40], %[fa0] offset:%c[aimm]+16384\n\tds_read_b128 %[x41], %[fa1] offset:%c[aimm]+16384\n\t"
+        "ds_read_b128 %[x50], %[fa0] offset:%c[aimm]+20480\n\tds_read_b128 %[x51], %[fa1] offset:%c[aimm]+20480\n\t"
+        "ds_read_b128 %[x60], %[fa0] offset:%c[aimm]+24576\n\tds_read_b128 %[x61], %[fa1] offset:%c[aimm]+24576\n\t"
+        "ds_read_b128 %[x70], %[fa0] offset:%c[aimm]+28672\n\tds_read_b128 %[x71], %[fa1] offset:%c[aimm]+28672\n\t"
+        "ds_read_b128 %[w0], %[fw0] offset:%c[wimm]\n\tds_read_b128 %[w1], %[fw1] offset:%c[wimm]\n\t"
+        "s_mov_b32 m0, %[m0w0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv0], %[wrs], %[wsoff] offen lds\n\t"
+        "s_mov_b32 m0, %[m0w1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv1], %[wrs], %[wsoff] offen lds\n\t"
+        "s_mov_b32 m0, %[m0a0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av0], %[ars], %[asoff] offen lds\n\t"
+        "s_mov_b32 m0, %[m0a1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av1], %[ars], %[asoff] offen lds\n\t"
+        "s_waitcnt vmcnt(6) lgkmcnt(0)"
+        : [x00] "=&v"(xk[0][0]), [x01] "=&v"(xk[0][1]), [x10] "=&v"(xk[1][0]), [x11] "=&v"(xk[1][1]), [x20] "=&v"(xk[2][0]),
+          [x21] "=&v"(xk[2][1]), [x30] "=&v"(xk[3][0]), [x31] "=&v"(xk[3][1]), [x40] "=&v"(xk[4][0]), [x41] "=&v"(xk[4][1]),
+          [x50] "=&v"(xk[5][0]), [x51] "=&v"(xk[5][1]), [x60] "=&v"(xk[6][0]), [x61] "=&v"(xk[6][1]), [x70] "=&v"(xk[7][0]),
+          [x71] "=&v"(xk[7][1]), [w0] "=&v"(w0), [w1] "=&v"(w1)
+        : [fa0] "v"(SLOT == 2 ? fa_hi[2 * P] : fa_lo[2 * P]), [fa1] "v"(SLOT == 2 ? fa_hi[2 * P + 1] : fa_lo[2 * P + 1]), [aimm] "i"(A_IMM),
+          [fw0] "v"(fw8_0), [fw1] "v"(fw8_1), [wimm] "i"(WS * W8_SLOT), [av0] "v"(a_voff[2 * P]), [av1] "v"(a_voff[2 * P + 1]),
+          [wv0] "v"(w_voff0), [wv1] "v"(w_voff1), [ars] "s"(a_rs), [wrs] "s"(w_rs), [m0a0] "s"(m0a0), [m0a1] "s"(m0a1), [m0w0] "s"(m0w0),
+          [m0w1] "s"(m0w1), [asoff] "s"(a_soff), [wsoff] "s"(w_soff)
+        : "memory");
+    asm volatile("s_barrier" : "+v"(w0)::"memory");
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE
+#pragma unroll
+    for (int t = 0; t < 8; ++t) R[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xk[t][0], w0, R[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) R[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xk[t][1], w1, R[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   using std::integral_constant;
 #ifndef LQER_I8_KSPLIT
 #define LQER_I8_KSPLIT 1  // 0: the token-tile split for every mode (A/B builds)
 #endif
   auto main_loop = [&](auto mode_c) {
-    if constexpr (NT == 4) {
+    if constexpr (W8) {
+      for (int kt = 0; kt < nk; kt += NSLOT) {  // (three steps = six half-steps: activation slot kt % 3, weight slot h % 3)
+        half_step_w8(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+        half_step_w8(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+        if (kt + 1 < nk) {
+          half_step_w8(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{});
+          half_step_w8(kt + 1, integral_constant<int, 1>{}, integral_constant<int, 1>{});
+        }
+        if (kt + 2 < nk) {
+          half_step_w8(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 0>{});
+          half_step_w8(kt + 2, integral_constant<int, 2>{}, integral_constant<int, 1>{});
+        }
+      }
+    } else if constexpr (NT == 4) {
       for (int kt = 0; kt < nk; kt += NSLOT) {  // unrolled by the ring size: slots are compile-time constants
         step4(kt, integral_constant<int, 0>{}, mode_c);
         if (kt + 1 < nk) step4(kt + 1, integral_constant<int, 1>{}, mode_c);
@@ -829,7 +1018,14 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     const int tm_n = tile_n / g.tiles_n;
     tn_next = tile_n - tm_n * g.tiles_n;
     m0_next = tm_n * BM, n0_next = tn_next * BN;
-    if (one_panel) issue_step(xq8 + (int64_t)m0_next * Kp8, g.w8 + (size_t)tn_next * nk * I8_WBLOCK, 0, 0);
+    if constexpr (W8) {
+      if (one_panel) {
+        issue_a8(xq8 + (int64_t)m0_next * Kp8, 0, 0);
+        issue_w8(g.w8 + (size_t)tn_next * nk * 2 * W8_SLOT, 0, 0);
+      }
+    } else {
+      if (one_panel) issue_step(xq8 + (int64_t)m0_next * Kp8, g.w8 + (size_t)tn_next * nk * I8_WBLOCK, 0, 0);
+    }
     load_tables(m0_next);
   }
 
@@ -840,13 +1036,13 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   asm volatile("" : "+s"(wave_e));
   const int lane = lane_e, wave = wave_e;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int ep_out = one_panel ? (wave < 6 ? 2 * A_SLOT + wave * EP_OUT_WAVE : OFF_W + 2 * W_SLOT + (wave - 6) * EP_OUT_WAVE)
+  const int ep_out = one_panel ? (wave < 6 ? 2 * A_SLOT + wave * EP_OUT_WAVE : OFF_W + 2 * (W8 ? W8_SLOT : W_SLOT) + (wave - 6) * EP_OUT_WAVE)
                                : EP_OUT + wave * EP_OUT_WAVE;
   // lane: output column n = n0 + 32 wave + (lane & 31); register j of tile i: token row m0 + 32 i + (j&3) + 8 (j>>2) + 4 lh.
   // Everything per row is tabulated in LDS once (row scale, B_out exponent differences), everything per column is a lane
   // constant; the side product's code is fully static per (limbs, slices) pair.
   const int n = n0 + wave * 32 + l31;
-  const float* const wscale = (const float*)(g.w8 + (size_t)g.tiles_n * nk * I8_WBLOCK);
+  const float* const wscale = (const float*)(g.w8 + (size_t)g.tiles_n * nk * (W8 ? 2 * W8_SLOT : I8_WBLOCK));
   // (EP_TAB + 0: 2^(ex[m] - mbits), read in the conversion pass below)
   const float* const tab_up = (const float*)(smem + EP_TAB + 1024);  // B_out: 2^(mbits - e[m]) ...
   const float* const tab_dn = (const float*)(smem + EP_TAB + 2048);  // ... and 2^(e[m] - mbits)
@@ -1123,6 +1319,34 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 }
 
 template <int DT, int NT>
+static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st);
+
+// 8-bit weight codes: 256-row tiles, half-step weight ring
+template <int DT>
+static int launch_w8(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
+  constexpr int BM = Geo<8>::BM, KERNEL_LDS = Geo<8>::KERNEL_LDS;
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = g.Np / BN;
+  constexpr int CUS = 256;
+  const int nt_all = g.tiles_m * g.tiles_n;
+  const unsigned grid = (unsigned)(nt_all < CUS ? nt_all : CUS);
+#define LQER_I8_LAUNCH8(LR, BO)                                                                   \
+  do {                                                                                            \
+    static LdsLimitOnce lds_once;                                                                 \
+    lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false, 8, true>, KERNEL_LDS);              \
+    k_lqer_gemm_i8<DT, LR, BO, false, 8, true><<<grid, 512, KERNEL_LDS, st>>>(g);                   \
+  } while (0)
+  if (!lowrank)
+    LQER_I8_LAUNCH8(false, 0);
+  else if (bout == 2)
+    LQER_I8_LAUNCH8(true, 2);
+  else
+    LQER_I8_LAUNCH8(true, 0);
+#undef LQER_I8_LAUNCH8
+  return check_launch("lqer_gemm_i8 (8-bit weights)");
+}
+
+template <int DT, int NT>
 static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
   constexpr int BM = Geo<NT>::BM, KERNEL_LDS = Geo<NT>::KERNEL_LDS;
   g.tiles_m = (g.M + BM - 1) / BM;
@@ -1166,6 +1390,7 @@ extern "C" int lqer_debug_set_i8_stamp_buffer(void* p) {
 // expand per MFMA doubles).  Llama-7B projections at M = 2048: 4096 x 4096 fills 128 CUs with 256-row tiles and all 256 with
 // 128-row ones; N = 11008: 2 rounds of 256 rows against 3 x 0.56.  LQER_TUNE_I8_ROWS_* pins the choice (tests: same bits).
 int i8_tile_rows(const GemmArgs& g) {
+  if (g.w_i8codes) return 256;  // (8-bit weight codes: the half-step weight ring is built for 256-row tiles)
   if (g.tuning & LQER_TUNE_I8_ROWS_128) return 128;
   if (g.tuning & LQER_TUNE_I8_ROWS_256) return 256;
   constexpr int64_t CUS = 256;
@@ -1186,6 +1411,15 @@ bool i8_eligible(const GemmArgs& g, int bout) {
 }
 
 int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st) {
+  if (g.w_i8codes) {
+    switch (dtype) {
+      case LQER_F32: return i8::launch_w8<LQER_F32>(g, lowrank, bout, st);
+      case LQER_F16: return i8::launch_w8<LQER_F16>(g, lowrank, bout, st);
+      case LQER_BF16: return i8::launch_w8<LQER_BF16>(g, lowrank, bout, st);
+    }
+    set_error("unknown dtype %d", dtype);
+    return LQER_E_INVALID;
+  }
   const bool t128 = i8_tile_rows(g) == 128;
   switch (dtype) {
     case LQER_F32: return t128 ? i8::launch<LQER_F32, 4>(g, lowrank, bout, st) : i8::launch<LQER_F32, 8>(g, lowrank, bout, st);
@@ -1197,19 +1431,29 @@ int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_
 }
 
 int i8_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, int mbits, void* w_i8, int32_t* flags, hipStream_t st) {
-  (void)mbits;  // (the exponent bytes of the sign-magnitude image are already biased by the mantissa width)
   const int64_t Np = lqer_padded_n(N);
   const int nk = (int)(lqer_padded_k(K) / 64), nk8 = (int)(padded_k8(K) / I8_BK);
   (void)hipMemsetAsync(flags, 0, 2 * sizeof(int32_t), st);
+  if (mbits > 3) {  // 8-bit codes from the three limb images
+    i8::k_i8_rows8<<<(unsigned)(Np / 256), 256, 0, st>>>((const uint8_t*)w_packed, N, Np, nk, nk8, (uint8_t*)w_i8, flags);
+    const int64_t items8 = Np * (2 * nk8) * 4;
+    i8::k_i8_codes8<<<(unsigned)((items8 + 255) / 256), 256, 0, st>>>((const uint8_t*)w_packed, N, Np, nk, nk8, (uint8_t*)w_i8);
+    return check_launch("lqer_i8_prepare (8-bit weights)");
+  }
+  // (the exponent bytes of the sign-magnitude image are already biased by the mantissa width)
   i8::k_i8_rows<<<(unsigned)((Np + 255) / 256), 256, 0, st>>>((const uint8_t*)w_packed, N, Np, nk, nk8, (uint8_t*)w_i8, flags);
   const int64_t items = Np * nk8;
   i8::k_i8_codes<<<(unsigned)((items + 255) / 256), 256, 0, st>>>((const uint8_t*)w_packed, N, Np, nk, nk8, (uint8_t*)w_i8);
   return check_launch("lqer_i8_prepare");
 }
 
-int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st) {
+int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st, bool codes8) {
   const int64_t Np = lqer_padded_n(N);
   const int nk8 = (int)(padded_k8(K) / I8_BK);
+  if (codes8) {
+    i8::k_i8_unpack8<<<(unsigned)((N * K + 255) / 256), 256, 0, st>>>((const uint8_t*)w_i8, N, K, Np, nk8, out);
+    return check_launch("lqer_unpack_weight_i8 (8-bit weights)");
+  }
   i8::k_i8_unpack<<<(unsigned)((N * K + 255) / 256), 256, 0, st>>>((const uint8_t*)w_i8, N, K, Np, nk8, out);
   return check_launch("lqer_unpack_weight_i8");
 }

@@ -115,7 +115,7 @@ class _LinearBase(nn.Linear):
         self._fw_cache = {}
         fx, fw, K = self._fmt["x"], self._fmt["w"], self.in_features
         if (self.a8_native and fx.kind == _lib.Q_MXINT and fw.kind == _lib.Q_MXINT and fx.width <= 8 and (fx.block <= 0 or fx.block >= K)
-                and K >= 128 and (fw.block <= 0 or fw.block >= K or fw.block % 128 == 0) and fw.width <= 4):
+                and K >= 128 and (fw.block <= 0 or fw.block >= K or fw.block % 128 == 0)):
             # one activation exponent per token, weight blocks of 128 k or more (the W4A8 INT configurations): integer
             # accumulation is exact - the int8 MFMA route, if every weight row's sums provably stay inside i32
             ok, w2 = ops.i8_prepare(p["w"], self.out_features, K, fw)

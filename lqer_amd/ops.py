@@ -255,11 +255,16 @@ def i8_prepare(w_packed: torch.Tensor, N: int, K: int, w_fmt: QFmt):
 
 
 @_on_tensor_device
-def unpack_weight_i8(w_packed: torch.Tensor, N: int, K: int) -> torch.Tensor:
-    """Test hook: the int8 route's weight image (inside the buffer of i8_prepare) -> dequantized fp32 [N, K]."""
+def unpack_weight_i8(w_packed: torch.Tensor, N: int, K: int, w_fmt: Optional[QFmt] = None) -> torch.Tensor:
+    """Test hook: the int8 route's weight image (inside the buffer of i8_prepare) -> dequantized fp32 [N, K] (`w_fmt`: needed for
+    weights of 5..8 bits, whose image of codes lies behind three limb images)."""
     _need_gpu(w_packed)
     out = torch.empty(N, K, dtype=torch.float32, device=w_packed.device)
-    check(_lib.lib().lqer_unpack_weight_i8(w_packed.data_ptr(), N, K, out.data_ptr(), _stream(w_packed.device)), "lqer_unpack_weight_i8")
+    if w_fmt is None:
+        check(_lib.lib().lqer_unpack_weight_i8(w_packed.data_ptr(), N, K, out.data_ptr(), _stream(w_packed.device)), "lqer_unpack_weight_i8")
+    else:
+        check(_lib.lib().lqer_unpack_weight_i8_fmt(w_packed.data_ptr(), N, K, C.byref(w_fmt), out.data_ptr(), _stream(w_packed.device)),
+              "lqer_unpack_weight_i8_fmt")
     return out
 
 

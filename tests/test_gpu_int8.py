@@ -384,3 +384,88 @@ def test_int8_bout_row_maxima_as_segment_partials(lq, M, K, N, r):
     assert torch.equal(mod(xd), y)
     mod.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_PARTS
     assert torch.equal(mod(xd), y)
+
+
+def _w8a8(wblock=-1, lqer=True):
+    from bench import _bfp
+
+    return dict(name="flexible_lqer" if lqer else "flexible", is_ptq=True, default=False, x_quantizer=_bfp(8, [1, -1], True),
+                w_quantizer=_bfp(8, [1, wblock], False), b_quantizer=_bfp(8, [1, -1], False))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 5e-3)])
+@pytest.mark.parametrize("M,K,N,r,bias", [(2048, 512, 8192, 0, True),     # LinearFlexible, the reference's W8A8 baseline form (no side path)
+                                          (2304, 200, 8000, 32, True),    # ragged K (padded 200 -> 256: an odd number of half-steps), N, M
+                                          (4096, 1000, 4352, 16, False),  # K = 1000: 16 half-steps of which the last is partly padding
+                                          (600, 384, 8192, 64, False)])   # three tiles of 256 rows, the last with 88 rows
+def test_w8a8_int8_route_vs_oracle_and_limb_route(lq, dtype, tol, M, K, N, r, bias):
+    """Weights of 8 bits with one block per row on the int8 MFMA kernel (round 5: the image holds the codes themselves - LDS-DMA,
+    one 16-byte LDS read per fragment, MFMA; sweep_baseline_no_lqer.sh:73-76 is this format): against the CPU oracle, and against the
+    SAME module on the three-limb route (bf16 kernels, exact too): the integer sums are the same numbers - 16-bit outputs agree
+    except for rare roundings of differently ordered fp32 side sums; run-to-run bit stable; the image gives the weight back."""
+    from bench import make_case
+    from lqer_amd import _lib, ops
+
+    qc = _w8a8(-1, lqer=r > 0)
+    case = make_case(M, K, N, max(r, 16), seed=M + N, bias=bias, quantize_ab=False)
+    x, W = case[0], case[1]
+    cls = lq.LinearFlexibleLqer if r > 0 else lq.LinearFlexible
+    mod = cls(K, N, bias=bias, q_config=qc, l_config={"rank": r} if r > 0 else None)
+    sd = {"weight": W}
+    if r > 0:
+        sd.update(A=case[2][:, :r].contiguous(), B=case[3][:r].contiguous())
+    if bias:
+        sd["bias"] = case[4]
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV).to(dtype)
+    xin = x.to(dtype).to(DEV)
+    y = mod(xin).clone()
+    assert mod._x_i8, "an 8-bit weight with one block per row is eligible for the int8 route"
+    L = _lib.lib()
+    dtc = _lib.F32 if dtype == torch.float32 else _lib.F16
+    assert L.lqer_gemm_route(C.byref(mod._desc()), M, dtc) == _lib.ROUTE_I8 and L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, dtc) == 256
+    for _ in range(5):
+        assert torch.equal(mod(xin), y)
+    wq = ops.quantize_mxint(W.to(dtype).to(DEV), mod._fmt["w"], want=("deq",))["deq"].cpu()
+    wq = torch.where(W.to(dtype).float().abs() <= 1e-8, torch.zeros_like(wq), wq)  # (packed images flush the pass-through range)
+    assert torch.equal(ops.unpack_weight_i8(mod._packed["w"], N, K, mod._fmt["w"]).cpu(), wq)
+    assert torch.equal(ops.unpack_weight(mod._single_copy("w"), N, K, mod._fmt["w"]).cpu(), wq)
+    cast = lambda t: None if t is None else t.to(dtype).float()
+    ref = O.lqer_linear_forward(cast(x), cast(W), cast(case[4]) if bias else None, cast(sd.get("A")), cast(sd.get("B")), qc)
+    assert float((y.float().cpu() - ref).norm() / ref.norm()) <= tol
+    # small token counts run the bf16 kernels on the limb images (same buffers): rows are independent
+    y_small = mod(xin[:100])
+    mod.a8_native = False
+    mod.invalidate_packed(weight_changed=False)
+    y2 = mod(xin)
+    assert not mod._x_i8
+    d = float((y.float() - y2.float()).norm() / y2.float().norm())
+    assert d <= (1e-5 if dtype == torch.float32 else tol / 4), d
+    if dtype != torch.float32:
+        assert float((y != y2).float().mean()) <= 0.01
+    assert torch.equal(y_small, y2[:100])
+
+
+def test_w8_blocks_of_128_take_the_int8_route_only_with_one_exponent_per_row(lq):
+    """8-bit weights in blocks of 128: Gaussian rows carry several exponents per row -> lqer_i8_prepare says no and the Linear keeps
+    the limb route (exact); rows whose blocks share their exponent are eligible - the same kernel, the same results as the limb route."""
+    from bench import make_case
+
+    M, K, N, r = 1024, 512, 1024, 32
+    x, W, A, B = make_case(M, K, N, r, seed=9, quantize_ab=False)
+    qc = _w8a8(128)
+    outs = []
+    for pinned in (False, True):
+        Wv = W.clone()
+        if pinned:
+            Wv = (0.04 * torch.rand(N, K, generator=torch.Generator().manual_seed(3)) - 0.02)
+            Wv[:, ::128] = 0.06  # one element per block pins every block exponent of every row to ceil(log2 0.06) = -4
+        mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+        mod.load_state_dict({"weight": Wv, "A": A, "B": B})
+        mod = mod.to(DEV).half()
+        xin = x.half().to(DEV)
+        y = mod(xin)
+        assert mod._x_i8 == pinned
+        ref = O.lqer_linear_forward(x.half().float(), Wv.half().float(), None, A.half().float(), B.half().float(), qc)
+        assert float((y.float().cpu() - ref).norm() / ref.norm()) <= 1e-3
+        outs.append(y)
