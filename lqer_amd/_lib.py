@@ -8,7 +8,8 @@ import subprocess
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblqer_hip.so")
+# (LQER_AMD_LIB: another build of the library - A/B measurements of one bench command across builds on one box)
+LIB_PATH = os.environ.get("LQER_AMD_LIB") or os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
 ABI_VERSION = 11

@@ -377,8 +377,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_decode1(Args<GROUP ? MAXMEM : 1>
     // (the panel's base as the SCALAR offset - part of the range check on gfx9 -, the lane's place inside a panel as the one
     // vector offset: no per-panel address registers to keep alive across column blocks)
     const int base = __builtin_amdgcn_readfirstlane(kt < nk ? kt * LQER_PANEL_BYTES : 0x7ffffff0);
-    p.cw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, codes_off, base, 0));
-    p.ex = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, exps_off, base, 0);
+#ifndef LQER_D1_WAUX
+#define LQER_D1_WAUX 2  // cache policy of the weight stream's loads: 0 default, 2 non-temporal (once-read bytes: a model walks 3.6 GB
+                        // of packed weights per token - 9.4 -> 9.0 us per forward over 48 rotating weights, bench d1; a single resident
+                        // weight re-read from the Infinity Cache is slower with it, 4.8 -> 5.5 us: not what a model does)
+#endif
+    p.cw = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, codes_off, base, LQER_D1_WAUX));
+    p.ex = __builtin_amdgcn_raw_buffer_load_b32(w_rsrc, exps_off, base, LQER_D1_WAUX);
   };
   // wave w takes panels w, w + 8, ...; two register buffers of 4 panels
   constexpr int UNR = 4;
