@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the LQER quantized-Linear hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|c2int|c2introw|c3int|c2w8a8|c2w8a8m8k|d1|d16|d1a16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c4row|c5|c4a16|c2int|c2introw|c3int|c2w8a8|c2w8a8m8k|d1|d16|d1a16|d1layer]
                     [--sweep auto|weak|strong] [--shard none|n] [--no-configs] [--no-cpu-baseline] [--no-check] [--no-module]
                     [--graph G] [--prewarm-ms T] [--dry-run-cpu]
 

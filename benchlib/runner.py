@@ -69,6 +69,8 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     from lqer_amd import _lib, ops, sweep
 
     rank, world, dev, dist = ctx.rank, ctx.world, ctx.dev, ctx.dist
+    if o.workload == "d1layer":
+        return _decode_layer(ctx, o)
     desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS[o.workload]
     if o.layers > 0:
         layers = o.layers
@@ -766,3 +768,147 @@ def _decode_group_region(ctx, unit, M, r, has_bias, rotate, warmup, steps, ev_fl
                            "vs_c_abi": round(el_m / el, 4)}}
     except Exception as e:  # (a secondary figure must not cost the bench line)
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def _decode_layer(ctx, o):
+    """Workload d1layer: a token step through Llama-7B decoder layers at M = 1 the way the model issues it - q/k/v as ONE launch
+    (lqer_linear_forward_group), o, gate/up as one launch, down - over `layers` distinct layers (own packed images: 113.5 MB each,
+    four of them do not fit the Infinity Cache).  Four launches per layer through the C ABI with pre-built plans; every launch type
+    is sampled with HIP events; algorithmic bytes per layer = the seven packed weights + B^T + A^T images + x + y."""
+    import copy
+
+    import lqer_amd
+    from lqer_amd import _lib, ops, sweep
+    from lqer_amd.linear import SharedActivation
+
+    from .workloads import HBM_PEAK_GBS
+
+    dev = ctx.dev
+    desc_txt, M, r, has_bias, qc, shapes, layers = WORKLOADS["d1layer"]
+    if o.layers > 0:
+        layers = o.layers
+    if ctx.world > 1:
+        sys.exit("d1layer is a single-GPU workload")
+    steps = o.steps if o.steps is not None else 200
+    warmup = o.warmup if o.warmup is not None else 20
+    L = _lib.lib()
+    H, I = 4096, 11008
+    protos = {}
+    for i, (K, N) in enumerate(((H, H), (H, I), (I, H))):
+        g = torch.Generator().manual_seed(sweep.unit_seed(0, i))
+        W, A, B = make_weights(g, K, N, r, bias=False, quantize_ab=True)
+        m = lqer_amd.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+        m.load_state_dict({"weight": W, "A": A, "B": B})
+        protos[(K, N)] = (m.to(dev).half(), (W, A, B))
+    xh = make_x(M, H, seed=0)[0].half().to(dev)
+    xi = make_x(M, I, seed=1)[0].half().to(dev)
+    for (K, N), (m, _) in protos.items():
+        m(xh if K == H else xi)  # packs
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    dtc = _lib.F16
+    lay = []
+    keep = []
+    for _ in range(layers):
+        q, k, v, op = (copy.deepcopy(protos[(H, H)][0]) for _ in range(4))
+        gt, up = (copy.deepcopy(protos[(H, I)][0]) for _ in range(2))
+        dn = copy.deepcopy(protos[(I, H)][0])
+        g_qkv, g_gu = SharedActivation([q, k, v]), SharedActivation([gt, up])
+        assert g_qkv.enabled and g_gu.enabled
+        for m in (q, k, v, op, gt, up):
+            m(xh)
+        dn(xi)
+        torch.cuda.synchronize()
+        p_qkv, p_gu = g_qkv._dplans.get((M, dtc)), g_gu._dplans.get((M, dtc))
+        if p_qkv is None or p_gu is None:
+            sys.exit("d1layer: lqer_linear_forward_group refused a group")
+        ys = [torch.empty(M, n, dtype=torch.float16, device=dev) for n in (H, H, H, I, I)]
+        for i in range(3):
+            p_qkv["tab"][i].y = ys[i].data_ptr()
+        for i in range(2):
+            p_gu["tab"][i].y = ys[3 + i].data_ptr()
+        singles = []
+        for m, x in ((op, xh), (dn, xi)):
+            ent = m._fw_cache[(M, x.dtype, 0)]
+            desc, ws_bytes, dt, consts = ent
+            y = torch.empty(M, m.out_features, dtype=torch.float16, device=dev)
+            singles.append((C.byref(desc), x.data_ptr(), dt, M, m.in_features, consts, y, ws_bytes))
+            keep.append((desc, y))
+        lay.append((p_qkv, p_gu, singles))
+        keep.append((q, k, v, op, gt, up, dn, g_qkv, g_gu, ys))
+    ws = ops.workspace(dev, max([pl["ws"] for la in lay for pl in la[:2]] + [sg[7] for la in lay for sg in la[2]] + [256]))
+    fwd_g, fwd = L.lqer_linear_forward_group, L.lqer_linear_forward
+    ev_flags = int(os.environ.get("LQER_BENCH_EVENT_FLAGS", "0x20000000"), 0)
+    new_pair = lambda: (HipEvent(ev_flags), HipEvent(ev_flags))
+    pool = [new_pair() for _ in range(96)]
+    events = {"qkv": [], "o": [], "gate_up": [], "down": []}
+    no = [0]
+
+    def launch(kind, fn, args, timed):
+        ev = timed and no[0] % 13 == 0 and pool
+        no[0] += 1
+        if ev:
+            e0, e1 = pool.pop()
+            e0.record(stream)
+        rc = fn(*args)
+        if rc:
+            _lib.check(rc, "d1layer " + kind)
+        if ev:
+            e1.record(stream)
+            events[kind].append((e0, e1))
+
+    def step(timed):
+        for p_qkv, p_gu, singles in lay:
+            launch("qkv", fwd_g, (p_qkv["tab"], 3, xh.data_ptr(), dtc, M, H, p_qkv["a_t"], 1, ws.data_ptr(), ws.numel(), stream), timed)
+            d, x, dt, m_, k_, consts, y, _ = singles[0]
+            launch("o", fwd, (d, x, dt, m_, k_, *consts, y.data_ptr(), H, ws.data_ptr(), ws.numel(), stream), timed)
+            launch("gate_up", fwd_g, (p_gu["tab"], 2, xh.data_ptr(), dtc, M, H, p_gu["a_t"], 1, ws.data_ptr(), ws.numel(), stream), timed)
+            d, x, dt, m_, k_, consts, y, _ = singles[1]
+            launch("down", fwd, (d, x, dt, m_, k_, *consts, y.data_ptr(), H, ws.data_ptr(), ws.numel(), stream), timed)
+
+    for _ in range(warmup):
+        step(False)
+    el = timed_region(ctx, lambda n: [step(True) for _ in range(n)], steps)
+    torch.cuda.synchronize()
+    ovh = RL.event_pair_overhead_ms(L, _lib, ops, dev, stream, (xh, H), new_pair, M)
+    # algorithmic bytes (SURVEY 8d's decode model): packed W 0.5625 B per weight, B^T and A^T one bf16 limb, x and y fp16
+    rp = -(-r // 16) * 16
+    lin = lambda K, N: N * K * 0.5625 + N * rp * 2 + rp * K * 2 + M * K * 2 + M * N * 2
+    by = {"qkv": 3 * lin(H, H) - 2 * M * H * 2, "o": lin(H, H), "gate_up": 2 * lin(H, I) - M * H * 2, "down": lin(I, H)}
+    by_layer = sum(by.values())
+    per = {}
+    for kind, evs in events.items():
+        ms = sorted(max(e0.elapsed_time(e1) - ovh, 1e-6) for e0, e1 in evs)
+        if ms:
+            med = ms[len(ms) // 2]
+            per[kind] = {"launch_us": round(med * 1e3, 2), "samples": len(ms), "algorithmic_mb": round(by[kind] / 1e6, 2),
+                         "gb_s": round(by[kind] / (med * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(by[kind] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    us_layer = el / steps / layers * 1e6
+    gbs = by_layer / (us_layer * 1e-6) / 1e9
+    # parity: q of the first layer against the oracle
+    parity = None
+    if o.check:
+        from oracle import lqer_oracle as O
+
+        W, A, B = protos[(H, H)][1]
+        h = lambda t: t.half().float()
+        ref = O.lqer_linear_forward(xh.float().cpu(), h(W), None, h(A), h(B), qc)
+        yq = torch.empty(M, H, dtype=torch.float16, device=dev)
+        lay[0][0]["tab"][0].y = yq.data_ptr()
+        step(False)
+        torch.cuda.synchronize()
+        parity = float((yq.float().cpu() - ref).norm() / ref.norm())
+        assert parity <= 1e-3, parity
+    fl = sum(flops(M, K, N, r) * c for K, N, c in shapes)
+    return {"metric": "W4A8+rank-r Linear GEMM TFLOPS-equiv", "value": round(fl / (us_layer * 1e-6) / 1e12, 3), "unit": "TFLOP/s-equiv", "n_gpus": 1,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": desc_txt + f" [{layers} distinct layers: {layers * 113.5:.0f} MB of packed weights walked per token step]",
+                       "tokens_per_step": M, "rank": r, "layers_per_rank": [layers],
+                       "boundary": "C ABI: lqer_linear_forward_group (q/k/v, gate/up) + lqer_linear_forward (o, down), pre-built plans"},
+            "tokens_per_s": round(M * steps / el, 1), "us_per_layer": round(us_layer, 2), "us_per_linear": round(us_layer / 7, 2),
+            "launches_per_layer": 4,
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": "k_decode1 (four launches per layer, launch gaps included: the whole layer step)",
+                         "algorithmic_bytes_per_layer": int(by_layer), "per_launch": per, "event_pair_overhead_us": round(ovh * 1e3, 2)},
+            "parity_rel_l2": parity}

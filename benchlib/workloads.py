@@ -68,6 +68,10 @@ WORKLOADS = {
     # decode sizes (HBM-bound on the packed weight; roofline quoted in GB/s): the small-M kernel
     "d1": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=1 (decode)", 1, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
     "d16": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=16 (decode)", 16, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),
+    # a decode step the way a model runs it: the 7 projections of Llama-7B decoder layers at M = 1 - q/k/v and gate/up as
+    # one-launch groups (lqer_linear_forward_group), o and down as single launches - walking 4 distinct layers (454 MB of packed weights)
+    "d1layer": ("Llama-7B decoder layer, 7 projections rank32 W4A8-MXINT16 M=1: q/k/v + gate/up as group launches, o + down single (decode)",
+                1, 32, False, MXINT_Q, LLAMA7B, 4),
 }
 
 
