@@ -890,10 +890,14 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   };
 
   // ---- W8: half-step h = 2 kt + P - the 32-k slices 2 P and 2 P + 1 of all 8 token tiles against this wave's two 16-byte weight
-  // fragments from weight slot h % 3.  LOAD: 16 activation fragments + 2 weight fragments, then the requests: the codes of half-step
-  // h + 2 FIRST, then this half's share of the activations of step kt + 2 - so that vmcnt(6) (this LOAD's four requests and the
-  // previous LOAD's two activation pieces may stay in flight) retires the codes of half-step h + 1 and, at P = 1, every piece of
-  // step kt + 1.  COMPUTE: 16 MFMAs, nothing else.
+  // fragments from weight slot h % 3.  LOAD: the 16 activation fragment reads, then the requests (the codes of half-step h + 2
+  // FIRST, then this half's share of the activations of step kt + 2), and only THEN the wait for this half-step's own codes: a wave
+  // reads the weight rows it requested itself, so their landing needs no barrier - just vmcnt(10) (this LOAD's four requests, the
+  // previous LOAD's four and the two activation pieces before those may stay in flight) right in front of the two weight reads,
+  // one phase later than a wait at the end of the previous LOAD would sit (the codes travel two half-steps ahead: that phase is a
+  // quarter of their time budget; measured +-0 at 8192 x 4096 x 4096 - 127.0 vs 127.4 us per launch: the loop is paced by the 64 KiB
+  // the two LDS-DMA streams bring in per step, ~38 GB/s per CU, not by this wait).  The activations, which every wave
+  // reads, keep their wait in front of the barrier: at P = 1 vmcnt(8) retires every piece of step kt + 1.  COMPUTE: 16 MFMAs.
   auto half_step_w8 = [&](int kt, auto slot_c, auto half_c) {
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr int P = decltype(half_c)::value;
@@ -916,12 +920,13 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         "ds_read_b128 %[x50], %[fa0] offset:%c[aimm]+20480\n\tds_read_b128 %[x51], %[fa1] offset:%c[aimm]+20480\n\t"
         "ds_read_b128 %[x60], %[fa0] offset:%c[aimm]+24576\n\tds_read_b128 %[x61], %[fa1] offset:%c[aimm]+24576\n\t"
         "ds_read_b128 %[x70], %[fa0] offset:%c[aimm]+28672\n\tds_read_b128 %[x71], %[fa1] offset:%c[aimm]+28672\n\t"
-        "ds_read_b128 %[w0], %[fw0] offset:%c[wimm]\n\tds_read_b128 %[w1], %[fw1] offset:%c[wimm]\n\t"
         "s_mov_b32 m0, %[m0w0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv0], %[wrs], %[wsoff] offen lds\n\t"
         "s_mov_b32 m0, %[m0w1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv1], %[wrs], %[wsoff] offen lds\n\t"
         "s_mov_b32 m0, %[m0a0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av0], %[ars], %[asoff] offen lds\n\t"
         "s_mov_b32 m0, %[m0a1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av1], %[ars], %[asoff] offen lds\n\t"
-        "s_waitcnt vmcnt(6) lgkmcnt(0)"
+        "s_waitcnt vmcnt(10)\n\t"
+        "ds_read_b128 %[w0], %[fw0] offset:%c[wimm]\n\tds_read_b128 %[w1], %[fw1] offset:%c[wimm]\n\t"
+        "s_waitcnt vmcnt(%c[vmend]) lgkmcnt(0)"
         : [x00] "=&v"(xk[0][0]), [x01] "=&v"(xk[0][1]), [x10] "=&v"(xk[1][0]), [x11] "=&v"(xk[1][1]), [x20] "=&v"(xk[2][0]),
           [x21] "=&v"(xk[2][1]), [x30] "=&v"(xk[3][0]), [x31] "=&v"(xk[3][1]), [x40] "=&v"(xk[4][0]), [x41] "=&v"(xk[4][1]),
           [x50] "=&v"(xk[5][0]), [x51] "=&v"(xk[5][1]), [x60] "=&v"(xk[6][0]), [x61] "=&v"(xk[6][1]), [x70] "=&v"(xk[7][0]),
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         : [fa0] "v"(SLOT == 2 ? fa_hi[2 * P] : fa_lo[2 * P]), [fa1] "v"(SLOT == 2 ? fa_hi[2 * P + 1] : fa_lo[2 * P + 1]), [aimm] "i"(A_IMM),
           [fw0] "v"(fw8_0), [fw1] "v"(fw8_1), [wimm] "i"(WS * W8_SLOT), [av0] "v"(a_voff[2 * P]), [av1] "v"(a_voff[2 * P + 1]),
           [wv0] "v"(w_voff0), [wv1] "v"(w_voff1), [ars] "s"(a_rs), [wrs] "s"(w_rs), [m0a0] "s"(m0a0), [m0a1] "s"(m0a1), [m0w0] "s"(m0w0),
-          [m0w1] "s"(m0w1), [asoff] "s"(a_soff), [wsoff] "s"(w_soff)
+          [m0w1] "s"(m0w1), [asoff] "s"(a_soff), [wsoff] "s"(w_soff), [vmend] "i"(P == 1 ? 8 : 10)
         : "memory");
     asm volatile("s_barrier" : "+v"(w0)::"memory");
     __builtin_amdgcn_s_setprio(0);

@@ -36,7 +36,8 @@ if gemm:
     tot, cnt = 0.0, 0
     for K, N, c in shapes:
         act = M * (-(-K // 128) * 128) * 1 if i8 else M * (-(-K // 64) * 64) * 2
-        w = N * K * (0.5 + 1 / 128 if i8 else 0.5625)
+        w8 = qc["w_quantizer"].get("width", 4) > 4  # 8-bit weights: the int8 image of codes (1 B), or three 4-bit limb images
+        w = N * K * ((1.0 if w8 else 0.5 + 1 / 128) if i8 else (3 * 0.5625 if w8 else 0.5625))
         tot += c * (act + w + M * rp * 2 + N * rp * 2 * limbs + M * N * 2 + (N * 4 if bias else 0))
         if any("k_decode1" in k for k in gemm):
             tot += c * rp * K * 2  # the one-launch forward reads A^T as well
