@@ -41,7 +41,16 @@ constexpr int R_SLOT = (BN / 16) * LQER_PANEL_BYTES;  // 9216 B  packed weight p
 constexpr int OFF_A = 0;
 // per tile height (MT 32-row tiles): activation slot 16 KiB (128 rows) or 8 KiB (64 rows), bf16; the panels behind the ring
 constexpr int a_slot_bytes(int mt) { return 32 * mt * BK * 2; }
-constexpr int gemm_lds_bytes(int mt) { return NSLOT * a_slot_bytes(mt) + NSLOT * R_SLOT; }  // 102400 B / 69632 B (two workgroups per CU)
+#ifdef LQER_ABL_E4M3SIM
+// Timing-only experiment (profiles/r05_e4m3_sim.txt): what the main loop would cost with a second, prefill-only
+// weight image of one e4m3 byte per weight - one more 1-KiB LDS-DMA per wave and step into a shadow region behind the ring (bytes of
+// a neighbouring k-step), one more 16-byte fragment read, and an expand of four v_cvt_scalef32_pk_bf16_fp8 per 8 weights.  The
+// results of this build are garbage; 128-row tiles only.
+constexpr int SH_SLOT = 8192, SH_PAD = 4096;
+constexpr int gemm_lds_bytes(int mt) { return NSLOT * a_slot_bytes(mt) + NSLOT * R_SLOT + NSLOT * SH_SLOT + SH_PAD; }
+#else
+constexpr int gemm_lds_bytes(int mt) { return NSLOT * a_slot_bytes(mt) + NSLOT * R_SLOT; }
+#endif  // 102400 B / 69632 B (two workgroups per CU)
 
 // byte offset of 16-byte chunk `c` (8 bf16 along k) of tile row `r`; rows are 128 B.
 // chunk ^ ((row >> 1) & 7): the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-B slots.
@@ -213,6 +222,11 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     if (wave == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_R + 8192 + slot * R_SLOT), 16, w_voff8,
                                                kt * LQER_PANEL_BYTES, 0, 0);
+#endif
+#ifdef LQER_ABL_E4M3SIM
+    if constexpr (MT == 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_R + NSLOT * R_SLOT + slot * SH_SLOT + wave * 1024), 16, w_voff,
+                                               (kt ^ 1) * LQER_PANEL_BYTES, 0, 0);
 #endif
   };
   // fragment read addresses (slot 0).  Activation: row = wave tile row + lane & 31, chunk 2 ks + (lane >> 5),
@@ -478,7 +492,11 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // which ends (lgkmcnt(0)) before barrier 2kt-1; the overwriting loads are issued after it.
   const bool late = wave >= 4;
   // loads(0) landed; two batches of AP + 1 (3, or 2 with 64-row tiles) may stay in flight
+#ifdef LQER_ABL_E4M3SIM
+  if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+#else
   if constexpr (MT == 4) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+#endif
   else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
   if (late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
@@ -522,6 +540,20 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     bf16x8 xa[4][MT];  // [ks][m tile]
     u32x4 wr;
     uint32_t we;
+#ifdef LQER_ABL_E4M3SIM
+    u32x4 wr2 = {0u, 0u, 0u, 0u};
+    if constexpr (MT == 4) {  // the second half of the e4m3 fragment + its LDS-DMA (waited for by the statement below)
+      const uint32_t m0sh = lds0 + OFF_R + NSLOT * R_SLOT + slot_new * SH_SLOT + wave * 1024;
+      const int sh_soff = (ktn ^ 1) * LQER_PANEL_BYTES;
+      asm volatile("ds_read_b128 %0, %1 offset:%c2\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %6 offen lds"
+                   : "=&v"(wr2)
+                   : "v"(fw_addr), "i"(NSLOT * R_SLOT + SLOT * SH_SLOT), "v"(w_voff), "s"(w_rs), "s"(m0sh), "s"(sh_soff)
+                   : "memory");
+    }
+#define LQER_I_VM "8"
+#else
+#define LQER_I_VM "6"
+#endif
     if constexpr (MT == 4) {
       asm volatile(
           "ds_read_b128 %0, %18 offset:%c25\n\tds_read_b32 %1, %19 offset:%c25+512\n\t"
@@ -540,7 +572,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
           "s_mov_b32 m0, %35\n\ts_nop 0\n\tbuffer_load_dwordx4 %29, %31, %37 offen lds\n\t"
           // own loads of step kt+1 landed: the batches of kt+2 and kt+3 (3 loads each, wave 0: 4 - it waits a little
           // more than it must) may stay in flight
-          "1:\n\ts_waitcnt vmcnt(6) lgkmcnt(0)"
+          "1:\n\ts_waitcnt vmcnt(" LQER_I_VM ") lgkmcnt(0)"
           : "=&v"(wr), "=&v"(we), "=&v"(xa[0][0]), "=&v"(xa[0][1]), "=&v"(xa[0][2]), "=&v"(xa[0][3]), "=&v"(xa[1][0]),
             "=&v"(xa[1][1]), "=&v"(xa[1][2]), "=&v"(xa[1][3]), "=&v"(xa[2][0]), "=&v"(xa[2][1]), "=&v"(xa[2][2]),
             "=&v"(xa[2][3]), "=&v"(xa[3][0]), "=&v"(xa[3][1]), "=&v"(xa[3][2]), "=&v"(xa[3][3])
@@ -570,10 +602,24 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
           : "memory", "scc");
     }
     STAMP(1);  // LDS reads + DMA issue + waits
+#ifdef LQER_ABL_E4M3SIM
+    int sim_ks = 0;
+    auto expand = [&](uint32_t word, uint32_t scale_bits) {  // 8 weights = 2 words of e4m3 bytes: four conversions, nothing else
+      const float scale = __uint_as_float(scale_bits);
+      const uint32_t w2 = wr2[sim_ks++ & 3];
+      u32x4 r;
+      r[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, scale, false));
+      r[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, scale, true));
+      r[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w2, scale, false));
+      r[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w2, scale, true));
+      return __builtin_bit_cast(bf16x8, r);
+    };
+#else
     auto expand = [](uint32_t word, uint32_t scale_bits) {
       if constexpr (WTWOS) return expand_frag_twos(word, scale_bits);
       else return expand_frag_t<XF16>(word, scale_bits);
     };
+#endif
     bf16x8 wb_first = expand(wr[0], (we & 0xffu) << 23);
     asm volatile("s_barrier" : "+v"(wb_first)::"memory");
     __builtin_amdgcn_s_setprio(0);
