@@ -3,7 +3,9 @@
 and quantizer configurations (MXINT blocks of 16, OPT-style bias blocks, the INT configuration, pass-through B_out,
 the INT templates as shipped = pass-through activations on the fp16 or the bf16-limb route, no side path; round 4: 4-bit
 `integer` weights, the int8 route with weight groups spread over several binades - every MODE of the int8 weight image -,
-the GEMM summing the partial tiles of x A itself, and at M <= 8 the q/k/v group launch against its members).  Shapes are
+the GEMM summing the partial tiles of x A itself, and at M <= 8 the q/k/v group launch against its members; round 5: the int8
+kernel from M = 128 with its tile height and pre-pass form pinned at random, weights of 5..8 bits on the limb route and - one
+exponent per row and per token - on the int8 code image).  Shapes are
 drawn to reach every GEMM kernel (small-M / one-launch decode, 128- and 64-row tiles, 256-row tiles bf16 and int8).
 usage: python tools/fuzz_parity.py [cases] [seed]"""
 import os, random, sys
@@ -15,10 +17,15 @@ from oracle import lqer_oracle as O
 
 
 def one_case(rng):
-    kind = rng.choice(["small", "small", "tile", "tile", "tile", "m256", "i8"])
-    if kind == "i8":  # the int8 tile kernel: M >= 512, per-token x, weight blocks of 128 (or whole rows) whose exponents spread
-        return (rng.choice([512, 768, 1024, 1300]), rng.choice([256, 384, 640, 1024]), rng.choice([256, 300, 512, 1024]),
-                rng.choice([0, 16, 32, 64]), rng.choice(["i8spread0", "i8spread2", "i8spread4", "i8spread7", "i8row"]), torch.float16)
+    kind = rng.choice(["small", "small", "tile", "tile", "tile", "m256", "i8", "i8", "w8"])
+    if kind == "i8":  # the int8 tile kernel: M >= 128, per-token x, weight blocks of 128 (or whole rows) whose exponents spread
+        return (rng.choice([128, 130, 200, 256, 384, 512, 768, 1024, 1300]), rng.choice([128, 256, 384, 640, 1024]), rng.choice([256, 300, 512, 1024, 1296]),
+                rng.choice([0, 16, 32, 64]), rng.choice(["i8spread0", "i8spread2", "i8spread4", "i8spread7", "i8row", "w8row", "w8row"]),
+                rng.choice([torch.float16, torch.float16, torch.bfloat16]))
+    if kind == "w8":  # weights of 5..8 bits: any M (decode, small-M, tiles), blocks of 16 / 32 / 128 / the row, MXINT or per-token x
+        return (rng.choice([1, 5, 16, 40, 100, 129, 300, 520]), rng.choice([64, 100, 256, 320, 520]), rng.choice([16, 160, 256, 300, 1024]),
+                rng.choice([0, 16, 32, 64]), rng.choice(["w8b16", "w6b32", "w5b16", "w7g128", "w8row", "w8opt"]),
+                rng.choice([torch.float16, torch.bfloat16, torch.float32]))
     if kind == "small":
         M = rng.randint(1, 64)
     elif kind == "tile":
@@ -39,15 +46,19 @@ def one_case(rng):
 
 def run_case(M, K, N, r, cfgname, dtype, dev):
     i8 = cfgname.startswith("i8")
+    w8 = lambda width, block, base: dict(base, w_quantizer=dict(base["w_quantizer"], width=width, block_size=block))
     if cfgname == "group":
         return run_group(M, K, N, r, dtype, dev)
     qc = {"i8spread0": INT_Q, "i8spread2": INT_Q, "i8spread4": INT_Q, "i8spread7": INT_Q, "i8row": INTROW_Q, "xa_in_gemm": MXINT_Q,
           "intw": dict(MXINT_Q, w_quantizer=dict(name="integer", width=4, frac_width=1 + (M + K) % 4, is_signed=True)),
+          "w8b16": w8(8, [1, 16], MXINT_Q), "w6b32": w8(6, [1, 32], MXINT_Q), "w5b16": w8(5, [1, 16], MXINT_Q), "w7g128": w8(7, [1, 128], INT_Q),
+          "w8row": w8(8, [1, -1], INT_Q), "w8opt": w8(8, [1, 16], OPT_Q),
           "mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q, "bout_pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"}),
           "a16": A16_Q, "a16mix": dict(A16_Q, B_out_quantizer=MXINT_Q["x_quantizer"]),
           "tile": dict(MXINT_Q, w_quantizer=dict(MXINT_Q["w_quantizer"], block_size=[(M % 3 + 1) * 4, 16 * (K % 2 + 1)]))}[cfgname]
-    bias = cfgname == "opt"
-    case = make_case(M, K, N, max(r, 1), seed=M * 7919 + K * 31 + N, bias=bias, quantize_ab=cfgname not in ("int", "a16", "a16mix") and not i8)
+    bias = cfgname in ("opt", "w8opt")
+    case = make_case(M, K, N, max(r, 1), seed=M * 7919 + K * 31 + N, bias=bias,
+                     quantize_ab=cfgname not in ("int", "a16", "a16mix", "w7g128", "w8row") and not i8)
     x, W, A, B = case[:4]
     if cfgname.startswith("i8spread"):  # per (row, 128-k group) scales 2^[0..spread]: PRESHIFT1 / PRESHIFT / FOLD tiles; some rows plain
         spread = int(cfgname[-1])
@@ -71,9 +82,13 @@ def run_case(M, K, N, r, cfgname, dtype, dev):
     mod.load_state_dict(sd)
     mod = mod.to(dev).to(dtype)
     mod.a16_native = (M + K + N) % 3 != 0  # pass-through fp16 activations: mostly the fp16 route, sometimes bf16 limbs
+    from lqer_amd import _lib
     if cfgname == "xa_in_gemm":
-        from lqer_amd import _lib
         mod.tuning = _lib.TUNE_XA_REDUCE_IN_GEMM | (_lib.TUNE_TILE_ROWS_128 if M % 2 else 0)
+    if i8 or cfgname == "w8row":  # the int8 kernel's tile height and the form of its B_out pre-pass, pinned at random (same bits)
+        pick = (M * 31 + K * 7 + N) % 6
+        mod.tuning = [0, _lib.TUNE_I8_ROWS_128, _lib.TUNE_I8_ROWS_256, _lib.TUNE_AMAX_ATOMIC, _lib.TUNE_AMAX_PARTS | _lib.TUNE_I8_ROWS_128,
+                      _lib.TUNE_AMAX_PARTS][pick]
     xin = x.to(dtype)
     y = mod(xin.to(dev)).float().cpu()
     cast = lambda t: None if t is None else t.to(dtype).float()
