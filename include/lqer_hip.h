@@ -162,6 +162,17 @@ int lqer_quantize_mxint(const void* x, int dtype, int64_t rows, int64_t cols, in
                         const lqer_qfmt_t* fmt, float* deq_f32, int8_t* codes, int8_t* exps,
                         void* stream);
 
+/* The same quantizer over 2-D TILES of an activation - blocks that span token rows: x [batches][rows][cols] dense, tiles of
+ * tile_rows x tile_cols (<= 0 or larger than the extent: the whole extent) anchored at (0, 0) of every batch element, ragged
+ * edges clipped (the reference pads them with zeros, which cannot raise a block maximum).  Replaces block_fp.py:111 ->
+ * quantizers/utils.py:211-237 (`_block_3d_activation`: x / A_out / B_out of a [batch, tokens, features] tensor with
+ * block_size [R, L], skip_first_dim = true) and utils.py:161-183 as utils.py:261-270 applies it to a 2-D activation with
+ * skip_first_dim = false (batches = 1).  deq_f32 [batches][rows][cols]; amax_scratch: one float per tile
+ * (batches * ceil(rows / R) * ceil(cols / L)).  A cold path - no template configuration has such blocks; the fused kernels
+ * keep per-row blocks. */
+int lqer_quantize_mxint_tiles(const void* x, int dtype, int64_t batches, int64_t rows, int64_t cols, const lqer_qfmt_t* fmt,
+                              int64_t tile_rows, int64_t tile_cols, float* deq_f32, float* amax_scratch, void* stream);
+
 /* Activation quantizer of the fast path (linear.py:148): x [M,K] -> exact bf16 image
  * xq [lqer_padded_m(M), lqer_padded_k(K)] (K padding zeroed; |x| <= 1e-8 flushed to 0).
  * Needs fmt->width <= 9 so that every value m*2^(e-w+1) is exactly representable in bf16.   */

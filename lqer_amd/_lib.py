@@ -71,6 +71,7 @@ SIGNATURES = {
     "lqer_padded_m": (_i64, [_i64]),
     "lqer_padded_r": (_i64, [_i64]),
     "lqer_quantize_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp, _vp, _vp]),
+    "lqer_quantize_mxint_tiles": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _i64, _i64, _vp, _vp, _vp]),
     "lqer_quantize_act_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp]),
     "lqer_linear_sizes": (_i, [_dp, _i64, C.POINTER(LinearSizes)]),
     "lqer_pack_weight_mxint": (_i, [_vp, _i, _i64, _i64, _i64, _qp, _vp, _vp, _vp]),

@@ -243,6 +243,26 @@ int lqer_quantize_mxint(const void* x, int dtype, int64_t rows, int64_t cols, in
   return quantize_dispatch(x, dtype, rows, cols, ld, q, o, (hipStream_t)stream);
 }
 
+int lqer_quantize_mxint_tiles(const void* x, int dtype, int64_t batches, int64_t rows, int64_t cols, const lqer_qfmt_t* fmt,
+                              int64_t tile_rows, int64_t tile_cols, float* deq_f32, float* amax_scratch, void* stream) {
+  if (batches < 0 || rows < 0 || cols < 0) {
+    set_error("quantize_mxint_tiles: bad shape batches=%lld rows=%lld cols=%lld", (long long)batches, (long long)rows, (long long)cols);
+    return LQER_E_INVALID;
+  }
+  if (batches * rows * cols == 0) return LQER_OK;
+  if (!x || !deq_f32 || !amax_scratch) {
+    set_error("quantize_mxint_tiles: null pointer");
+    return LQER_E_INVALID;
+  }
+  if (!fmt_ok(fmt, "quantize_mxint_tiles", 24)) return LQER_E_UNSUPPORTED;
+  if (fmt->kind != LQER_Q_MXINT) {
+    set_error("quantize_mxint_tiles: the format is not block_fp");
+    return LQER_E_INVALID;
+  }
+  const int64_t R = (tile_rows <= 0 || tile_rows > rows) ? rows : tile_rows, L = (tile_cols <= 0 || tile_cols > cols) ? cols : tile_cols;
+  return quantize_tiles_dispatch(x, dtype, batches, rows, cols, R, L, make_qp(*fmt), deq_f32, amax_scratch, (hipStream_t)stream);
+}
+
 int lqer_quantize_act_mxint(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const lqer_qfmt_t* fmt,
                             void* xq_bf16, void* stream) {
   if ((!x || !xq_bf16) && M * K > 0) {

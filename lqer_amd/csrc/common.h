@@ -466,6 +466,8 @@ struct GemmArgs {
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
                       const QuantOut& o, hipStream_t st);
+int quantize_tiles_dispatch(const void* x, int dtype, int64_t batches, int64_t rows, int64_t cols, int64_t R, int64_t L, const QP& q,
+                            float* out, float* amax, hipStream_t st);
 int pack_weight_dispatch(const void* W, int dtype, int64_t N, int64_t K, int64_t ld, const QP& q, int64_t block_rows, void* out,
                          void* scratch, hipStream_t st);
 int unpack_weight_dispatch(const void* in, int64_t N, int64_t K, int mbits, bool twos, float* out, hipStream_t st);

@@ -395,4 +395,68 @@ int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int6
   return LQER_E_INVALID;
 }
 
+// ---- 2-D tiles of an activation (blocks that span token rows) --------------------------------------------------------------------
+// Reference quantizers/utils.py:211-237 (`_block_3d_activation`: [batch, tokens, features] with skip_first_dim = true, tiles of
+// R x L over (tokens, features) of every batch element) and :161-183 (`_block_2d_weight`, which utils.py:261-270 also applies to a
+// 2-D activation when skip_first_dim = false).  Zero padding of ragged edges cannot raise a maximum, so the tiles are simply
+// clipped.  A cold path (no template configuration has such blocks): two passes, no staging -
+//   k_tile_amax : one wave per (batch, row, column tile) segment, lanes stride the segment (coalesced), one atomicMax of the
+//                 fp32 bit pattern per wave into amax[batch][row / R][column tile] (max is order-independent: reproducible);
+//   k_tile_quant: one thread per element, the element routine of every other quantizer (block_exponent / mxint_mantissa).
+template <int DT>
+__global__ __launch_bounds__(256) void k_tile_amax(const void* __restrict__ x, int64_t batches, int64_t rows, int64_t cols, int64_t R,
+                                                   int64_t L, int64_t tr, int64_t tc, unsigned int* __restrict__ amax) {
+  const int lane = threadIdx.x & 63;
+  const int64_t segs = batches * rows * tc;
+  for (int64_t sgi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sgi < segs; sgi += (int64_t)gridDim.x * 4) {
+    const int64_t c = sgi % tc, br = sgi / tc, r = br % rows, b = br / rows;
+    const int64_t k0 = c * L, k1 = k0 + L < cols ? k0 + L : cols;
+    float m = 0.0f;
+    for (int64_t k = k0 + lane; k < k1; k += 64) m = fmaxf(m, fabsf(load_elem<DT>(x, (b * rows + r) * cols + k)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0 && m > 0.0f) atomicMax(amax + (b * tr + r / R) * tc + c, __float_as_uint(m));
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_tile_quant(const void* __restrict__ x, int64_t batches, int64_t rows, int64_t cols, int64_t R,
+                                                    int64_t L, int64_t tr, int64_t tc, const float* __restrict__ amax, QP q,
+                                                    float* __restrict__ out) {
+  const int64_t total = batches * rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t k = i % cols, br = i / cols, r = br % rows, b = br / rows;
+    const float a = amax[(b * tr + r / R) * tc + k / L];
+    const float v = load_elem<DT>(x, i);
+    const bool any = a > 0.0f;
+    const int e = any ? block_exponent(a, q) : 0;
+    const float m = any ? mxint_mantissa(v, e, q) : 0.0f;
+    out[i] = fabsf(v) <= 1e-8f ? v : ldexpf(m, e - q.mbits);
+  }
+}
+
+template <int DT>
+static int launch_tiles(const void* x, int64_t batches, int64_t rows, int64_t cols, int64_t R, int64_t L, const QP& q, float* out,
+                        float* amax, hipStream_t st) {
+  const int64_t tr = (rows + R - 1) / R, tc = (cols + L - 1) / L;
+  (void)hipMemsetAsync(amax, 0, (size_t)(batches * tr * tc) * sizeof(float), st);
+  const int64_t segs = batches * rows * tc, total = batches * rows * cols;
+  const unsigned g1 = (unsigned)((segs + 3) / 4 < 65536 ? (segs + 3) / 4 : 65536);
+  const unsigned g2 = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  k_tile_amax<DT><<<g1, 256, 0, st>>>(x, batches, rows, cols, R, L, tr, tc, (unsigned int*)amax);
+  k_tile_quant<DT><<<g2, 256, 0, st>>>(x, batches, rows, cols, R, L, tr, tc, amax, q, out);
+  return LQER_OK;
+}
+
+int quantize_tiles_dispatch(const void* x, int dtype, int64_t batches, int64_t rows, int64_t cols, int64_t R, int64_t L, const QP& q,
+                            float* out, float* amax, hipStream_t st) {
+  switch (dtype) {
+    case LQER_F32: return launch_tiles<LQER_F32>(x, batches, rows, cols, R, L, q, out, amax, st);
+    case LQER_F16: return launch_tiles<LQER_F16>(x, batches, rows, cols, R, L, q, out, amax, st);
+    case LQER_BF16: return launch_tiles<LQER_BF16>(x, batches, rows, cols, R, L, q, out, amax, st);
+  }
+  set_error("unknown dtype %d", dtype);
+  return LQER_E_INVALID;
+}
+
 }  // namespace lqer

@@ -67,6 +67,9 @@ class _LinearBase(nn.Linear):
         self.tuning = 0            # lqer_linear_desc_t.tuning (_lib.TUNE_*): per-call kernel-variant knobs of tests, same bits
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
+        # activation quantizers whose blocks can span token rows ([R, L] tiles, skip_first_dim = false): the tile route below
+        self._tiles = any(getattr(self._fmt.get(r), "act_tiles", None) is not None for r in ("x", "A_out", "B_out"))
+        self.__dict__["_inner"] = None  # (the tile route's main-product Linear: not a registered submodule - it shares this module's parameters)
 
     # -- configuration -------------------------------------------------------------------------
     def _setup_quantizers(self, q_config: dict):
@@ -185,6 +188,9 @@ class _LinearBase(nn.Linear):
         linear.py:149-153 runs it once).  Writes through `weight.data` are invisible to autograd's version counter, so
         after `mod.weight.data.copy_(W2)` call `invalidate_packed(weight_changed=True)`; in-place writes to the parameter
         itself (`mod.weight.copy_(W2)` under no_grad) are noticed by the next forward without any call."""
+        inner = self.__dict__.get("_inner")
+        if inner is not None:  # (the tile route's twin holds the images of this module's weight / bias)
+            inner.invalidate_packed(weight_changed=weight_changed, bias_changed=bias_changed)
         self._packed = None
         self._fw_cache = {}
         self._x_f16 = False
@@ -387,7 +393,53 @@ class _LinearBase(nn.Linear):
         self._bias_q = keep_bias
         return True
 
+    def _forward_tiles(self, x: torch.Tensor) -> torch.Tensor:
+        """The forward when an activation quantizer's blocks can span token rows (reference quantizers/utils.py:211-237 for
+        [batch, tokens, features] tensors, :161-183 for 2-D tensors with skip_first_dim = false) - a COLD route, statement by
+        statement what linear.py:145-157 does, because such blocks cannot live inside the fused kernels (a tile's exponent
+        needs the maximum over R token rows: the quantizers become launches of their own over the whole tensor):
+            x_q   = Q_x(x)                          HIP tile quantizer (ops.quantize_act_tiles -> lqer_quantize_mxint_tiles)
+            main  = x_q W_q^T + b_q                 the fused HIP GEMM of a LinearFlexible twin with a pass-through x_quantizer that
+                                                    shares weight / bias (x_q's values are exact in the module's dtype)
+            side  = Q_Bout(Q_Aout(x_q A) B)         two rank-r library GEMMs (torch.matmul, as the reference) around the HIP quantizers
+        No template configuration of the reference has such blocks."""
+        f = self._fmt
+        if x.dim() < 2 or x.dim() > 3:
+            raise RuntimeError(f"Unsupported x.ndim = {x.dim()}")  # (quantizers/utils.py:284)
+
+        def q(role, t):
+            fm = f.get(role)
+            if fm is None or fm.kind == _lib.Q_PASSTHROUGH:
+                return t
+            if fm.kind == _lib.Q_MXINT:
+                return ops.quantize_act_tiles(t, fm)
+            return ops.quantize_mxint(t, fm, want=("deq",))["deq"].to(t.dtype)  # integer: elementwise
+
+        w, b = self._parameters["weight"], self._parameters["bias"]
+        inner = self.__dict__.get("_inner")
+        if inner is None:
+            # the twin lives as long as this module and quantizes the weight / bias ONCE (linear.py:149-153), by the base class's own
+            # rules: it is handed this module's Parameter objects before every call (.to() across device types replaces them),
+            # notices in-place writes through their version counters, and invalidate_packed() is forwarded to it
+            qc = dict(name="flexible", is_ptq=True, default=self.q_config.get("default"),
+                      x_quantizer=dict(name="passthrough"), w_quantizer=deepcopy(self.q_config.get("w_quantizer", self.q_config.get("default"))))
+            if b is not None:
+                qc["b_quantizer"] = deepcopy(self.q_config.get("b_quantizer", self.q_config.get("default")))
+            inner = self.__dict__["_inner"] = LinearFlexible(self.in_features, self.out_features, bias=b is not None, device="meta", q_config=qc)
+        inner._parameters["weight"], inner._parameters["bias"] = w, b
+        inner.tuning = self.tuning
+        xq = q("x", x)
+        y = inner(xq)
+        self.w_is_quantized = True
+        if self.rank > 0:
+            prm = self._parameters
+            xaq = q("A_out", torch.matmul(xq, prm["A"]))
+            y = y + q("B_out", torch.matmul(xaq, prm["B"]))
+        return y
+
     def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
+        if self._tiles:
+            return self._forward_tiles(x)
         self._written_in_place()
         if self._packed is None or self.w_is_quantized is False:
             self._pack()
@@ -458,7 +510,7 @@ class SharedActivation:
     def __init__(self, members):
         self.members = list(members)
         m0 = self.members[0]
-        ok = all(isinstance(m, LinearFlexibleLqer) and m.rank > 0 and m.in_features == m0.in_features for m in self.members)
+        ok = all(isinstance(m, LinearFlexibleLqer) and m.rank > 0 and m.in_features == m0.in_features and not m._tiles for m in self.members)
         key = lambda f: (f.kind, f.width, f.block, f.exp_width, f.exp_bias)
         ok = ok and all(key(m._fmt["x"]) == key(m0._fmt["x"]) and key(m._fmt["A_out"]) == key(m0._fmt["A_out"]) for m in self.members)
         # A_out blocks must not straddle two members' columns of the concatenated x A: blocks of 16 (the padded ranks are

@@ -83,6 +83,7 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
             bs = bs[-1:]  # right-aligned to a 1-D tensor: only the last entry counts
     else:
         block_rows = 1
+        act_tiles = None
         if role == "w" and not skip:
             # the 2-D weight with skip_first_dim = false (quantizers/utils.py:161-183): [R, L] = tiles of R rows x L k, a lone [L]
             # is right-aligned to [-1, L] = all rows x L (utils.py:42-67).  One exponent per tile, repeated per row in the image.
@@ -91,19 +92,61 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
             block_rows = int(bs[-2]) if len(bs) >= 2 else -1
             if block_rows == 0:
                 raise ValueError(f"block_size {bs}: a block of 0 rows")
+        elif role in ("x", "A_out", "B_out") and (not skip or (len(bs) >= 2 and bs[-2] != 1)):
+            # an activation whose blocks can span token rows (quantizers/utils.py:211-237: [R, L] tiles over (tokens, features) of
+            # every batch element of a 3-D tensor; :261-270: a 2-D tensor with skip_first_dim = false is blocked like a weight, a
+            # lone [L] then means all rows x L).  What the tiles are depends on the tensor's rank at call time (a 2-D tensor with
+            # skip_first_dim = true is blocked per row whatever R says, utils.py:127-144): the module's tile route decides there
+            # (linear.py `_forward_tiles`, ops.quantize_act_tiles) - the fused kernels never see this format.
+            act_tiles = (int(bs[-2]) if len(bs) >= 2 else -1, int(bs[-1]), skip)
         elif any(b != 1 for b in bs[:-1]):
             raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path for '{role}'")
-        elif len(bs) < 2 and not skip:
-            raise NotImplementedError(
-                f"block_size {bs} with skip_first_dim = false is right-aligned to [-1, {bs[-1]}] (2-D tiles over all rows, "
-                "quantizers/utils.py:42-67): only per-row blocks ([1, L], or [L] with skip_first_dim = true) are implemented")
     ew = int(cfg.get("exponent_width", 8))
     eb = cfg.get("exponent_bias", None)
     eb = 2 ** (ew - 1) - 1 if eb in (None, "none", "None", "NA") else int(eb)
     fmt = QFmt(_lib.Q_MXINT, int(cfg.get("width", 12)), int(bs[-1]), ew, eb)
     if role != "b" and block_rows != 1:
         fmt.block_rows = block_rows  # (a Python attribute beside the C fields: only the packing call needs it)
+    if role != "b" and act_tiles is not None:
+        fmt.act_tiles = act_tiles    # (R, L, skip_first_dim) as configured - a Python attribute, see above
     return fmt
+
+
+def act_tile_shape(fmt: QFmt, ndim: int):
+    """(R, L) of an activation format for a tensor of `ndim` dims, as the reference's dispatch reads it (quantizers/utils.py:261-284;
+    R, L <= 0: the whole extent): per-row blocks -> (1, L); `None`-free: raises what the reference raises."""
+    t = getattr(fmt, "act_tiles", None)
+    if t is None:
+        return 1, int(fmt.block)
+    R, L, skip = t
+    if ndim == 2:
+        return (1, L) if skip else (R, L)  # utils.py:127-144 infers the block against ONE row; :161-183 tiles the matrix
+    if ndim == 3:
+        if not skip:
+            raise NotImplementedError("block 3d weight is not supported.")  # (utils.py:279, verbatim)
+        return R, L
+    raise RuntimeError(f"Unsupported x.ndim = {ndim}")  # (utils.py:284)
+
+
+@_on_tensor_device
+def quantize_act_tiles(x: torch.Tensor, fmt: QFmt) -> torch.Tensor:
+    """block_fp quantizer of an ACTIVATION whose format may have blocks spanning token rows (make_qfmt roles x / A_out / B_out with
+    `act_tiles`): x [tokens, features] or [batch, tokens, features] -> the quantized tensor, same shape and dtype (the reference
+    quantizer's contract, block_fp.py:111).  Tiles are anchored per batch element (utils.py:211-237)."""
+    _need_gpu(x)
+    R, L = act_tile_shape(fmt, x.dim())
+    xc = x.contiguous()
+    rows, cols = xc.shape[-2], xc.shape[-1]
+    batches = xc.shape[0] if xc.dim() == 3 else 1
+    Re = rows if R <= 0 or R > rows else R
+    Le = cols if L <= 0 or L > cols else L
+    out = torch.empty(xc.shape, dtype=torch.float32, device=x.device)
+    if xc.numel() == 0:
+        return out.to(x.dtype)
+    amax = torch.empty(batches * (-(-rows // Re)) * (-(-cols // Le)), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lqer_quantize_mxint_tiles(xc.data_ptr(), dtype_code(xc), batches, rows, cols, C.byref(fmt), Re, Le, out.data_ptr(),
+                                               amax.data_ptr(), _stream(x.device)), "lqer_quantize_mxint_tiles")
+    return out.to(x.dtype)
 
 
 @_on_tensor_device

@@ -217,6 +217,15 @@ def main():
         ("w8g128", (9, 256), 256, 96, 32, False, dict(int_q, w_quantizer=bfp_cfg(8, [1, 128], False)), None, True),
         ("w8b16", (7, 176), 176, 160, 32, True, dict(mxint_q, w_quantizer=bfp_cfg(8, [1, 16], False)), abq, False),
         ("w6b32", (2, 5, 192), 192, 64, 16, False, dict(mxint_q, w_quantizer=bfp_cfg(6, [1, 32], False)), abq, True),
+        # activation blocks that span token rows (round 5; quantizers/utils.py:211-237 for 3-D tensors, :161-183 / :261-270 for 2-D
+        # tensors with skip_first_dim = false): A_out / B_out fall back to the x quantizer, so all three are tiled
+        ("acttile3d", (2, 20, 176), 176, 64, 16, True, dict(mxint_q, x_quantizer=bfp_cfg(8, [4, 16], True)), abq, False),
+        ("acttile_ragged", (3, 7, 72), 72, 40, 16, False, dict(mxint_q, x_quantizer=bfp_cfg(8, [3, 32], True)), abq, True),
+        ("acttile2d", (24, 128), 128, 96, 32, False, dict(mxint_q, x_quantizer=bfp_cfg(8, [8, 16], False)), abq, False),
+        ("acttile2d_all", (10, 64), 64, 48, 16, True, dict(mxint_q, x_quantizer=bfp_cfg(8, [32], False)), abq, False),
+        ("acttile_r_on_2d", (9, 64), 64, 48, 16, False, dict(mxint_q, x_quantizer=bfp_cfg(8, [4, 16], True)), abq, False),  # R is read per row
+        ("acttile_whole", (2, 6, 64), 64, 48, 16, False, dict(mxint_q, x_quantizer=bfp_cfg(8, [-1, -1], True)), abq, False),  # one exponent per batch element
+        ("acttile_bout", (2, 6, 64), 64, 48, 16, False, dict(mxint_q, B_out_quantizer=bfp_cfg(8, [2, 16], True)), abq, False),  # only B_out tiled
     ]
     f = {}
     for name, xs, K, N, r, has_b, qc, abc, use_s in cases:

@@ -146,8 +146,9 @@ def test_make_qfmt_schema():
     assert ops.make_qfmt(dict(name="block_fp", width=4, block_size=[1, -1])).block == -1
     assert ops.make_qfmt(dict(name="block_fp", width=4, block_size=128)).block == 128
     assert ops.make_qfmt(dict(name="passthrough", width=16, frac_width=9)).kind == _lib.Q_PASSTHROUGH
-    with pytest.raises(NotImplementedError):
-        ops.make_qfmt(dict(name="block_fp", width=8, block_size=[16, 1]))
+    # (round 5) an activation's blocks may span token rows: the format carries (R, L, skip_first_dim) for the module's tile route
+    assert ops.make_qfmt(dict(name="block_fp", width=8, block_size=[16, 1])).act_tiles == (16, 1, True)
+    assert not hasattr(f, "act_tiles")
     with pytest.raises(NotImplementedError):
         ops.make_qfmt(dict(name="minifloat", width=8))
     # "integer" (quantizers/integer.py:10-43): fixed point for x / b / A_out; frac_width rides in exp_bias, is_signed in exp_width
@@ -171,10 +172,14 @@ def test_make_qfmt_schema():
     ft = ops.make_qfmt(dict(w, block_size=[8, 32]), "w")
     assert ft.block == 32 and ft.block_rows == 8
     assert not hasattr(ops.make_qfmt(dict(w, block_size=[1, 16]), "w"), "block_rows")  # the templates' per-row blocks
-    with pytest.raises(NotImplementedError):
-        ops.make_qfmt(dict(w, width=8), "x")
-    with pytest.raises(NotImplementedError):
-        ops.make_qfmt(dict(w, width=8, block_size=[8, 16]), "x")
+    fx = ops.make_qfmt(dict(w, width=8), "x")  # (round 5: the tile route - a 2-D activation is blocked like a weight, utils.py:261-270)
+    assert fx.act_tiles == (-1, 128, False) and ops.act_tile_shape(fx, 2) == (-1, 128)
+    with pytest.raises(NotImplementedError, match="block 3d weight"):  # (the reference's own refusal, utils.py:279)
+        ops.act_tile_shape(fx, 3)
+    fx = ops.make_qfmt(dict(w, width=8, block_size=[8, 16], skip_first_dim=True), "B_out")
+    assert fx.act_tiles == (8, 16, True) and ops.act_tile_shape(fx, 3) == (8, 16) and ops.act_tile_shape(fx, 2) == (1, 16)
+    with pytest.raises(RuntimeError, match="Unsupported x.ndim"):
+        ops.act_tile_shape(fx, 4)
     assert ops.make_qfmt(dict(w, skip_first_dim=True), "w").block == 128
     assert ops.make_qfmt(dict(w, block_size=[1, 128]), "w").block == 128
     assert ops.make_qfmt(dict(name="block_fp", width=8, block_size=[16], skip_first_dim=False), "b").block == 16
@@ -226,18 +231,22 @@ def test_product_does_not_import_oracle():
                 assert "/root/reference" not in txt
 
 
-def test_activation_tiles_are_refused_at_construction():
-    """Activation quantizers whose blocks span token rows (a first-dim block != 1: quantizers/utils.py:127-144, :211-237 with
-    skip_first_dim = false, or [R, L] tiles) are NOT implemented on the HIP path - no template uses them.  The refusal is explicit
-    and early: the module's constructor raises, nothing is ever approximated per row (INTEGRATION.md "Explicit refusals")."""
+def test_activation_tiles_take_the_tile_route():
+    """Activation quantizers whose blocks span token rows (a first-dim block != 1: quantizers/utils.py:211-237 [R, L] tiles of a
+    3-D tensor; :161-183 / :261-270 a 2-D tensor with skip_first_dim = false) are never approximated per row: round 5 gave them a
+    route of their own (linear.py `_forward_tiles`: HIP tile quantizers around the fused GEMM) - the module says so at construction,
+    the templates' per-row form does not take it, and there is still no CPU path."""
     import lqer_amd
 
     bfp = lambda w, bs, skip: dict(name="block_fp", width=w, exponent_width=8, exponent_bias=None, block_size=bs, skip_first_dim=skip)
     base = dict(name="flexible_lqer", is_ptq=True, default=False, w_quantizer=bfp(4, [1, 16], False), b_quantizer=bfp(8, [-1], False))
     for role, cfg in (("x_quantizer", bfp(8, [4, 16], False)), ("x_quantizer", bfp(8, [16], False)), ("A_out_quantizer", bfp(8, [2, 16], False)),
-                      ("B_out_quantizer", bfp(8, [8, 1], False))):
+                      ("B_out_quantizer", bfp(8, [8, 1], True))):
         qc = dict(base, x_quantizer=bfp(8, [1, 16], True))
         qc[role] = cfg
-        with pytest.raises(NotImplementedError):
-            lqer_amd.LinearFlexibleLqer(64, 64, bias=False, q_config=qc, l_config={"rank": 16})
-    lqer_amd.LinearFlexibleLqer(64, 64, bias=False, q_config=dict(base, x_quantizer=bfp(8, [1, 16], True)), l_config={"rank": 16})  # the templates' form
+        mod = lqer_amd.LinearFlexibleLqer(64, 64, bias=False, q_config=qc, l_config={"rank": 16})
+        assert mod._tiles, role
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            mod(torch.zeros(2, 3, 64))
+    mod = lqer_amd.LinearFlexibleLqer(64, 64, bias=False, q_config=dict(base, x_quantizer=bfp(8, [1, 16], True)), l_config={"rank": 16})  # the templates' form
+    assert not mod._tiles

@@ -192,6 +192,70 @@ def test_forward_vs_reference_vectors(ops, golden_fwd, name):
         assert torch.equal(mod.bias.detach().cpu(), t("bq"))
 
 
+ACT_TILE_CASES = ["acttile3d", "acttile_ragged", "acttile2d", "acttile2d_all", "acttile_r_on_2d", "acttile_whole", "acttile_bout"]
+
+
+@pytest.mark.parametrize("name", ACT_TILE_CASES)
+def test_forward_activation_tiles_vs_reference_vectors(ops, golden_fwd, name):
+    """Activation quantizers whose blocks span token rows (round 5; reference quantizers/utils.py:211-237 for 3-D tensors,
+    :161-183 / :261-270 for 2-D tensors with skip_first_dim = false): the HIP tile quantizer is bit-exact on x and on the
+    reference's own intermediates, the module's tile route matches the reference's y, quantizes weight / bias once, and its
+    results do not depend on the call count, the dtype's route (fp16 within the fp16 bar) or a copy of the module."""
+    import copy
+
+    g, cfgs = golden_fwd
+    mod, t = _module_from_case(g, cfgs, name)
+    assert mod._tiles
+    x = t("x").to(DEV)
+    assert torch.equal(ops.quantize_act_tiles(x, mod._fmt["x"]).cpu(), t("xq"))
+    assert torch.equal(ops.quantize_act_tiles(t("xA").to(DEV), mod._fmt["A_out"]).cpu(), t("xAq"))
+    assert torch.equal(ops.quantize_act_tiles(t("xAB").to(DEV), mod._fmt["B_out"]).cpu(), t("xABq"))
+    y = mod(x).cpu()
+    ref = t("y")
+    assert y.shape == ref.shape and y.dtype == torch.float32
+    err = (y - ref).norm() / ref.norm()
+    assert err <= 1e-5, float(err)
+    assert torch.equal(mod.weight.detach().cpu(), t("wq"))  # quantized once, in place (linear.py:149-153)
+    if mod.bias is not None:
+        assert torch.equal(mod.bias.detach().cpu(), t("bq"))
+    assert torch.equal(mod(x).cpu(), y)                      # ... and not a second time
+    assert torch.equal(copy.deepcopy(mod)(x).cpu(), y)
+    assert list(mod.state_dict()) == (["weight", "bias", "A", "B"] if mod.bias is not None else ["weight", "A", "B"])  # (the twin is no submodule)
+    # fp16 module and tokens: against the oracle on the same fp16-rounded tokens (the weight / bias already hold their quantized
+    # values, A and B are 8-bit MXINT: all exact in fp16), at the fp16-output bar
+    from oracle import lqer_oracle as O
+
+    mh = mod.half()
+    xh = x.half()
+    yh = mh(xh).float().cpu()
+    bq = t("bq") if mod.bias is not None else None
+    refh = O.lqer_linear_forward(xh.float().cpu(), t("wq"), bq, t("A"), t("B"), cfgs[name], weight_is_quantized=True)
+    assert (yh - refh).norm() / refh.norm() <= 1e-3
+    # new values in place: the twin's images follow
+    with torch.no_grad():
+        mod.weight.copy_(t("W").to(DEV).to(mod.weight.dtype) * 0.5)
+    y2 = mod(x.half()).float().cpu()
+    assert not torch.equal(y2, yh)
+
+
+def test_activation_tiles_refusals_mirror_the_reference(ops):
+    import lqer_amd
+
+    bfp = lambda w, bs, skip: dict(name="block_fp", width=w, exponent_width=8, exponent_bias=None, block_size=bs, skip_first_dim=skip)
+    qc = dict(name="flexible_lqer", is_ptq=True, default=False, x_quantizer=bfp(8, [4, 16], False), w_quantizer=bfp(4, [1, 16], False))
+    mod = lqer_amd.LinearFlexibleLqer(64, 32, bias=False, q_config=qc, l_config={"rank": 16}).to(DEV)
+    assert mod(torch.randn(8, 64, device=DEV)).shape == (8, 32)
+    with pytest.raises(NotImplementedError, match="block 3d weight"):   # utils.py:279
+        mod(torch.randn(2, 8, 64, device=DEV))
+    with pytest.raises(RuntimeError, match="Unsupported x.ndim"):        # utils.py:284
+        mod(torch.randn(2, 2, 8, 64, device=DEV))
+    # the standalone op on empty / tiny inputs
+    f = mod._fmt["x"]
+    assert ops.quantize_act_tiles(torch.zeros(0, 64, device=DEV), f).shape == (0, 64)
+    z = ops.quantize_act_tiles(torch.zeros(5, 64, device=DEV), f)
+    assert torch.equal(z, torch.zeros_like(z))
+
+
 def test_forward_stages_vs_reference_vectors(ops, golden_fwd):
     """xq and xAq (the two quantized intermediates that are materialised) against the vectors."""
     import ctypes as C
