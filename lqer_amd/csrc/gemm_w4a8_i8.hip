@@ -219,8 +219,16 @@ __global__ __launch_bounds__(256) void k_i8_unpack(const uint8_t* __restrict__ i
 
 // ---- 8-bit weights (W8): the int8 image holds the CODES ------------------------------------------------------------------------
 // Source: the three 4-bit limb images of lqer_pack_weight_mxint (pack.hip: m = 64 a + 8 b + c, limb l at panel column l Kp/64 + pk,
-// limb 2's exponent byte = e - mbits + 127).  Image: per (n tile of 256 rows, half-step of 64 k) 256 rows x 64 B of int8 codes - a
-// row's four 16-byte chunks (16 k each, natural order) XOR-ed with (row >> 2) & 3 - then the row scales 2^(e[n] - mbits) fp32 [Np].
+// limb 2's exponent byte = e - mbits + 127).  Image: FRAGMENT-MAJOR - per (n tile of 256 rows, step of 128 k) 32 KiB laid out as
+// [wave = row / 32][32-k slice 0..3][lane = row % 32 + 32 (k % 32 / 16)][16 codes]: the 1 KiB a wave's MFMA B-operand of one slice is,
+// in lane order, so that one 16-byte load per lane fetches it fully coalesced (NT = 4: straight into registers) and an LDS copy of
+// it is read back linearly (NT = 8); then the row scales 2^(e[n] - mbits) fp32 [Np].
+__host__ __device__ inline size_t w8_image_offset(int64_t n, int64_t k, int nk8) {
+  const int64_t tn = n >> 8;
+  const int rl = (int)(n & 255), kk = (int)(k & 127);
+  return ((size_t)tn * nk8 + (size_t)(k >> 7)) * 32768 + (size_t)(rl >> 5) * 4096 + (size_t)(kk >> 5) * 1024 +
+         (size_t)((rl & 31) + 32 * ((kk & 31) >> 4)) * 16 + (size_t)(kk & 15);
+}
 __device__ __forceinline__ int w8_code(const uint8_t* wp, int64_t n, int nk, int k) {  // k < 64 nk
   const int kp = k >> 6, kk = k & 63, seg = kk >> 4, i = kk & 15, j = i & 7, pos = j < 4 ? 2 * j : 2 * (j - 4) + 1;
   int m = 0;
@@ -285,7 +293,8 @@ __global__ __launch_bounds__(256) void k_i8_codes8(const uint8_t* __restrict__ w
       out[i >> 2] |= b << (8 * (i & 3));
     }
   }
-  *(u32x4*)(img + ((size_t)tn * nh + h) * (256 * 64) + rl * 64 + ((c ^ ((rl >> 2) & 3)) << 4)) = out;
+  (void)tn, (void)rl;
+  *(u32x4*)(img + w8_image_offset(n, (int64_t)h * 64 + c * 16, nk8)) = out;
 }
 
 // test hook: the image back to dequantized fp32 [N,K]
@@ -296,9 +305,7 @@ __global__ __launch_bounds__(256) void k_i8_unpack8(const uint8_t* __restrict__ 
   const int64_t n = idx / K, k = idx - n * K;
   const int nh = 2 * nk8;
   const float* wscale = (const float*)(img + (size_t)(Np / 256) * nh * (256 * 64));
-  const int64_t tn = n / 256;
-  const int rl = (int)(n - tn * 256), h = (int)(k >> 6), c = (int)((k & 63) >> 4), i = (int)(k & 15);
-  const int8_t code = (int8_t)img[((size_t)tn * nh + h) * (256 * 64) + rl * 64 + ((c ^ ((rl >> 2) & 3)) << 4) + i];
+  const int8_t code = (int8_t)img[w8_image_offset(n, k, nk8)];
   out[idx] = (float)code * wscale[n];
 }
 
@@ -308,14 +315,18 @@ __global__ __launch_bounds__(256) void k_i8_unpack8(const uint8_t* __restrict__ 
 // cw << (4 - q) carries them: 11 vector instructions per 8 weights - 7 when no row of the tile spreads over more than two
 // binades, PRESHIFT1 -, no folds), FOLD (one v_lshl_add_u32 per output element and group), or NONE.  The main loops live in one
 // kernel; the choice is uniform per tile.
-// W8 (NT = 8, no SHIFT): 8-bit weights (the reference's W8A8 baseline, sweep_baseline_no_lqer.sh:73-76) - the image holds the
-// int8 codes themselves, one exponent per row: the weight fragment of a slice is ONE 16-byte LDS read, no expand at all.  A
-// 128-k step of codes is 32 KiB per tile - twice the nibbles - so the weight ring runs at HALF-step granularity: three slots of
-// 256 rows x 64 k (16 KiB, in the 48 KiB the nibble ring occupies), the half-step h = 2 kt + P in slot h % 3, requested two
-// half-steps ahead; the activation ring stays as it is (three 128-k slots, two steps ahead).
+// W8 (no SHIFT): 8-bit weights (the reference's W8A8 baseline, sweep_baseline_no_lqer.sh:73-76) - the image holds the int8 codes
+// themselves, fragment-major, one exponent per row: no expand at all.  A 128-k step of codes is 32 KiB per tile - twice the nibbles.
+//   NT = 8: the weight ring runs at HALF-step granularity - three slots of 256 rows x 64 k (16 KiB, in the 48 KiB the nibble ring
+//           occupies), the half-step h = 2 kt + P in slot h % 3, requested two half-steps ahead; the weight fragment of a slice
+//           is one 16-byte LDS read; the activation ring stays as it is (three 128-k slots, two steps ahead).
+//   NT = 4: a wave's weight rows are nobody else's - its codes skip LDS: four coalesced 16-byte loads per lane and step into one of
+//           four register sets, three steps ahead beside the activation ring (step4_w8).  35.8 us per round of 4096-k tiles on
+//           all 256 CUs where 256-row tiles fill half of them in 63 us (M = 2048, 4096 x 4096); 1,500 cycles per step.
 template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT, bool W8 = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
-  static_assert(!W8 || (NT == 8 && !SHIFT), "8-bit weight codes: 256-row tiles, one exponent per weight row");
+  static_assert(!W8 || !SHIFT, "8-bit weight codes: one exponent per weight row");
+  constexpr bool W8D = W8 && NT == 4;  // ... on 128-row tiles: the codes go straight from global memory into registers (step4_w8)
   constexpr int W8_SLOT = 256 * 64;  // one half-step of int8 codes
   using G = Geo<NT>;
   constexpr int BM = G::BM, DEPTH = G::DEPTH, NSLOT = G::NSLOT, A_SLOT = G::A_SLOT, NPA = G::NPA, OFF_A = G::OFF_A, OFF_W = G::OFF_W;
@@ -369,7 +380,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   }
   // weights: the block's 16 KiB of nibbles are 16 contiguous 1-KiB pieces: wave w stages pieces 2w and 2w+1; wave 0 also the
   // 256 shift bytes (4 B per lane)
-  const int w_voff0 = (2 * wave) * 1024 + lane * 16, w_voff1 = w_voff0 + 1024, s_voff = 256 * 64 + lane * 4;
+  // (W8: the wave's own 4 KiB of the step's fragment-major block - slices 2 P and 2 P + 1 of half-step P are its pieces 2 P, 2 P + 1)
+  const int w_voff0 = (W8 ? wave * 4096 : (2 * wave) * 1024) + lane * 16, w_voff1 = w_voff0 + 1024, s_voff = 256 * 64 + lane * 4;
   const uint8_t* const a_base = xq8 + (int64_t)m0 * Kp8;
   const uint8_t* const w_base = g.w8 + (size_t)tn * nk * (W8 ? 2 * W8_SLOT : I8_WBLOCK);
   int tile_mode = I8_MODE_NONE;  // (workgroup-uniform)
@@ -397,9 +409,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const uint32_t fw_a = lds0 + OFF_W + rw * 64 + (((2 * lh) ^ ((rw >> 2) & 3)) << 4);      // slices 0, 1
   const uint32_t fw_b = lds0 + OFF_W + rw * 64 + (((2 * lh + 1) ^ ((rw >> 2) & 3)) << 4);  // slices 2, 3
   const uint32_t fs_addr = lds0 + OFF_W + 256 * 64 + rw;
-  // W8: the row's 64 bytes of a half-step = 4 chunks of 16 k; slice s of the half, lane half lh -> chunk 2 s + lh (XOR-ed as above)
-  const uint32_t fw8_0 = lds0 + OFF_W + rw * 64 + ((lh ^ ((rw >> 2) & 3)) << 4);
-  const uint32_t fw8_1 = lds0 + OFF_W + rw * 64 + (((2 + lh) ^ ((rw >> 2) & 3)) << 4);
+  // (fragment-major image: the wave reads back, lane by lane, the two 1-KiB pieces it copied itself)
+  const uint32_t fw8_0 = lds0 + OFF_W + (2 * wave) * 1024 + lane * 16;
+  const uint32_t fw8_1 = fw8_0 + 1024;
 
   // one LDS-DMA batch = the operands of one step: NPA + 2 loads per wave (wave 0: one more)
   auto issue_step = [&](const uint8_t* ab, const uint8_t* wb, int kt, int slot) {
@@ -427,9 +439,25 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   };
   auto issue_w8 = [&](const uint8_t* wb, int h, int ws) {  // half-step h of the tile's codes -> weight slot ws
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, nk * 2 * W8_SLOT, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + ws * W8_SLOT + (2 * wave) * 1024), 16, w_voff0, h * W8_SLOT, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + ws * W8_SLOT + (2 * wave + 1) * 1024), 16, w_voff1, h * W8_SLOT, 0,
-                                             0);
+    const int soff = (h >> 1) * (2 * W8_SLOT) + (h & 1) * 2048;  // step h / 2, the wave's pieces 2 (h % 2) and 2 (h % 2) + 1
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + ws * W8_SLOT + (2 * wave) * 1024), 16, w_voff0, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + ws * W8_SLOT + (2 * wave + 1) * 1024), 16, w_voff1, soff, 0, 0);
+  };
+  // W8 on 128-row tiles (W8D): a wave's weight rows are nobody else's, so its codes skip LDS - four 16-byte loads per lane and step
+  // from the fragment-major image (1 KiB per instruction, fully coalesced) into one of four register sets, three steps ahead.  These
+  // loads and the activation LDS-DMA of the same loop are BUILTINS, not asm: hipcc's waitcnt pass then counts every request and its
+  // own wait in front of the MFMAs that read a set is exact (loads return in issue order; the manual vmcnt at the end of LOAD, for
+  // the activations everybody reads, has retired the set by then anyway).
+  i32x4 wq[W8D ? 4 : 1][4];
+  const int wq_voff = wave * 4096 + lane * 16;
+  auto issue_wq = [&](const uint8_t* wb, int kt, auto set_c) {
+    if constexpr (W8D) {
+      constexpr int S = decltype(set_c)::value;
+      const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, nk * 2 * W8_SLOT, 0x00020000);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+        wq[S][sl] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wq_voff + sl * 1024, kt * (2 * W8_SLOT), 0));
+    }
   };
   // per-row constants of the epilogue: requested ahead, written to LDS (asm: invisible to hipcc's waitcnt pass, which would
   // drain the ring fill in front of a visible LDS store) once the ring fill has been issued
@@ -476,7 +504,23 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // the tile's first two steps (past the end of K: dropped by the buffer range check).  A later tile's step 0 is already in
   // slot 0 when the epilogue before it kept out of that slot (one panel of xAq); its row constants were requested there too
   if (first) load_tables(m0);
-  if constexpr (W8) {
+  if constexpr (W8D) {
+    // request order per step [A x 2, W x 4] (a compiler barrier between the two keeps it): the vmcnt(12) below retires step 0 whole,
+    // the vmcnt(16) at the end of every LOAD the activations of the step after it
+    using std::integral_constant;
+    if (first || !one_panel) issue_a8(a_base, 0, 0);
+    asm volatile("" ::: "memory");
+    issue_wq(w_base, 0, integral_constant<int, 0>{});
+    asm volatile("" ::: "memory");
+    issue_a8(a_base, 1, 1);
+    asm volatile("" ::: "memory");
+    issue_wq(w_base, 1, integral_constant<int, 1>{});
+    asm volatile("" ::: "memory");
+    issue_a8(a_base, 2, 2);
+    asm volatile("" ::: "memory");
+    issue_wq(w_base, 2, integral_constant<int, 2>{});
+    asm volatile("" ::: "memory");
+  } else if constexpr (W8) {
     // request order [A(0) x 4, W(0) x 2, W(1) x 2, A(1) x 4]: the vmcnt(6) below leaves W(1) and A(1) in flight; the first LOAD's
     // vmcnt(6) - its own four requests and two more - then retires W(1), which the second LOAD reads
     if (first || !one_panel) {
@@ -509,6 +553,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // whole batch of step kt+3 (4 loads, wave 0: 5), ends with vmcnt(8): the batches of kt+2 and kt+3 may stay in flight.
   const bool late = wave >= 4;
   if constexpr (NT == 8) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // step 0 landed, the tables written
+  else if constexpr (W8D) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
@@ -889,6 +934,51 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // ---- W8 on 128-row tiles: one phase per 128-k step.  LOAD: the requests of step kt + 3 first (two activation pieces by LDS-DMA,
+  // then the wave's four 1-KiB code fragments into register set (kt + 3) % 4), then the 16 activation fragment reads of step kt and
+  // vmcnt(16): of the three batches in flight only the activations of step kt + 1 - the oldest two requests - must have landed
+  // before the barrier lets anyone read them; COMPUTE: 16 MFMAs on register set kt % 4, no expand.
+  auto step4_w8 = [&](int kt, auto slot_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int slot_new = (SLOT + DEPTH) % NSLOT;
+    constexpr int A_IMM = SLOT * A_SLOT;
+    __builtin_amdgcn_s_setprio(1);
+    const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
+    issue_a8(a_base, ktn, slot_new);
+    asm volatile("" ::: "memory");
+    issue_wq(w_base, ktn, std::integral_constant<int, slot_new>{});
+    i32x4 xa[4][4];  // [token tile][slice]
+    asm volatile(
+        "ds_read_b128 %[x00], %[fa0] offset:%c[aimm]\n\tds_read_b128 %[x01], %[fa1] offset:%c[aimm]\n\t"
+        "ds_read_b128 %[x02], %[fa2] offset:%c[aimm]\n\tds_read_b128 %[x03], %[fa3] offset:%c[aimm]\n\t"
+        "ds_read_b128 %[x10], %[fa0] offset:%c[aimm]+4096\n\tds_read_b128 %[x11], %[fa1] offset:%c[aimm]+4096\n\t"
+        "ds_read_b128 %[x12], %[fa2] offset:%c[aimm]+4096\n\tds_read_b128 %[x13], %[fa3] offset:%c[aimm]+4096\n\t"
+        "ds_read_b128 %[x20], %[fa0] offset:%c[aimm]+8192\n\tds_read_b128 %[x21], %[fa1] offset:%c[aimm]+8192\n\t"
+        "ds_read_b128 %[x22], %[fa2] offset:%c[aimm]+8192\n\tds_read_b128 %[x23], %[fa3] offset:%c[aimm]+8192\n\t"
+        "ds_read_b128 %[x30], %[fa0] offset:%c[aimm]+12288\n\tds_read_b128 %[x31], %[fa1] offset:%c[aimm]+12288\n\t"
+        "ds_read_b128 %[x32], %[fa2] offset:%c[aimm]+12288\n\tds_read_b128 %[x33], %[fa3] offset:%c[aimm]+12288\n\t"
+        "s_waitcnt vmcnt(16) lgkmcnt(0)"
+        : [x00] "=&v"(xa[0][0]), [x01] "=&v"(xa[0][1]), [x02] "=&v"(xa[0][2]), [x03] "=&v"(xa[0][3]), [x10] "=&v"(xa[1][0]),
+          [x11] "=&v"(xa[1][1]), [x12] "=&v"(xa[1][2]), [x13] "=&v"(xa[1][3]), [x20] "=&v"(xa[2][0]), [x21] "=&v"(xa[2][1]),
+          [x22] "=&v"(xa[2][2]), [x23] "=&v"(xa[2][3]), [x30] "=&v"(xa[3][0]), [x31] "=&v"(xa[3][1]), [x32] "=&v"(xa[3][2]),
+          [x33] "=&v"(xa[3][3])
+        : [fa0] "v"(fa_lo[0]), [fa1] "v"(fa_lo[1]), [fa2] "v"(fa_lo[2]), [fa3] "v"(fa_lo[3]), [aimm] "i"(A_IMM)
+        : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- COMPUTE
+    if constexpr (W8D) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) R[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[t][ks], wq[SLOT][ks], R[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // ---- W8: half-step h = 2 kt + P - the 32-k slices 2 P and 2 P + 1 of all 8 token tiles against this wave's two 16-byte weight
   // fragments from weight slot h % 3.  LOAD: the 16 activation fragment reads, then the requests (the codes of half-step h + 2
   // FIRST, then this half's share of the activations of step kt + 2), and only THEN the wait for this half-step's own codes: a wave
@@ -906,7 +996,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     constexpr int A_IMM = (SLOT == 2 ? 0 : SLOT * A_SLOT);  // tile t: + 4096 t
     __builtin_amdgcn_s_setprio(1);
     const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
-    const int a_soff = ktn * I8_BK, w_soff = (2 * (kt + 1) + P) * W8_SLOT;
+    const int a_soff = ktn * I8_BK, w_soff = (kt + 1) * (2 * W8_SLOT) + P * 2048;
     const uint32_t m0a0 = m0_a + slot_new * A_SLOT + (2 * P) * 1024, m0a1 = m0a0 + 1024;
     const uint32_t m0w0 = m0_w + WS_NEW * W8_SLOT, m0w1 = m0w0 + 1024;
     i32x4 xk[8][2];  // [token tile][slice of this half]
@@ -953,7 +1043,20 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #define LQER_I8_KSPLIT 1  // 0: the token-tile split for every mode (A/B builds)
 #endif
   auto main_loop = [&](auto mode_c) {
-    if constexpr (W8) {
+    if constexpr (W8D) {
+      // unrolled by the ring size (activation slot and register set are compile-time constants) with NO exit inside the four steps:
+      // K is walked in multiples of 512 - a step past its end multiplies whatever the activation slot holds (int8 of an earlier
+      // step) with the zeros the range-checked weight loads return: exactly nothing (at most 3 steps per tile; none at K = 4096).
+      // Why: hipcc structurizes `if (kt + i < nk)` / `break` into flags tested at the loop latch, its waitcnt pass then sees a
+      // path from step 1 straight back to step 0 and waits for all but 6-9 requests in front of step 0's MFMAs - the prefetch
+      // distance would collapse to one step every fourth step.
+      for (int kt = 0; kt < nk; kt += NSLOT) {
+        step4_w8(kt, integral_constant<int, 0>{});
+        step4_w8(kt + 1, integral_constant<int, 1>{});
+        step4_w8(kt + 2, integral_constant<int, 2>{});
+        step4_w8(kt + 3, integral_constant<int, 3 % NSLOT>{});
+      }
+    } else if constexpr (W8) {
       for (int kt = 0; kt < nk; kt += NSLOT) {  // (three steps = six half-steps: activation slot kt % 3, weight slot h % 3)
         half_step_w8(kt, integral_constant<int, 0>{}, integral_constant<int, 0>{});
         half_step_w8(kt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
@@ -1026,7 +1129,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     if constexpr (W8) {
       if (one_panel) {
         issue_a8(xq8 + (int64_t)m0_next * Kp8, 0, 0);
-        issue_w8(g.w8 + (size_t)tn_next * nk * 2 * W8_SLOT, 0, 0);
+        if constexpr (!W8D) issue_w8(g.w8 + (size_t)tn_next * nk * 2 * W8_SLOT, 0, 0);  // (W8D: registers - requested at the tile's head)
       }
     } else {
       if (one_panel) issue_step(xq8 + (int64_t)m0_next * Kp8, g.w8 + (size_t)tn_next * nk * I8_WBLOCK, 0, 0);
@@ -1326,10 +1429,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 template <int DT, int NT>
 static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st);
 
-// 8-bit weight codes: 256-row tiles, half-step weight ring
-template <int DT>
+// 8-bit weight codes: 128-row tiles with the codes straight into registers, or 256-row tiles with a half-step weight ring in LDS
+template <int DT, int NT>
 static int launch_w8(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
-  constexpr int BM = Geo<8>::BM, KERNEL_LDS = Geo<8>::KERNEL_LDS;
+  constexpr int BM = Geo<NT>::BM, KERNEL_LDS = Geo<NT>::KERNEL_LDS;
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = g.Np / BN;
   constexpr int CUS = 256;
@@ -1338,8 +1441,8 @@ static int launch_w8(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
 #define LQER_I8_LAUNCH8(LR, BO)                                                                   \
   do {                                                                                            \
     static LdsLimitOnce lds_once;                                                                 \
-    lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false, 8, true>, KERNEL_LDS);              \
-    k_lqer_gemm_i8<DT, LR, BO, false, 8, true><<<grid, 512, KERNEL_LDS, st>>>(g);                   \
+    lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false, NT, true>, KERNEL_LDS);             \
+    k_lqer_gemm_i8<DT, LR, BO, false, NT, true><<<grid, 512, KERNEL_LDS, st>>>(g);                  \
   } while (0)
   if (!lowrank)
     LQER_I8_LAUNCH8(false, 0);
@@ -1395,9 +1498,11 @@ extern "C" int lqer_debug_set_i8_stamp_buffer(void* p) {
 // expand per MFMA doubles).  Llama-7B projections at M = 2048: 4096 x 4096 fills 128 CUs with 256-row tiles and all 256 with
 // 128-row ones; N = 11008: 2 rounds of 256 rows against 3 x 0.56.  LQER_TUNE_I8_ROWS_* pins the choice (tests: same bits).
 int i8_tile_rows(const GemmArgs& g) {
-  if (g.w_i8codes) return 256;  // (8-bit weight codes: the half-step weight ring is built for 256-row tiles)
   if (g.tuning & LQER_TUNE_I8_ROWS_128) return 128;
   if (g.tuning & LQER_TUNE_I8_ROWS_256) return 256;
+  // (8-bit weight codes: the same rule - the 128-row kernel, codes straight into registers, takes 35.8 us per round of 4096-k tiles
+  // against 63.5 us of the 256-row kernel's half-step LDS ring: 0.56 again.  M = 2048 x 4096 x 4096: 128 rows, all 256 CUs,
+  // 35.8 us against 63 us on half of them; M = 8192: 256 rows, 127 us against 137 us)
   constexpr int64_t CUS = 256;
   const int64_t tn = g.Np / i8::BN;
   const int64_t r256 = (((g.M + 255) / 256) * tn + CUS - 1) / CUS, r128 = (((g.M + 127) / 128) * tn + CUS - 1) / CUS;
@@ -1417,10 +1522,11 @@ bool i8_eligible(const GemmArgs& g, int bout) {
 
 int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st) {
   if (g.w_i8codes) {
+    const bool w128 = i8_tile_rows(g) == 128;
     switch (dtype) {
-      case LQER_F32: return i8::launch_w8<LQER_F32>(g, lowrank, bout, st);
-      case LQER_F16: return i8::launch_w8<LQER_F16>(g, lowrank, bout, st);
-      case LQER_BF16: return i8::launch_w8<LQER_BF16>(g, lowrank, bout, st);
+      case LQER_F32: return w128 ? i8::launch_w8<LQER_F32, 4>(g, lowrank, bout, st) : i8::launch_w8<LQER_F32, 8>(g, lowrank, bout, st);
+      case LQER_F16: return w128 ? i8::launch_w8<LQER_F16, 4>(g, lowrank, bout, st) : i8::launch_w8<LQER_F16, 8>(g, lowrank, bout, st);
+      case LQER_BF16: return w128 ? i8::launch_w8<LQER_BF16, 4>(g, lowrank, bout, st) : i8::launch_w8<LQER_BF16, 8>(g, lowrank, bout, st);
     }
     set_error("unknown dtype %d", dtype);
     return LQER_E_INVALID;

@@ -399,8 +399,9 @@ def _w8a8(wblock=-1, lqer=True):
                                           (4096, 1000, 4352, 16, False),  # K = 1000: 16 half-steps of which the last is partly padding
                                           (600, 384, 8192, 64, False)])   # three tiles of 256 rows, the last with 88 rows
 def test_w8a8_int8_route_vs_oracle_and_limb_route(lq, dtype, tol, M, K, N, r, bias):
-    """Weights of 8 bits with one block per row on the int8 MFMA kernel (round 5: the image holds the codes themselves - LDS-DMA,
-    one 16-byte LDS read per fragment, MFMA; sweep_baseline_no_lqer.sh:73-76 is this format): against the CPU oracle, and against the
+    """Weights of 8 bits with one block per row on the int8 MFMA kernel (round 5: the image holds the codes themselves, fragment-major -
+    128-row tiles load them straight into registers, 256-row tiles through a half-step LDS ring; no expand either way;
+    sweep_baseline_no_lqer.sh:73-76 is this format): against the CPU oracle, and against the
     SAME module on the three-limb route (bf16 kernels, exact too): the integer sums are the same numbers - 16-bit outputs agree
     except for rare roundings of differently ordered fp32 side sums; run-to-run bit stable; the image gives the weight back."""
     from bench import make_case
@@ -423,9 +424,15 @@ def test_w8a8_int8_route_vs_oracle_and_limb_route(lq, dtype, tol, M, K, N, r, bi
     assert mod._x_i8, "an 8-bit weight with one block per row is eligible for the int8 route"
     L = _lib.lib()
     dtc = _lib.F32 if dtype == torch.float32 else _lib.F16
-    assert L.lqer_gemm_route(C.byref(mod._desc()), M, dtc) == _lib.ROUTE_I8 and L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, dtc) == 256
+    assert L.lqer_gemm_route(C.byref(mod._desc()), M, dtc) == _lib.ROUTE_I8
     for _ in range(5):
         assert torch.equal(mod(xin), y)
+    # the 128-row kernel (codes straight into registers) and the 256-row kernel (half-step LDS ring), pinned: the bits of the default
+    for rows, bit in ((128, _lib.TUNE_I8_ROWS_128), (256, _lib.TUNE_I8_ROWS_256)):
+        mod.tuning = bit
+        assert L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, dtc) == rows
+        assert torch.equal(mod(xin), y), rows
+    mod.tuning = 0
     wq = ops.quantize_mxint(W.to(dtype).to(DEV), mod._fmt["w"], want=("deq",))["deq"].cpu()
     wq = torch.where(W.to(dtype).float().abs() <= 1e-8, torch.zeros_like(wq), wq)  # (packed images flush the pass-through range)
     assert torch.equal(ops.unpack_weight_i8(mod._packed["w"], N, K, mod._fmt["w"]).cpu(), wq)
