@@ -261,6 +261,9 @@ class _LinearBase(nn.Linear):
     def packed_state(self) -> dict:
         """The packed operands as flat tensors: 4-bit weight panels with their block exponents, the used bf16 limbs
         of A^T and B^T, the quantized bias, and an int32 header (version, K, N, rank, limb counts, formats)."""
+        if self._tiles:
+            raise NotImplementedError("packed checkpoints hold the fused path's images: a module whose activation blocks span token rows "
+                                      "(the tile route) keeps its dense state_dict")
         self.pack()
         p = self._packed
         al, bl = int(p.get("a_limbs_orig", p.get("a_limbs", 0))), int(p.get("b_limbs", 0))
@@ -281,6 +284,8 @@ class _LinearBase(nn.Linear):
     def load_packed_state(self, state: dict, device: torch.device) -> None:
         """Attach images written by packed_state(); the dense weight / A / B parameters are not consulted afterwards
         (they may be left uninitialised).  Raises if the file does not match this module's shape or quantizers."""
+        if self._tiles:
+            raise NotImplementedError("packed checkpoints hold the fused path's images: not for a module on the tile route")
         hdr = [int(v) for v in state["header"].tolist()]
         want = [self.PACKED_FORMAT_VERSION, self.in_features, self.out_features, self.rank]
         if hdr[:4] != want:

@@ -248,5 +248,7 @@ def test_activation_tiles_take_the_tile_route():
         assert mod._tiles, role
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             mod(torch.zeros(2, 3, 64))
+        with pytest.raises(NotImplementedError, match="tile route"):  # packed checkpoints are images of the fused path
+            mod.packed_state()
     mod = lqer_amd.LinearFlexibleLqer(64, 64, bias=False, q_config=dict(base, x_quantizer=bfp(8, [1, 16], True)), l_config={"rank": 16})  # the templates' form
     assert not mod._tiles
