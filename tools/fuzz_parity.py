@@ -17,7 +17,10 @@ from oracle import lqer_oracle as O
 
 
 def one_case(rng):
-    kind = rng.choice(["small", "small", "tile", "tile", "tile", "m256", "i8", "i8", "w8"])
+    kind = rng.choice(["small", "small", "tile", "tile", "tile", "m256", "i8", "i8", "w8", "acttile"])
+    if kind == "acttile":  # activation blocks that span token rows (the module's tile route): M is batch x tokens of a 3-D tensor
+        return (rng.choice([6, 20, 35, 64]), rng.choice([64, 100, 176, 320]), rng.choice([16, 40, 160, 300]), rng.choice([0, 8, 16, 32]),
+                rng.choice(["at4x16", "at3x32", "atallx16", "at2d8x16", "atbout"]), rng.choice([torch.float16, torch.bfloat16, torch.float32]))
     if kind == "i8":  # the int8 tile kernel: M >= 128, per-token x, weight blocks of 128 (or whole rows) whose exponents spread
         return (rng.choice([128, 130, 200, 256, 384, 512, 768, 1024, 1300]), rng.choice([128, 256, 384, 640, 1024]), rng.choice([256, 300, 512, 1024, 1296]),
                 rng.choice([0, 16, 32, 64]), rng.choice(["i8spread0", "i8spread2", "i8spread4", "i8spread7", "i8row", "w8row", "w8row"]),
@@ -53,6 +56,11 @@ def run_case(M, K, N, r, cfgname, dtype, dev):
           "intw": dict(MXINT_Q, w_quantizer=dict(name="integer", width=4, frac_width=1 + (M + K) % 4, is_signed=True)),
           "w8b16": w8(8, [1, 16], MXINT_Q), "w6b32": w8(6, [1, 32], MXINT_Q), "w5b16": w8(5, [1, 16], MXINT_Q), "w7g128": w8(7, [1, 128], INT_Q),
           "w8row": w8(8, [1, -1], INT_Q), "w8opt": w8(8, [1, 16], OPT_Q),
+          "at4x16": dict(MXINT_Q, x_quantizer=dict(MXINT_Q["x_quantizer"], block_size=[4, 16])),
+          "at3x32": dict(MXINT_Q, x_quantizer=dict(MXINT_Q["x_quantizer"], block_size=[3, 32])),
+          "atallx16": dict(MXINT_Q, x_quantizer=dict(MXINT_Q["x_quantizer"], block_size=[-1, 16])),
+          "at2d8x16": dict(MXINT_Q, x_quantizer=dict(MXINT_Q["x_quantizer"], block_size=[8, 16], skip_first_dim=False)),
+          "atbout": dict(MXINT_Q, B_out_quantizer=dict(MXINT_Q["x_quantizer"], block_size=[2, 16])),
           "mxint": MXINT_Q, "opt": OPT_Q, "int": INT_Q, "bout_pass": dict(MXINT_Q, B_out_quantizer={"name": "passthrough"}),
           "a16": A16_Q, "a16mix": dict(A16_Q, B_out_quantizer=MXINT_Q["x_quantizer"]),
           "tile": dict(MXINT_Q, w_quantizer=dict(MXINT_Q["w_quantizer"], block_size=[(M % 3 + 1) * 4, 16 * (K % 2 + 1)]))}[cfgname]
@@ -90,11 +98,15 @@ def run_case(M, K, N, r, cfgname, dtype, dev):
         mod.tuning = [0, _lib.TUNE_I8_ROWS_128, _lib.TUNE_I8_ROWS_256, _lib.TUNE_AMAX_ATOMIC, _lib.TUNE_AMAX_PARTS | _lib.TUNE_I8_ROWS_128,
                       _lib.TUNE_AMAX_PARTS][pick]
     xin = x.to(dtype)
+    if cfgname.startswith("at") and cfgname != "at2d8x16" and M % 2 == 0:
+        xin = xin.reshape(2, M // 2, K)  # [batch, tokens, features]: the tiles are anchored per batch element
     y = mod(xin.to(dev)).float().cpu()
     cast = lambda t: None if t is None else t.to(dtype).float()
     ref = O.lqer_linear_forward(xin.float(), cast(W), cast(b), cast(sd.get("A")) if r else None, cast(sd.get("B")) if r else None, qcm)
     err = float((y - ref).norm() / ref.norm().clamp_min(1e-30))
     tol = {torch.float16: 1e-3, torch.bfloat16: 6e-3, torch.float32: 3e-5}[dtype]
+    if cfgname.startswith("at") and dtype != torch.float32:
+        tol *= 2  # the tile route rounds x A and (x A) B to the module's dtype between the quantizers, as the reference does
     return err, tol
 
 
