@@ -118,6 +118,12 @@ typedef struct lqer_linear_desc {
                                          row behind a zero-fill launch (the round-4 form) instead of per-segment partial maxima in plain
                                          stores that the GEMM folds (no zero-fill launch); max is order-independent: same bits         */
 #define LQER_TUNE_AMAX_PARTS 0x80000   /* ... the segment partials at every N (default: up to N = 4096, where they are faster)     */
+#define LQER_TUNE_AMAX_XCH_MISS 0x100000 /* int8 route, ONE round of 128-row tiles (at most one tile per CU) and one B_out block per row:
+                                         by default there is NO pre-pass launch - every workgroup publishes the row maxima of its own
+                                         tile's side product as tagged granules and gathers its row band's at the epilogue (either
+                                         AMAX pin above restores the pre-pass).  This bit makes every workgroup treat the others'
+                                         granules as missing, i.e. take the fall-back that computes the whole band's maxima itself (a
+                                         workgroup that times out on a neighbour does the same): same bits                          */
 #define LQER_TUNE_XA_REDUCE_IN_GEMM 0x20000 /* lqer_linear_forward on 128-row tiles: no reduce launch between the quantizer and the
                                          GEMM - its workgroups sum the partial tiles of x A for their own rows (lqer_tile_partials).
                                          Off by default: measured slower (C2: the GEMM grows by 5.3 us, the launch it saves took

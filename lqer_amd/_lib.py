@@ -19,6 +19,7 @@ K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
 ROUTE_SMALLM, ROUTE_TILE128, ROUTE_TILE256, ROUTE_I8 = 0, 1, 2, 3
 TUNE_TILE_ROWS_128, TUNE_TILE_ROWS_64, TUNE_DECODE_NO_POLL, TUNE_XA_REDUCE_IN_GEMM = 0x1, 0x2, 0x10000, 0x20000
 TUNE_I8_ROWS_128, TUNE_I8_ROWS_256, TUNE_AMAX_ATOMIC, TUNE_AMAX_PARTS = 0x4, 0x8, 0x40000, 0x80000
+TUNE_AMAX_XCH_MISS = 0x100000  # int8 route's in-GEMM exchange of the B_out row maxima: every workgroup takes its fall-back
 
 
 def tune_xcd_block(t: int) -> int:

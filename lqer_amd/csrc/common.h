@@ -461,7 +461,12 @@ struct GemmArgs {
   int i8_shift;         // some weight group carries a non-zero shift (blocks of 128 with differing exponents)
   int tuning;           // lqer_linear_desc_t.tuning of the call (LQER_TUNE_*: kernel-variant knobs of tests, same bits)
   int w_twos;           // the packed weight holds two's-complement nibbles (w_quantizer = integer): the 128-row tile kernel only
-  int w_i8codes;        // int8 route: w8 holds 8-bit CODES (weights of 5..8 bits, one exponent per row), half-step layout
+  int w_i8codes;        // int8 route: w8 holds 8-bit CODES (weights of 5..8 bits, one exponent per row), fragment-major layout
+  // int8 route, one round of 128-row tiles, one B_out block per row: NO pre-pass launch - every workgroup publishes the row maxima of
+  // its own tile's side product as {value, tag} granules [tiles_n][Mp] in bout_amax and gathers its row band's at the epilogue
+  // (gemm_w4a8_i8.hip "exchange"); xch_nonce = the host part of the tag
+  int bout_xch;
+  uint32_t xch_nonce;
 };
 
 int quantize_dispatch(const void* x, int dtype, int64_t rows, int64_t cols, int64_t ld, const QP& q,
@@ -494,7 +499,8 @@ bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) 
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 bool i8_eligible(const GemmArgs& g, int bout);     // gemm_w4a8_i8.hip: the int8 MFMA main loop (g.w8 set, large M)
 int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
-int i8_tile_rows(const GemmArgs& g);  // 256, or 128 where that takes fewer (weighted) rounds of one tile per CU
+int i8_tile_rows(const GemmArgs& g);
+bool i8_amax_exchange_ok(const GemmArgs& g, bool lowrank, int bout);  // the int8 kernel can exchange the B_out row maxima itself  // 256, or 128 where that takes fewer (weighted) rounds of one tile per CU
 int i8_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, int mbits, void* w_i8, int32_t* flags, hipStream_t st);
 int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st, bool codes8 = false);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16

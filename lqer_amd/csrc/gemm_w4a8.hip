@@ -25,6 +25,7 @@
 //  * the two waves of a SIMD run half a k-step apart (LOAD / COMPUTE ping-pong, see the main loop).
 //  * tiles are numbered so that each of the 8 XCDs works on a contiguous run of tiles (same token
 //    rows -> the activation slab stays in that XCD's L2).
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -1084,8 +1085,9 @@ size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout) {
   const int64_t Np = lqer_padded_n(N);
   const int64_t L = (bout.block <= 0 || bout.block >= N) ? Np : bout.block;
   const int64_t nblk = (Np + L - 1) / L;
-  // (one block per row on the int8 route: up to LQER_AMAX_NSEG column-segment partials per row instead of one atomic cell)
-  return (size_t)lqer_padded_m(m_max) * (nblk == 1 ? LQER_AMAX_NSEG : nblk) * sizeof(float);
+  // (one block per row on the int8 route: up to LQER_AMAX_NSEG column-segment partials per row instead of one atomic cell - or as
+  // many {value, tag} granules of 8 bytes when the GEMM exchanges the maxima itself)
+  return (size_t)lqer_padded_m(m_max) * (nblk == 1 ? 2 * LQER_AMAX_NSEG : nblk) * sizeof(float);
 }
 
 // B_out handling of a launch: 0 pass-through, 1 blocks of 16 (maxima in registers), 2 other blocks (pre-pass); < 0 error
@@ -1163,13 +1165,23 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
       // rank 32: 111.9 us with partials against 104.4 with cells, where 4096 x 4096 gains 2 us; tools/ab_i8.py --rows --amax)
       const bool parts = g.w8 && g.bout_nblk == 1 && !(g.tuning & LQER_TUNE_AMAX_ATOMIC) &&
                          (tiles_n32 <= 8 * LQER_AMAX_NSEG || (g.tuning & LQER_TUNE_AMAX_PARTS));
-      const size_t need = (size_t)lqer_padded_m(g.M) * (parts ? LQER_AMAX_NSEG : g.bout_nblk) * sizeof(float);
+      // ... or no pre-pass at all: one round of the int8 kernel's 128-row tiles exchanges the maxima inside the GEMM launch
+      const bool xch = g.w8 && g.bout_nblk == 1 && !(g.tuning & (LQER_TUNE_AMAX_ATOMIC | LQER_TUNE_AMAX_PARTS)) && i8_eligible(g, bout) &&
+                       i8_amax_exchange_ok(g, lowrank, bout);
+      const size_t need = (size_t)lqer_padded_m(g.M) * (xch ? 2 * LQER_AMAX_NSEG : (parts ? LQER_AMAX_NSEG : g.bout_nblk)) * sizeof(float);
       if (!scratch || scratch_bytes < need) {
         set_error("linear_gemm: scratch %zu B < %zu B for the B_out row-block maxima", scratch_bytes, need);
         return LQER_E_WORKSPACE;
       }
       g.bout_amax = (float*)scratch;
       g.bout_nseg = 0;
+      g.bout_xch = 0;
+      if (xch) {
+        // the call's tag: a counter spread over all 32 bits (odd multiplier: a bijection); the kernel mixes in its dispatch id and queue
+        static std::atomic<uint32_t> xch_calls{1};
+        g.bout_xch = 1;
+        g.xch_nonce = xch_calls.fetch_add(1, std::memory_order_relaxed) * 0x9E3779B1u;
+      } else {
       if (!parts) (void)hipMemsetAsync(scratch, 0, need, st);
       // padded rank (x limbs of x A) -> 16-deep slices (a template parameter: exact, no per-slice branch) and row groups per wave
       const int nks = g.rp / 16;
@@ -1232,6 +1244,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
         default: set_error("B_out pre-pass: padded rank %d x limbs > 256", g.rp); return LQER_E_UNSUPPORTED;
       }
 #undef LQER_AMAX
+      }  // (pre-pass)
   }
   if (g.w8) {  // LQER_Q_MXINT_I8: xq is the int8 image - only the int8 kernel can read it
     if (!i8_eligible(g, bout)) {

@@ -71,6 +71,12 @@ struct Geo {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_g;  // a {value, tag} granule of the row-maxima exchange
+
+// llvm.amdgcn.dispatch.id (see decode1.hip): the same value in every workgroup of a launch, a new one for every launch - replayed
+// hipGraph nodes included
+extern "C" __device__ unsigned long long lqer_dispatch_id() __asm("llvm.amdgcn.dispatch.id");
+constexpr int XCH_SWEEPS = 64;  // polls of a missing granule (~1 us each) before the workgroup computes the band's maxima itself
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -356,6 +362,24 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // with ONE 64-column panel of xAq the epilogue lives in ring slots 1 and 2 (stage: activation slot 1; output transposes:
   // activation slot 2, waves 6 and 7 in weight slot 2), so that slot 0 can take the next tile's first step meanwhile
   const bool one_panel = !LOWRANK || g.rp <= 64;  // (wave-uniform)
+  // ---- exchange of the B_out row maxima inside the launch (one round of 128-row tiles, one block per row: no pre-pass) ------------
+  // Every workgroup computes, in its prologue (under the ring fill), the row maxima of ITS tile's side product - k_bout_amax's
+  // arithmetic and order for these 256 columns - and publishes them as {value, tag} granules [tn][row] (one 8-byte sc1 store per row:
+  // value and tag arrive together, nothing to zero, nothing to fence); at the epilogue the 128 row threads gather the tiles_n granules
+  // of their row (sc1 loads, requested before the conversion pass, polled until the tags match) and fold them - max is order-
+  // independent: the bits of the pre-pass.  The tag is the launch's nonce (host counter + dispatch id + queue: a replayed graph node
+  // gets a fresh one).  Nobody has to wait for anybody: a workgroup that does not see a neighbour's granules in time (a grid that is
+  // not resident at once: another stream's kernel on the CUs) computes the whole band's maxima itself, same routine.
+  constexpr bool XCH_OK = NT == 4 && LOWRANK && BOUT == 2;
+  bool xch = false;
+  uint32_t xtag = 0;
+  if constexpr (XCH_OK) {
+    xch = g.bout_xch != 0;
+    if (xch)
+      xtag = (g.xch_nonce + (uint32_t)lqer_dispatch_id() * 0x9E3779B1u) ^
+             ((uint32_t)((unsigned long long)__builtin_amdgcn_queue_ptr() >> 6) * 0x85EBCA6Bu);
+  }
+  const int64_t xch_Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
   const int ep_stage = one_panel ? A_SLOT : EP_STAGE;
   float t_xs = 0.f, t_amax = 0.f;  // this lane's row constants of the tile whose tables are written next
   bool first = true;
@@ -465,7 +489,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     if (tid < BM) {
       t_xs = g.xscale[m0_ + tid];
       if constexpr (LOWRANK && BOUT == 2) {
-        if (g.bout_nseg > 0) {  // the pre-pass left one partial per column segment (no atomics, no zero-fill): fold them
+        if (xch) {  // (gathered at the epilogue)
+          t_amax = 1.0f;
+        } else if (g.bout_nseg > 0) {  // the pre-pass left one partial per column segment (no atomics, no zero-fill): fold them
           const int64_t Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
           // (all cells requested at once - a runtime loop waits for every load in turn, 16 round trips in front of the ring
           // fill; segments past the last one re-read it: max does not mind)
@@ -501,40 +527,145 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       }
     }
   };
-  // the tile's first two steps (past the end of K: dropped by the buffer range check).  A later tile's step 0 is already in
-  // slot 0 when the epilogue before it kept out of that slot (one panel of xAq); its row constants were requested there too
-  if (first) load_tables(m0);
-  if constexpr (W8D) {
-    // request order per step [A x 2, W x 4] (a compiler barrier between the two keeps it): the vmcnt(12) below retires step 0 whole,
-    // the vmcnt(16) at the end of every LOAD the activations of the step after it
-    using std::integral_constant;
-    if (first || !one_panel) issue_a8(a_base, 0, 0);
-    asm volatile("" ::: "memory");
-    issue_wq(w_base, 0, integral_constant<int, 0>{});
-    asm volatile("" ::: "memory");
-    issue_a8(a_base, 1, 1);
-    asm volatile("" ::: "memory");
-    issue_wq(w_base, 1, integral_constant<int, 1>{});
-    asm volatile("" ::: "memory");
-    issue_a8(a_base, 2, 2);
-    asm volatile("" ::: "memory");
-    issue_wq(w_base, 2, integral_constant<int, 2>{});
-    asm volatile("" ::: "memory");
-  } else if constexpr (W8) {
-    // request order [A(0) x 4, W(0) x 2, W(1) x 2, A(1) x 4]: the vmcnt(6) below leaves W(1) and A(1) in flight; the first LOAD's
-    // vmcnt(6) - its own four requests and two more - then retires W(1), which the second LOAD reads
-    if (first || !one_panel) {
-      issue_a8(a_base, 0, 0);
-      issue_w8(w_base, 0, 0);
+  // exchange: the side product of column tile `tnx` against this workgroup's 128 rows, this wave's 32 columns - operands straight from
+  // global memory in k_bout_amax's layout and summation order (limb-major, slices ascending; B^T fragment as the A operand, so that
+  // every register of a lane's accumulator is the same token row), folded into the running row maxima mx[u] (rows 32 u + l31)
+  bf16x8 pbf[XCH_OK ? 8 : 1], pxf[XCH_OK ? 4 : 1][XCH_OK ? 4 : 1];
+  const int xch_nsl = XCH_OK ? g.rp / 16 : 0;
+  auto xch_load_s = [&](int tnx, auto nl_c, auto nsl_c) {  // static (limbs, slices): straight-line requests
+    if constexpr (XCH_OK) {
+      constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value;
+      const bf16_t* const bl = g.bt + (int64_t)(tnx * BN + wave * 32 + l31) * g.rp + 8 * lh;
+      const int64_t limb = (int64_t)g.Np * g.rp;
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int ks = 0; ks < NSL; ++ks) pbf[l * 4 + ks] = *(const bf16x8*)(bl + l * limb + ks * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int ks = 0; ks < NSL; ++ks) pxf[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)(m0 + 32 * u + l31) * g.xaq_ld + ks * 16 + 8 * lh);
     }
-    issue_w8(w_base, 1, 1);
-    issue_a8(a_base, 1, 1);
+  };
+  auto xch_compute_s = [&](float (&mx)[4], auto nl_c, auto nsl_c) {
+    if constexpr (XCH_OK) {
+      constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int ks = 0; ks < NSL; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pbf[l * 4 + ks], pxf[u][ks], acc, 0, 0, 0);
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[k])), fabsf(acc[k + 1]));
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);  // lanes l and l ^ 32
+        mx[u] = fmaxf(mx[u], fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+      }
+    }
+  };
+  const int xch_key = XCH_OK ? g.b_limbs * 16 + xch_nsl : 0;  // (wave-uniform; i8_amax_exchange_ok admits exactly six cases)
+  // ... the waves' maxima through LDS (asm: an LDS access hipcc can see would wait for every LDS-DMA in flight): [wave][row] fp32 in
+  // activation slot 3 - free in the prologue until the first LOAD requests step 3, and at the epilogue until the output transposes
+  const uint32_t xch_red = lds0 + OFF_A + 3 * A_SLOT;
+  auto xch_reduce = [&](const float (&mx)[4]) -> float {  // -> the row maximum of row `tid` (threads tid < BM)
+    float r = 0.f;
+    if constexpr (XCH_OK) {
+      if (lh == 0) {
+        const uint32_t a = xch_red + (wave * BM + l31) * 4;
+        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:128\n\tds_write_b32 %0, %3 offset:256\n\tds_write_b32 %0, %4 offset:384" ::"v"(a),
+                     "v"(mx[0]), "v"(mx[1]), "v"(mx[2]), "v"(mx[3])
+                     : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < BM) {
+        const uint32_t a = xch_red + tid * 4;
+        float v0, v1, v2, v3, v4, v5, v6, v7;
+        asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:512\n\tds_read_b32 %2, %8 offset:1024\n\tds_read_b32 %3, %8 offset:1536\n\t"
+                     "ds_read_b32 %4, %8 offset:2048\n\tds_read_b32 %5, %8 offset:2560\n\tds_read_b32 %6, %8 offset:3072\n\t"
+                     "ds_read_b32 %7, %8 offset:3584\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                     : "v"(a)
+                     : "memory");
+        r = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), fmaxf(fmaxf(v4, v5), fmaxf(v6, v7)));
+      }
+    }
+    return r;
+  };
+  // granules [Mp][LQER_AMAX_NSEG] x {value, tag}: a row's 16 granules are 128 contiguous bytes
+  const auto xch_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, XCH_OK && xch ? (int)(xch_Mp * LQER_AMAX_NSEG * 8) : 0, 0x00020000);
+  auto ring_fill = [&]() {
+    // the tile's first two steps (past the end of K: dropped by the buffer range check).  A later tile's step 0 is already in
+    // slot 0 when the epilogue before it kept out of that slot (one panel of xAq); its row constants were requested there too
+    if (first) load_tables(m0);
+    if constexpr (W8D) {
+      // request order per step [A x 2, W x 4] (a compiler barrier between the two keeps it): the vmcnt(12) below retires step 0 whole,
+      // the vmcnt(16) at the end of every LOAD the activations of the step after it
+      using std::integral_constant;
+      if (first || !one_panel) issue_a8(a_base, 0, 0);
+      asm volatile("" ::: "memory");
+      issue_wq(w_base, 0, integral_constant<int, 0>{});
+      asm volatile("" ::: "memory");
+      issue_a8(a_base, 1, 1);
+      asm volatile("" ::: "memory");
+      issue_wq(w_base, 1, integral_constant<int, 1>{});
+      asm volatile("" ::: "memory");
+      issue_a8(a_base, 2, 2);
+      asm volatile("" ::: "memory");
+      issue_wq(w_base, 2, integral_constant<int, 2>{});
+      asm volatile("" ::: "memory");
+    } else if constexpr (W8) {
+      // request order [A(0) x 4, W(0) x 2, W(1) x 2, A(1) x 4]: the vmcnt(6) below leaves W(1) and A(1) in flight; the first LOAD's
+      // vmcnt(6) - its own four requests and two more - then retires W(1), which the second LOAD reads
+      if (first || !one_panel) {
+        issue_a8(a_base, 0, 0);
+        issue_w8(w_base, 0, 0);
+      }
+      issue_w8(w_base, 1, 1);
+      issue_a8(a_base, 1, 1);
+    } else {
+      if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
+      issue_step(a_base, w_base, 1, 1);
+      if constexpr (DEPTH == 3) issue_step(a_base, w_base, 2, 2);
+    }
+    write_tables();
+  };
+  // exchange: this tile's side-product operands are requested AHEAD of the ring fill (loads return in issue order) and multiplied
+  // behind it - one switch around both halves, so that only the registers of the (limbs, slices) case at hand are live across the fill
+  float xmx[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (XCH_OK) {
+    if (xch) {
+      using std::integral_constant;
+      auto pre = [&](auto nl_c, auto nsl_c) {
+        xch_load_s(tn, nl_c, nsl_c);
+        ring_fill();
+        xch_compute_s(xmx, nl_c, nsl_c);
+      };
+      switch (xch_key) {
+        case 16 + 1: pre(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+        case 16 + 2: pre(integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
+        case 16 + 4: pre(integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+        case 32 + 1: pre(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+        case 32 + 2: pre(integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+        default: pre(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+      }
+    } else {
+      ring_fill();
+    }
   } else {
-    if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
-    issue_step(a_base, w_base, 1, 1);
-    if constexpr (DEPTH == 3) issue_step(a_base, w_base, 2, 2);
+    ring_fill();
   }
-  write_tables();
+  if constexpr (XCH_OK) {
+    if (xch) {  // this tile's row maxima -> granules [tn][m0 + row]; the miss vote of the epilogue starts clean
+      const float r = xch_reduce(xmx);
+      if (tid < BM) {
+        const u32x2_g gv = {__float_as_uint(r), xtag};
+        __builtin_amdgcn_raw_buffer_store_b64(gv, xch_rsrc, (int)(((m0 + tid) * LQER_AMAX_NSEG + tn) * 8), 0, 16);  // sc1
+      }
+      if (tid == 0) asm volatile("ds_write_b32 %0, %1 offset:1020" ::"v"(lds0 + EP_TAB), "v"(0u) : "memory");
+    }
+  }
 
   i32x16 R[NT];
 #pragma unroll
@@ -1159,6 +1290,18 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // activation tile's row pitch and swizzle); this wave's B^T fragments in registers when there are at most 8 (limb,
   // 16-deep slice) pairs - rank 64 with fp16 A / B, rank 128 with 8-bit A / B -, else re-fetched from L2 for every token
   // tile.  Their latency passes under the conversion of the integer tile (below).
+  // exchange: this row's granules of every column tile, requested now by LDS-DMA (no registers held across the conversion pass;
+  // sc1) into activation slot 3 - [wave][piece j][lane][16 B] = granules 2 j, 2 j + 1 of row 64 wave + lane; a wave reads back what it
+  // requested itself (vmcnt, no barrier).  Their round trip passes under the staging and the conversion.
+  const int tid_e = wave * 64 + lane;
+  if constexpr (XCH_OK) {
+    if (xch && wave < 2) {
+#pragma unroll
+      for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + OFF_A + 3 * A_SLOT + wave * 8192 + j * 1024), 16,
+                                                 (int)((m0 + tid_e) * (LQER_AMAX_NSEG * 8)) + j * 16, 0, 0, 16);
+    }
+  }
   bf16x8 sb[LOWRANK ? 8 : 1];
 #pragma unroll
   for (int i = 0; i < (LOWRANK ? 8 : 1); ++i) sb[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};  // (defined on every path: not carried around the tile loop)
@@ -1237,11 +1380,102 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   asm volatile("" ::"v"(R[0][0]), "v"(R[NT - 1][15]));
   I8_STAMP(cp_b, cp_x);
 #endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // exchange: the row's B_out scales from the gathered maximum (write_tables' arithmetic), in front of the barrier below
+  auto xch_tables = [&](float amax_row) {
+    if constexpr (XCH_OK) {
+      int up = g.bout.mbits - block_exponent(amax_row, g.bout);
+      up = up > 126 ? 126 : (up < -126 ? -126 : up);
+      const uint32_t upb = (uint32_t)(127 + up) << 23;
+      asm volatile("ds_write_b32 %0, %1 offset:1024\n\tds_write_b32 %0, %2 offset:2048\n\tds_write_b32 %0, %3 offset:3072" ::"v"(
+                       lds0 + EP_TAB + 4 * tid_e),
+                   "v"(upb), "v"((uint32_t)(127 - up) << 23), "v"(1e-9f * __uint_as_float(upb))
+                   : "memory");
+    }
+  };
+  if constexpr (XCH_OK) {
+    if (xch && wave < 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's requests: the granules - and the xAq pieces, awaited below anyway)
+      const uint32_t ga = lds0 + OFF_A + 3 * A_SLOT + wave * 8192 + lane * 16;
+      u32x4 gq[LQER_AMAX_NSEG / 2];  // piece j: {value, tag} of column tiles 2 j and 2 j + 1
+      asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
+                   "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\t"
+                   "ds_read_b128 %7, %8 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(gq[0]), "=&v"(gq[1]), "=&v"(gq[2]), "=&v"(gq[3]), "=&v"(gq[4]), "=&v"(gq[5]), "=&v"(gq[6]), "=&v"(gq[7])
+                   : "v"(ga)
+                   : "memory");
+      const int ntile = g.tiles_n;  // (granules of column tiles that do not exist are never looked at)
+      bool ok = !(g.tuning & LQER_TUNE_AMAX_XCH_MISS);  // (test knob: take the fall-back)
+      for (int tries = 0; ok; ++tries) {
+        bool all = true;
+#pragma unroll
+        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
+          all = all && (2 * j >= ntile || gq[j][1] == xtag) && (2 * j + 1 >= ntile || gq[j][3] == xtag);
+        if (all) break;
+        if (tries == XCH_SWEEPS) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
+          if ((2 * j < ntile && gq[j][1] != xtag) || (2 * j + 1 < ntile && gq[j][3] != xtag))
+            gq[j] = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc, (int)((m0 + tid_e) * (LQER_AMAX_NSEG * 8)) + j * 16, 0, 16);  // sc1
+      }
+      if (ok) {
+        float m = 0.f;  // (maxima are >= 0)
+#pragma unroll
+        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j) {
+          if (2 * j < ntile) m = fmaxf(m, __uint_as_float(gq[j][0]));
+          if (2 * j + 1 < ntile) m = fmaxf(m, __uint_as_float(gq[j][2]));
+        }
+        xch_tables(m);
+      } else {
+        asm volatile("ds_write_b32 %0, %1 offset:1020" ::"v"(lds0 + EP_TAB), "v"(1u) : "memory");  // the workgroup's vote
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef LQER_CLOCKPROBE
   I8_STAMP(cp_cc, cp_x);
 #endif
   __syncthreads();  // the xAq tile has landed for every wave
+  if constexpr (XCH_OK) {
+    if (xch) {
+      uint32_t vote;
+      asm volatile("ds_read_b32 %0, %1 offset:1020\n\ts_waitcnt lgkmcnt(0)" : "=v"(vote) : "v"(lds0 + EP_TAB) : "memory");
+      if (__builtin_amdgcn_readfirstlane((int)vote) != 0) {
+        // fall-back (workgroup-uniform): some row did not see a neighbour's granules - every column tile's maxima are computed here,
+        // same routine, same bits (the output regions are not in use yet: the reduce buffer is free)
+        // (one row group at a time: the accumulators of the tile are live here - 16 fragment registers instead of 64)
+        float mx[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int tnx = 0; tnx < g.tiles_n; ++tnx) {
+          const bf16_t* const bl = g.bt + (int64_t)(tnx * BN + wave * 32 + l31) * g.rp + 8 * lh;
+#pragma unroll 1
+          for (int u = 0; u < 4; ++u) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int l = 0; l < g.b_limbs; ++l)
+              for (int ks = 0; ks < xch_nsl; ++ks) {
+                const bf16x8 bfr = *(const bf16x8*)(bl + l * bt_limb + ks * 16);
+                const bf16x8 xfr = *(const bf16x8*)(g.xaq + (int64_t)(m0 + 32 * u + l31) * g.xaq_ld + ks * 16 + 8 * lh);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, xfr, acc, 0, 0, 0);
+              }
+            float m = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[k])), fabsf(acc[k + 1]));
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            if (u == 0) mx[0] = fmaxf(mx[0], m);
+            else if (u == 1) mx[1] = fmaxf(mx[1], m);
+            else if (u == 2) mx[2] = fmaxf(mx[2], m);
+            else mx[3] = fmaxf(mx[3], m);
+          }
+        }
+        const float r = xch_reduce(mx);
+        if (tid_e < BM) xch_tables(r);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+  }
 #ifdef LQER_CLOCKPROBE
   I8_STAMP(cp_e1, cp_e1r);
 #endif
@@ -1507,6 +1741,18 @@ int i8_tile_rows(const GemmArgs& g) {
   const int64_t tn = g.Np / i8::BN;
   const int64_t r256 = (((g.M + 255) / 256) * tn + CUS - 1) / CUS, r128 = (((g.M + 127) / 128) * tn + CUS - 1) / CUS;
   return r128 * 56 < r256 * 100 ? 128 : 256;
+}
+
+// The int8 kernel exchanges the B_out row maxima itself (no pre-pass launch) when every tile is resident at once - one round of
+// 128-row tiles, at most one per CU -, the row band has at most LQER_AMAX_NSEG column tiles (one granule each per row) and the side
+// product is at most 2 limbs x 4 slices (its operands wait in registers under the ring fill).
+bool i8_amax_exchange_ok(const GemmArgs& g, bool lowrank, int bout) {
+  if (!lowrank || bout != 2 || g.bout_nblk != 1) return false;
+  if (i8_tile_rows(g) != 128) return false;
+  const int64_t tn = g.Np / i8::BN, tm = (g.M + 127) / 128;
+  if (tn > LQER_AMAX_NSEG || tm * tn > 256) return false;
+  const int nsl = g.rp / 16;
+  return (g.b_limbs == 1 || g.b_limbs == 2) && (nsl == 1 || nsl == 2 || nsl == 4);
 }
 
 // The int8 main loop needs: the int8 images (g.w8 set by the caller for an LQER_Q_MXINT_I8 descriptor), a token count of the

@@ -386,6 +386,76 @@ def test_int8_bout_row_maxima_as_segment_partials(lq, M, K, N, r):
     assert torch.equal(mod(xd), y)
 
 
+@pytest.mark.parametrize("M,K,N,r,qname,dtype", [(2048, 512, 4096, 32, "int", torch.float16),    # 16 x 16 tiles: the whole band of granules
+                                                 (300, 256, 1000, 16, "int", torch.float16),     # ragged M and N: 3 x 4 tiles
+                                                 (1000, 384, 2048, 64, "introw", torch.bfloat16),  # rank 64: two limbs x four slices
+                                                 (130, 128, 256, 16, "w8", torch.float16),       # 8-bit codes (registers), one column tile
+                                                 (640, 256, 512, 32, "int", torch.float32)])
+def test_int8_bout_row_maxima_exchanged_inside_the_gemm(lq, M, K, N, r, qname, dtype):
+    """One round of 128-row tiles with one B_out block per row: NO pre-pass launch - every workgroup publishes the row maxima of its
+    tile's side product as tagged granules and gathers its row band's at the epilogue.  Same bits as the pre-pass in both of its forms
+    (max is order-independent) and as the fall-back every workgroup takes when it does not see a neighbour in time (forced here by
+    LQER_TUNE_AMAX_XCH_MISS); stale or garbage granules in the workspace must not matter (the tag is per launch); a captured graph
+    replayed with new tokens follows them (the tag carries the dispatch id); two streams running such GEMMs at once finish (nobody
+    waits without a bound) with the same bits."""
+    from bench import INT_Q, INTROW_Q, W8A8_Q, make_case
+    from lqer_amd import _lib, ops
+    from lqer_amd.graph import GraphedCallable
+
+    qc = {"int": INT_Q, "introw": INTROW_Q, "w8": W8A8_Q}[qname]
+    x, W, A, B = make_case(M, K, N, r, seed=N + r + M, quantize_ab=False)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).to(dtype)
+    xd = x.to(dtype).to(DEV)
+    mod.tuning = _lib.TUNE_AMAX_PARTS | _lib.TUNE_I8_ROWS_128
+    want = mod(xd).clone()
+    assert mod._x_i8
+    L = _lib.lib()
+    dtc = _lib.F32 if dtype == torch.float32 else _lib.F16
+    assert L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, dtc) == 128
+    mod.tuning = 0
+    assert L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, dtc) == 128  # (the shapes above are one round of 128-row tiles by default)
+    ws = ops.workspace(torch.device(DEV), 16)
+    for fill in (0x00, 0x7F, 0xFF):  # stale granules: zeros, large floats with a constant "tag", NaN patterns
+        ws.fill_(fill)
+        assert torch.equal(mod(xd), want), fill
+    for _ in range(4):
+        assert torch.equal(mod(xd), want)
+    mod.tuning = _lib.TUNE_AMAX_XCH_MISS
+    assert torch.equal(mod(xd), want)
+    mod.tuning = _lib.TUNE_AMAX_ATOMIC
+    assert torch.equal(mod(xd), want)
+    mod.tuning = 0
+    # a captured graph, replayed with other tokens
+    xs = xd.clone()
+    gc = GraphedCallable(mod, xs, warmup=1)
+    for scale in (1.0, -0.5, 3.0):
+        xn = (x * scale).to(dtype).to(DEV)
+        mod.tuning = _lib.TUNE_AMAX_PARTS
+        ref = mod(xn).clone()
+        mod.tuning = 0
+        got = gc(xn).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), scale
+    # two streams at once (separate modules: separate workspaces per stream)
+    mod2 = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+    mod2.load_state_dict({"weight": W, "A": A, "B": B})
+    mod2 = mod2.to(DEV).to(dtype)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(6):
+        with torch.cuda.stream(s1):
+            o1 = mod(xd)
+        with torch.cuda.stream(s2):
+            o2 = mod2(xd)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1, want) and torch.equal(o2, want)
+
+
 def _w8a8(wblock=-1, lqer=True):
     from bench import _bfp
 

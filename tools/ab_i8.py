@@ -53,10 +53,12 @@ def main():
         d128, d256 = mod._desc(), mod._desc()
         d128.tuning, d256.tuning = _lib.TUNE_I8_ROWS_128, _lib.TUNE_I8_ROWS_256
         variants = [("i8r128", d128), ("i8r256", d256), ("bf16", mod._desc(plain=True))]
-        if a.amax:  # ... and the round-4 form of the B_out pre-pass (atomicMax cells behind a zero-fill launch)
-            d128a = mod._desc()
+        if a.amax:  # ... the forms of the B_out row maxima: exchanged inside the GEMM launch (default where eligible), the pre-pass
+            # with segment partials, the pre-pass with atomicMax cells behind a zero-fill launch (round 4)
+            d128p, d128a = mod._desc(), mod._desc()
+            d128p.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_PARTS
             d128a.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_ATOMIC
-            variants = [("i8r128", d128), ("r128at", d128a)]
+            variants = [("i8r128", d128), ("r128pa", d128p), ("r128at", d128a)]
     for name, desc in variants:
         ws = torch.empty(ops.linear_sizes(desc, M).workspace, dtype=torch.uint8, device=dev)
         xq = ws.data_ptr()
@@ -86,7 +88,8 @@ def main():
         d = (outs[i8n].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
         print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs[i8n] != outs['bf16']).float().mean()):.2e}")
     if a.rows and a.amax:
-        print("segment partials vs atomic cells bit-identical:", bool(torch.equal(outs["i8r128"], outs["r128at"])))
+        print("in-GEMM exchange / segment partials / atomic cells bit-identical:",
+              bool(torch.equal(outs["i8r128"], outs["r128at"]) and torch.equal(outs["i8r128"], outs["r128pa"])))
     elif a.rows:
         print("128-row vs 256-row int8 tiles bit-identical:", bool(torch.equal(outs["i8r128"], outs["i8r256"])),
               " default tile rows:", L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, _lib.F16))
