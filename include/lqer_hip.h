@@ -265,7 +265,9 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t
                     const void* a_t, int a_limbs, void* xaq_bf16, void* scratch,
                     size_t scratch_bytes, void* stream);
 /* scratch of lqer_linear_gemm: 0 unless B_out blocks differ from 16 columns (then the kernel needs
- * the per-row-block maxima of xAq @ B, computed by a pre-pass it launches itself). */
+ * the per-row-block maxima of xAq @ B: a pre-pass it launches itself - or, on the int8 route with one block per row and one round
+ * of 128-row tiles, tagged granules that the GEMM's own workgroups exchange through this scratch, LQER_TUNE_AMAX_XCH_MISS above).
+ * The contents of the scratch need no initialisation and may be anything left by earlier calls. */
 size_t lqer_linear_gemm_scratch_bytes(const lqer_linear_desc_t* desc, int64_t m_max);
 int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
                      const void* w_packed, const void* xaq_bf16, const void* b_t, int b_limbs,
