@@ -14,6 +14,7 @@ ap.add_argument("--K", type=int, default=5120)
 ap.add_argument("--N", type=int, default=5120)
 ap.add_argument("--r", type=int, default=64)
 ap.add_argument("--wblock", type=int, default=128)
+ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="lqer_linear_desc_t.tuning, e.g. 0x80000: the pre-pass with segment partials instead of the in-GEMM exchange")
 a = ap.parse_args()
 from lqer_amd import _lib
 _lib.LIB_PATH = os.path.abspath(a.lib)  # the module and every helper bind the diagnostic build
@@ -38,6 +39,7 @@ tiles = (-(-M // BMt)) * (-(-N // 256))
 buf = torch.zeros(tiles * 8 * 8, dtype=torch.int64, device=dev)
 assert L.lqer_debug_set_i8_stamp_buffer(buf.data_ptr()) == 0
 desc = mod._desc()
+desc.tuning = a.tuning
 p = mod._packed
 st = torch.cuda.current_stream().cuda_stream
 Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
@@ -61,7 +63,7 @@ steps = -(-K // 128)
 cyc, rt = b[:, :, 0], b[:, :, 1]
 clk = (cyc / rt * 100e6).median().item()
 med = lambda t: t.median().item()
-print(f"M={M} K={K} N={N} r={r} wblock={a.wblock} tile rows {BMt}: call (pre-pass + GEMM) {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, {tiles} tiles = {tiles / 256:.2f} rounds")
+print(f"M={M} K={K} N={N} r={r} wblock={a.wblock} tuning={a.tuning:#x} tile rows {BMt}: call (pre-pass + GEMM) {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, {tiles} tiles = {tiles / 256:.2f} rounds")
 print(f"  main loop   {med(cyc):9.0f} cycles = {med(cyc) / steps:6.0f} per 128-k step ({BMt * 8} = MFMA-bound), {med(rt) / 100:7.2f} us; clock {clk / 1e9:.3f} GHz")
 print(f"  ring fill   {med(b[:, :, 2]):9.0f} cycles")
 pk = buf.cpu().view(tiles, 8, 8)[:nb, :, 3]
