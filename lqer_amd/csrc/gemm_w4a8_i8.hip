@@ -364,10 +364,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const bool one_panel = !LOWRANK || g.rp <= 64;  // (wave-uniform)
   // ---- exchange of the B_out row maxima inside the launch (one round of 128-row tiles, one block per row: no pre-pass) ------------
   // Every workgroup computes, in its prologue (under the ring fill), the row maxima of ITS tile's side product - k_bout_amax's
-  // arithmetic and order for these 256 columns - and publishes them as {value, tag} granules [tn][row] (one 8-byte sc1 store per row:
-  // value and tag arrive together, nothing to zero, nothing to fence); at the epilogue the 128 row threads gather the tiles_n granules
-  // of their row (sc1 loads, requested before the conversion pass, polled until the tags match) and fold them - max is order-
-  // independent: the bits of the pre-pass.  The tag is the launch's nonce (host counter + dispatch id + queue: a replayed graph node
+  // arithmetic and order for these 256 columns - and publishes their block exponents, four rows per {bytes, tag} granule [row quad][tn]
+  // (one 8-byte sc1 store: bytes and tag arrive together, nothing to zero, nothing to fence); at the epilogue the 128 row threads
+  // gather the tiles_n granules of their quad (sc1, requested before the conversion pass, polled until the tags match) and take the
+  // largest exponent - the exponent of a maximum is the maximum of the exponents: the bits of the pre-pass.  The tag is the launch's nonce (host counter + dispatch id + queue: a replayed graph node
   // gets a fresh one).  Nobody has to wait for anybody: a workgroup that does not see a neighbour's granules in time (a grid that is
   // not resident at once: another stream's kernel on the CUs) computes the whole band's maxima itself, same routine.
   constexpr bool XCH_OK = NT == 4 && LOWRANK && BOUT == 2;
@@ -593,8 +593,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     }
     return r;
   };
-  // granules [Mp][LQER_AMAX_NSEG] x {value, tag}: a row's 16 granules are 128 contiguous bytes
-  const auto xch_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, XCH_OK && xch ? (int)(xch_Mp * LQER_AMAX_NSEG * 8) : 0, 0x00020000);
+  // granules [Mp / 4][LQER_AMAX_NSEG] x {exponent bytes of 4 rows, tag}: a row quad's 16 granules are 128 contiguous bytes
+  const auto xch_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, XCH_OK && xch ? (int)(xch_Mp / 4 * LQER_AMAX_NSEG * 8) : 0, 0x00020000);
   auto ring_fill = [&]() {
     // the tile's first two steps (past the end of K: dropped by the buffer range check).  A later tile's step 0 is already in
     // slot 0 when the epilogue before it kept out of that slot (one panel of xAq); its row constants were requested there too
@@ -659,9 +659,16 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   if constexpr (XCH_OK) {
     if (xch) {  // this tile's row maxima -> granules [tn][m0 + row]; the miss vote of the epilogue starts clean
       const float r = xch_reduce(xmx);
-      if (tid < BM) {
-        const u32x2_g gv = {__float_as_uint(r), xtag};
-        __builtin_amdgcn_raw_buffer_store_b64(gv, xch_rsrc, (int)(((m0 + tid) * LQER_AMAX_NSEG + tn) * 8), 0, 16);  // sc1
+      if (tid < BM) {  // (waves 0 and 1, whole)
+        // what travels is the row's block EXPONENT (the exponent of a maximum is the maximum of the exponents: block_exponent is
+        // monotone), one byte - four rows per granule: {4 exponent bytes, tag}, a quarter of the requests and bytes at the gather
+        uint32_t wv = (uint32_t)(block_exponent(r, g.bout) - g.bout.emin) << (8 * (tid & 3));
+        wv |= __shfl_xor(wv, 1, 64);
+        wv |= __shfl_xor(wv, 2, 64);
+        if ((tid & 3) == 0) {
+          const u32x2_g gv = {wv, xtag};
+          __builtin_amdgcn_raw_buffer_store_b64(gv, xch_rsrc, (int)((((m0 + tid) >> 2) * LQER_AMAX_NSEG + tn) * 8), 0, 16);  // sc1
+        }
       }
       if (tid == 0) asm volatile("ds_write_b32 %0, %1 offset:1020" ::"v"(lds0 + EP_TAB), "v"(0u) : "memory");
     }
@@ -1290,16 +1297,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // activation tile's row pitch and swizzle); this wave's B^T fragments in registers when there are at most 8 (limb,
   // 16-deep slice) pairs - rank 64 with fp16 A / B, rank 128 with 8-bit A / B -, else re-fetched from L2 for every token
   // tile.  Their latency passes under the conversion of the integer tile (below).
-  // exchange: this row's granules of every column tile, requested now by LDS-DMA (no registers held across the conversion pass;
-  // sc1) into activation slot 3 - [wave][piece j][lane][16 B] = granules 2 j, 2 j + 1 of row 64 wave + lane; a wave reads back what it
-  // requested itself (vmcnt, no barrier).  Their round trip passes under the staging and the conversion.
+  // exchange: the granules of this tile's 32 row quads x every column tile (4 KiB), requested now by LDS-DMA (no registers held across
+  // the conversion pass; sc1) into activation slot 3: wave w (0, 1) brings quads 16 w .. 16 w + 15 with two requests - request j, lane l:
+  // quad 8 j + l / 8, piece l % 8 (16 B = the granules of column tiles 2 p, 2 p + 1) - and reads back what it requested itself
+  // (vmcnt, no barrier).  The round trip passes under the staging and the conversion.
   const int tid_e = wave * 64 + lane;
   if constexpr (XCH_OK) {
     if (xch && wave < 2) {
 #pragma unroll
-      for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + OFF_A + 3 * A_SLOT + wave * 8192 + j * 1024), 16,
-                                                 (int)((m0 + tid_e) * (LQER_AMAX_NSEG * 8)) + j * 16, 0, 0, 16);
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + OFF_A + 3 * A_SLOT + wave * 2048 + j * 1024), 16,
+                                                 (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16, 0, 0, 16);
     }
   }
   bf16x8 sb[LOWRANK ? 8 : 1];
@@ -1381,9 +1389,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   I8_STAMP(cp_b, cp_x);
 #endif
   // exchange: the row's B_out scales from the gathered maximum (write_tables' arithmetic), in front of the barrier below
-  auto xch_tables = [&](float amax_row) {
+  auto xch_tables = [&](int e_row) {  // (e_row = block_exponent of the row's maximum)
     if constexpr (XCH_OK) {
-      int up = g.bout.mbits - block_exponent(amax_row, g.bout);
+      int up = g.bout.mbits - e_row;
       up = up > 126 ? 126 : (up < -126 ? -126 : up);
       const uint32_t upb = (uint32_t)(127 + up) << 23;
       asm volatile("ds_write_b32 %0, %1 offset:1024\n\tds_write_b32 %0, %2 offset:2048\n\tds_write_b32 %0, %3 offset:3072" ::"v"(
@@ -1395,15 +1403,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   if constexpr (XCH_OK) {
     if (xch && wave < 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's requests: the granules - and the xAq pieces, awaited below anyway)
-      const uint32_t ga = lds0 + OFF_A + 3 * A_SLOT + wave * 8192 + lane * 16;
-      u32x4 gq[LQER_AMAX_NSEG / 2];  // piece j: {value, tag} of column tiles 2 j and 2 j + 1
-      asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\tds_read_b128 %3, %8 offset:3072\n\t"
-                   "ds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\tds_read_b128 %6, %8 offset:6144\n\t"
-                   "ds_read_b128 %7, %8 offset:7168\n\ts_waitcnt lgkmcnt(0)"
+      const int qw = lane >> 2;  // this row's quad within the wave's 16
+      const uint32_t ga = lds0 + OFF_A + 3 * A_SLOT + wave * 2048 + (qw >> 3) * 1024 + (qw & 7) * 128;
+      u32x4 gq[LQER_AMAX_NSEG / 2];  // piece p: {bytes, tag} of column tiles 2 p and 2 p + 1
+      asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+                   "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\t"
+                   "ds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(gq[0]), "=&v"(gq[1]), "=&v"(gq[2]), "=&v"(gq[3]), "=&v"(gq[4]), "=&v"(gq[5]), "=&v"(gq[6]), "=&v"(gq[7])
                    : "v"(ga)
                    : "memory");
       const int ntile = g.tiles_n;  // (granules of column tiles that do not exist are never looked at)
+      const int goff = (int)(((m0 >> 2) + 16 * wave + qw) * (LQER_AMAX_NSEG * 8));
       bool ok = !(g.tuning & LQER_TUNE_AMAX_XCH_MISS);  // (test knob: take the fall-back)
       for (int tries = 0; ok; ++tries) {
         bool all = true;
@@ -1419,16 +1429,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
           if ((2 * j < ntile && gq[j][1] != xtag) || (2 * j + 1 < ntile && gq[j][3] != xtag))
-            gq[j] = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc, (int)((m0 + tid_e) * (LQER_AMAX_NSEG * 8)) + j * 16, 0, 16);  // sc1
+            gq[j] = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc, goff + j * 16, 0, 16);  // sc1
       }
       if (ok) {
-        float m = 0.f;  // (maxima are >= 0)
+        const int sh = 8 * (lane & 3);
+        uint32_t eb = 0;  // (exponent bytes are >= 0: e - emin)
 #pragma unroll
         for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j) {
-          if (2 * j < ntile) m = fmaxf(m, __uint_as_float(gq[j][0]));
-          if (2 * j + 1 < ntile) m = fmaxf(m, __uint_as_float(gq[j][2]));
+          if (2 * j < ntile) eb = max(eb, (gq[j][0] >> sh) & 0xffu);
+          if (2 * j + 1 < ntile) eb = max(eb, (gq[j][2] >> sh) & 0xffu);
         }
-        xch_tables(m);
+        xch_tables((int)eb + g.bout.emin);
       } else {
         asm volatile("ds_write_b32 %0, %1 offset:1020" ::"v"(lds0 + EP_TAB), "v"(1u) : "memory");  // the workgroup's vote
       }
@@ -1471,7 +1482,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
           }
         }
         const float r = xch_reduce(mx);
-        if (tid_e < BM) xch_tables(r);
+        if (tid_e < BM) xch_tables(block_exponent(r, g.bout));
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
