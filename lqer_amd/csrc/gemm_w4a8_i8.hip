@@ -28,6 +28,7 @@
 // Tile, ring and wave structure are those of gemm_w4a8_m256.hip: 256(m) x 256(n) per workgroup, 8 waves side by side
 // along n, LDS-DMA into a 3-slot ring two steps ahead (one step = 128 k = 128 B per activation row, the same row
 // pitch and swizzle), LOAD / COMPUTE ping-pong between the two waves of a SIMD, half a step (4 token tiles) per phase.
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -1757,11 +1758,26 @@ int i8_tile_rows(const GemmArgs& g) {
 // The int8 kernel exchanges the B_out row maxima itself (no pre-pass launch) when every tile is resident at once - one round of
 // 128-row tiles, at most one per CU -, the row band has at most LQER_AMAX_NSEG column tiles (one granule each per row) and the side
 // product is at most 2 limbs x 4 slices (its operands wait in registers under the ring fill).
+// (the CUs this device really has - a partitioned part shows 32 of them: a grid that runs in rounds there would send every workgroup
+// through its polls and its fall-back; queried once per device)
+static int device_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int c = cus[dev & 63].load(std::memory_order_relaxed);
+  if (c == 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 1;
+    cus[dev & 63].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+
 bool i8_amax_exchange_ok(const GemmArgs& g, bool lowrank, int bout) {
   if (!lowrank || bout != 2 || g.bout_nblk != 1) return false;
   if (i8_tile_rows(g) != 128) return false;
   const int64_t tn = g.Np / i8::BN, tm = (g.M + 127) / 128;
-  if (tn > LQER_AMAX_NSEG || tm * tn > 256) return false;
+  const int cus = device_cus();
+  if (tn > LQER_AMAX_NSEG || tm * tn > (cus < 256 ? cus : 256)) return false;
   const int nsl = g.rp / 16;
   return (g.b_limbs == 1 || g.b_limbs == 2) && (nsl == 1 || nsl == 2 || nsl == 4);
 }
