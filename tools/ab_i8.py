@@ -59,6 +59,10 @@ def main():
             d128p.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_PARTS
             d128a.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_ATOMIC
             variants = [("i8r128", d128), ("r128pa", d128p), ("r128at", d128a)]
+    if a.amax and not a.rows:  # the library's own tile height; the row maxima exchanged in the launch (where eligible) / the two pre-pass forms
+        dx, dp, da = mod._desc(), mod._desc(), mod._desc()
+        dp.tuning, da.tuning = _lib.TUNE_AMAX_PARTS, _lib.TUNE_AMAX_ATOMIC
+        variants = [("i8xch", dx), ("i8pa", dp), ("i8at", da)]
     for name, desc in variants:
         ws = torch.empty(ops.linear_sizes(desc, M).workspace, dtype=torch.uint8, device=dev)
         xq = ws.data_ptr()
@@ -83,11 +87,14 @@ def main():
         gemm(rt)
         torch.cuda.synchronize()
         outs[name] = y.clone()
-    i8n = "i8r128" if a.rows else "int8"
+    i8n = "i8r128" if a.rows else ("i8xch" if a.amax else "int8")
     if "bf16" in outs:
         d = (outs[i8n].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
         print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs[i8n] != outs['bf16']).float().mean()):.2e}")
-    if a.rows and a.amax:
+    if a.amax and not a.rows:
+        print("in-GEMM exchange / segment partials / atomic cells bit-identical:",
+              bool(torch.equal(outs["i8xch"], outs["i8at"]) and torch.equal(outs["i8xch"], outs["i8pa"])))
+    elif a.rows and a.amax:
         print("in-GEMM exchange / segment partials / atomic cells bit-identical:",
               bool(torch.equal(outs["i8r128"], outs["r128at"]) and torch.equal(outs["i8r128"], outs["r128pa"])))
     elif a.rows:
