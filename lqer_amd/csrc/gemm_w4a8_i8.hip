@@ -62,7 +62,16 @@ struct Geo {
   // behind the ring, written at the start of a tile: per-row constants of the epilogue - the x row scales, the B_out
   // scales 2^(mbits - e[m]) and 2^(e[m] - mbits) - fp32 [256] each
   static constexpr int EP_TAB = GEMM_LDS;
-  static constexpr int KERNEL_LDS = GEMM_LDS + 4 * 1024;  // ... and 1e-9 * 2^(mbits - e[m]), the B_out quantizer's epsilon after scaling
+  // ... and 1e-9 * 2^(mbits - e[m]), the B_out quantizer's epsilon after scaling; behind the tables 256 B per wave that nobody reads: where
+  // the waves other than wave 0 point the ring fill's shift-byte request (issue_step: every wave issues the same number of requests,
+  // without a branch)
+  static constexpr int EP_DUMP = GEMM_LDS + 4 * 1024;
+  static constexpr int KERNEL_LDS = EP_DUMP + 8 * 256;
+  // XCH instantiation: the tile's one panel of xAq lives behind the tables from the prologue on (requested right behind the first ring
+  // step, read by the epilogue's side product - nothing is staged after the main loop)
+  static constexpr int EP_XAQ = KERNEL_LDS;
+  static constexpr int KERNEL_LDS_XCH = KERNEL_LDS + PANEL;
+  static_assert(KERNEL_LDS_XCH <= 160 * 1024 || NT == 8, "LDS of the exchange instantiation");
   // one panel of xAq: the epilogue lives in ring slots 1.. (stage: activation slot 1; output transposes: the activation slots
   // behind it, waves 6 and 7 in weight slot 2), so that slot 0 can take the next tile's first step meanwhile
   static_assert(2 * A_SLOT + 6 * EP_OUT_WAVE <= NSLOT * A_SLOT && 2 * EP_OUT_WAVE <= W_SLOT && PANEL <= A_SLOT,
@@ -77,6 +86,13 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_g;  // a {value, tag}
 // llvm.amdgcn.dispatch.id (see decode1.hip): the same value in every workgroup of a launch, a new one for every launch - replayed
 // hipGraph nodes included
 extern "C" __device__ unsigned long long lqer_dispatch_id() __asm("llvm.amdgcn.dispatch.id");
+// The gather's FIRST read of the granules: sc0 alone (past the CU's L1, served by the XCD's L2).  The tile map puts a row band's column
+// tiles on one XCD whenever a band has at most 32 of them, and the publisher's sc1 store goes through that same L2: a hit costs a
+// fraction of the agent-scope round trip behind the L2.  A stale or foreign line just fails the tag test and is polled at agent scope.
+#ifndef LQER_XCH_GATHER_AUX
+#define LQER_XCH_GATHER_AUX 1
+#endif
+constexpr int XCH_GATHER_AUX = LQER_XCH_GATHER_AUX;
 constexpr int XCH_SWEEPS = 64;  // polls of a missing granule (~1 us each) before the workgroup computes the band's maxima itself
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -330,9 +346,14 @@ __global__ __launch_bounds__(256) void k_i8_unpack8(const uint8_t* __restrict__ 
 //   NT = 4: a wave's weight rows are nobody else's - its codes skip LDS: four coalesced 16-byte loads per lane and step into one of
 //           four register sets, three steps ahead beside the activation ring (step4_w8).  35.8 us per round of 4096-k tiles on
 //           all 256 CUs where 256-row tiles fill half of them in 63 us (M = 2048, 4096 x 4096); 1,500 cycles per step.
-template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT, bool W8 = false>
+// XCH (round 6): the instantiation for ONE round of 128-row tiles that exchanges the B_out row maxima inside the launch (what used to be
+// the runtime flag g.bout_xch) - no tile loop, every operand of the epilogue requested in the prologue (the xAq panel in an LDS region
+// of its own behind the row tables, the wave's B^T fragments, column scale and bias in registers across the main loop), the first ring
+// step requested before anything else.
+template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT, bool W8 = false, bool XCH = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   static_assert(!W8 || !SHIFT, "8-bit weight codes: one exponent per weight row");
+  static_assert(!XCH || (NT == 4 && LOWRANK && BOUT == 2), "the in-launch exchange: 128-row tiles, one B_out block per row");
   constexpr bool W8D = W8 && NT == 4;  // ... on 128-row tiles: the codes go straight from global memory into registers (step4_w8)
   constexpr int W8_SLOT = 256 * 64;  // one half-step of int8 codes
   using G = Geo<NT>;
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int wave_k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef LQER_CLOCKPROBE
   unsigned long long cp_c[4], cp_r[4], cp_e1 = 0, cp_e1r = 0, cp_e2 = 0, cp_e2r = 0, cp_a = 0, cp_b = 0, cp_cc = 0, cp_x = 0;
+  unsigned long long cp_p[4] = {0, 0, 0, 0}, cp_tries = 0;  // round 6: prologue sections (first request out, all requests out, row maxima computed, published)
   I8_STAMP(cp_c[0], cp_r[0]);
 #endif
 
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 
   // with ONE 64-column panel of xAq the epilogue lives in ring slots 1 and 2 (stage: activation slot 1; output transposes:
   // activation slot 2, waves 6 and 7 in weight slot 2), so that slot 0 can take the next tile's first step meanwhile
-  const bool one_panel = !LOWRANK || g.rp <= 64;  // (wave-uniform)
+  const bool one_panel = XCH || !LOWRANK || g.rp <= 64;  // (wave-uniform)
   // ---- exchange of the B_out row maxima inside the launch (one round of 128-row tiles, one block per row: no pre-pass) ------------
   // Every workgroup computes, in its prologue (under the ring fill), the row maxima of ITS tile's side product - k_bout_amax's
   // arithmetic and order for these 256 columns - and publishes their block exponents, four rows per {bytes, tag} granule [row quad][tn]
@@ -371,19 +393,39 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // largest exponent - the exponent of a maximum is the maximum of the exponents: the bits of the pre-pass.  The tag is the launch's nonce (host counter + dispatch id + queue: a replayed graph node
   // gets a fresh one).  Nobody has to wait for anybody: a workgroup that does not see a neighbour's granules in time (a grid that is
   // not resident at once: another stream's kernel on the CUs) computes the whole band's maxima itself, same routine.
-  constexpr bool XCH_OK = NT == 4 && LOWRANK && BOUT == 2;
-  bool xch = false;
+  constexpr bool XCH_OK = XCH;
+  constexpr bool xch = XCH;
   uint32_t xtag = 0;
-  if constexpr (XCH_OK) {
-    xch = g.bout_xch != 0;
-    if (xch)
-      xtag = (g.xch_nonce + (uint32_t)lqer_dispatch_id() * 0x9E3779B1u) ^
-             ((uint32_t)((unsigned long long)__builtin_amdgcn_queue_ptr() >> 6) * 0x85EBCA6Bu);
+  if constexpr (XCH) {
+    // host call counter, dispatch id and queue are mixed INDEPENDENTLY (distinct odd multipliers, then a murmur-style finaliser), with
+    // the launch's shape on top: two launches share a tag only by a 2^-32 accident, never by calls + dispatch id adding up alike
+    uint32_t h = g.xch_nonce ^ ((uint32_t)lqer_dispatch_id() * 0xC2B2AE35u) ^
+                 ((uint32_t)((unsigned long long)__builtin_amdgcn_queue_ptr() >> 6) * 0x85EBCA6Bu) ^ ((uint32_t)g.M * 0x27D4EB2Fu) ^
+                 ((uint32_t)g.Np * 0x165667B1u);
+    h ^= h >> 16, h *= 0x7FEB352Du, h ^= h >> 15, h *= 0x846CA68Bu, h ^= h >> 16;
+    xtag = h;
   }
   const int64_t xch_Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
-  const int ep_stage = one_panel ? A_SLOT : EP_STAGE;
+  const int ep_stage = XCH ? G::EP_XAQ : (one_panel ? A_SLOT : EP_STAGE);
   float t_xs = 0.f, t_amax = 0.f;  // this lane's row constants of the tile whose tables are written next
   bool first = true;
+  // the tile's MODE byte travels as the aligned dword around it, requested a tile ahead (here: the first tile's, a scalar load - nothing
+  // has been stored yet; the next tile's where the epilogue requests its row constants) and looked at only where the main loop is
+  // chosen: a byte load at the head of the tile sat, with its vmcnt(0), in front of the ring fill
+  // XCH: this wave's B^T fragments (the side product's B operand, <= 2 limbs x 4 slices), its column's scale and bias: requested once, in
+  // the prologue, for the row-maxima pre-phase AND the epilogue
+  bf16x8 sbx[XCH ? 8 : 1];
+  float ws_x = 0.f, bv_x = 0.f;
+  uint32_t mode_word = 0, mode_sh = 0;
+  auto load_mode = [&](int tn_) {
+    if constexpr (SHIFT) {
+      // (the table starts on a 4-byte boundary: pointer arithmetic on the kernel argument keeps the load a GLOBAL one - through an
+      // integer cast it becomes a flat load, behind which hipcc's waitcnt pass drains everything)
+      mode_word = ((const uint32_t*)(g.w8 + i8_weight_mode_offset(g.Np, nk)))[tn_ >> 2];
+      mode_sh = 8u * (uint32_t)(tn_ & 3);
+    }
+  };
+  load_mode(tn);
 
   for (;;) {  // ---- tiles of this workgroup ----------------------------------------------------------------------------
   // Per-lane constants are re-derived for every tile from laundered ids (an empty asm the optimiser cannot look through):
@@ -409,8 +451,6 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int w_voff0 = (W8 ? wave * 4096 : (2 * wave) * 1024) + lane * 16, w_voff1 = w_voff0 + 1024, s_voff = 256 * 64 + lane * 4;
   const uint8_t* const a_base = xq8 + (int64_t)m0 * Kp8;
   const uint8_t* const w_base = g.w8 + (size_t)tn * nk * (W8 ? 2 * W8_SLOT : I8_WBLOCK);
-  int tile_mode = I8_MODE_NONE;  // (workgroup-uniform)
-  if constexpr (SHIFT) tile_mode = __builtin_amdgcn_readfirstlane((int)g.w8[i8_weight_mode_offset(g.Np, nk) + tn]);
   auto make_rs = [](const uint8_t* base, uint32_t range) {
     const unsigned long long b64 = (unsigned long long)base;
     return (u32x4){(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b64),
@@ -450,9 +490,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
                                              kt * I8_WBLOCK, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + slot * W_SLOT + (2 * wave + 1) * 1024), 16, w_voff1,
                                              kt * I8_WBLOCK, 0, 0);
-    if (wave == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + OFF_W + slot * W_SLOT + 256 * 64), 4, s_voff, kt * I8_WBLOCK,
-                                               0, 0);
+    // the 256 shift bytes are wave 0's; the other waves issue the same request against an EMPTY range into a dump area of their own.
+    // No branch: hipcc's waitcnt pass counts the requests behind a load only back to the last control-flow join - with a branch per step
+    // it waited for the whole ring fill (vmcnt(0)) wherever the prologue uses anything it has loaded
+    const auto s_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, wave == 0 ? nk * I8_WBLOCK : 0, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s_rsrc, (lds_void*)(smem + (wave == 0 ? OFF_W + slot * W_SLOT + 256 * 64 : G::EP_DUMP + wave * 256)), 4,
+                                             s_voff, kt * I8_WBLOCK, 0, 0);
   };
   // W8: the two operands have their own cadence
   auto issue_a8 = [&](const uint8_t* ab, int kt, int slot) {
@@ -531,7 +574,6 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // exchange: the side product of column tile `tnx` against this workgroup's 128 rows, this wave's 32 columns - operands straight from
   // global memory in k_bout_amax's layout and summation order (limb-major, slices ascending; B^T fragment as the A operand, so that
   // every register of a lane's accumulator is the same token row), folded into the running row maxima mx[u] (rows 32 u + l31)
-  bf16x8 pbf[XCH_OK ? 8 : 1], pxf[XCH_OK ? 4 : 1][XCH_OK ? 4 : 1];
   const int xch_nsl = XCH_OK ? g.rp / 16 : 0;
   auto xch_load_s = [&](int tnx, auto nl_c, auto nsl_c) {  // static (limbs, slices): straight-line requests
     if constexpr (XCH_OK) {
@@ -541,23 +583,33 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #pragma unroll
       for (int l = 0; l < NL; ++l)
 #pragma unroll
-        for (int ks = 0; ks < NSL; ++ks) pbf[l * 4 + ks] = *(const bf16x8*)(bl + l * limb + ks * 16);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int ks = 0; ks < NSL; ++ks) pxf[u][ks] = *(const bf16x8*)(g.xaq + (int64_t)(m0 + 32 * u + l31) * g.xaq_ld + ks * 16 + 8 * lh);
+        for (int ks = 0; ks < NSL; ++ks) sbx[l * NSL + ks] = *(const bf16x8*)(bl + l * limb + ks * 16);
     }
   };
   auto xch_compute_s = [&](float (&mx)[4], auto nl_c, auto nsl_c) {
     if constexpr (XCH_OK) {
       constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value;
+      // the xAq fragments of the 4 row groups come from the tile's LDS panel (requested once per workgroup, 16 KiB, where round 5 had
+      // every wave fetch all 128 rows itself - 64 KiB per workgroup through a texture path that the ring fill needs); asm reads: an LDS
+      // access hipcc can see waits for every LDS-DMA in flight
+      bf16x8 pxf[4][NSL];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int ks = 0; ks < NSL; ++ks)
+          asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(pxf[u][ks]) : "v"(lds0 + G::EP_XAQ + swz(l31, 2 * ks + lh)), "i"(u * 4096) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pxf[0][0])::"memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int ks = 0; ks < NSL; ++ks) asm volatile("" : "+v"(pxf[u][ks]));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int l = 0; l < NL; ++l)
 #pragma unroll
-          for (int ks = 0; ks < NSL; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pbf[l * 4 + ks], pxf[u][ks], acc, 0, 0, 0);
+          for (int ks = 0; ks < NSL; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sbx[l * NSL + ks], pxf[u][ks], acc, 0, 0, 0);
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[k])), fabsf(acc[k + 1]));
@@ -596,18 +648,35 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   };
   // granules [Mp / 4][LQER_AMAX_NSEG] x {exponent bytes of 4 rows, tag}: a row quad's 16 granules are 128 contiguous bytes
   const auto xch_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, XCH_OK && xch ? (int)(xch_Mp / 4 * LQER_AMAX_NSEG * 8) : 0, 0x00020000);
-  auto ring_fill = [&]() {
-    // the tile's first two steps (past the end of K: dropped by the buffer range check).  A later tile's step 0 is already in
-    // slot 0 when the epilogue before it kept out of that slot (one panel of xAq); its row constants were requested there too
-    if (first) load_tables(m0);
+  // The ring fill in two halves (round 6).  HEAD: the tile's first step - the request everything waits for - goes out before anything else
+  // (a later tile's step 0 is already in slot 0 when the epilogue before it kept out of that slot - one panel of xAq -, its row constants
+  // were requested there too).  Between the halves: whatever else the prologue reads (the first tile's row constants; XCH: the xAq panel,
+  // the side product's fragments, column scale and bias) - loads return in issue order, so the counted waits below, which leave only the
+  // TAIL's requests in flight, cover it.  TAIL: the steps behind the first (past the end of K: dropped by the buffer range check) and the
+  // tables' LDS writes.
+  auto ring_fill_head = [&]() {
+    using std::integral_constant;
     if constexpr (W8D) {
       // request order per step [A x 2, W x 4] (a compiler barrier between the two keeps it): the vmcnt(12) below retires step 0 whole,
       // the vmcnt(16) at the end of every LOAD the activations of the step after it
-      using std::integral_constant;
       if (first || !one_panel) issue_a8(a_base, 0, 0);
       asm volatile("" ::: "memory");
       issue_wq(w_base, 0, integral_constant<int, 0>{});
       asm volatile("" ::: "memory");
+    } else if constexpr (W8) {
+      // request order [A(0) x 4, W(0) x 2, W(1) x 2, A(1) x 4]: the vmcnt(6) below leaves W(1) and A(1) in flight; the first LOAD's
+      // vmcnt(6) - its own four requests and two more - then retires W(1), which the second LOAD reads
+      if (first || !one_panel) {
+        issue_a8(a_base, 0, 0);
+        issue_w8(w_base, 0, 0);
+      }
+    } else {
+      if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
+    }
+  };
+  auto ring_fill_tail = [&]() {
+    using std::integral_constant;
+    if constexpr (W8D) {
       issue_a8(a_base, 1, 1);
       asm volatile("" ::: "memory");
       issue_wq(w_base, 1, integral_constant<int, 1>{});
@@ -617,43 +686,77 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       issue_wq(w_base, 2, integral_constant<int, 2>{});
       asm volatile("" ::: "memory");
     } else if constexpr (W8) {
-      // request order [A(0) x 4, W(0) x 2, W(1) x 2, A(1) x 4]: the vmcnt(6) below leaves W(1) and A(1) in flight; the first LOAD's
-      // vmcnt(6) - its own four requests and two more - then retires W(1), which the second LOAD reads
-      if (first || !one_panel) {
-        issue_a8(a_base, 0, 0);
-        issue_w8(w_base, 0, 0);
-      }
       issue_w8(w_base, 1, 1);
       issue_a8(a_base, 1, 1);
     } else {
-      if (first || !one_panel) issue_step(a_base, w_base, 0, 0);
       issue_step(a_base, w_base, 1, 1);
       if constexpr (DEPTH == 3) issue_step(a_base, w_base, 2, 2);
     }
     write_tables();
   };
-  // exchange: this tile's side-product operands are requested AHEAD of the ring fill (loads return in issue order) and multiplied
-  // behind it - one switch around both halves, so that only the registers of the (limbs, slices) case at hand are live across the fill
+  auto ring_fill = [&]() {
+    ring_fill_head();
+    if (first) load_tables(m0);
+    ring_fill_tail();
+  };
+  // exchange: the tile's first ring step first, then - in this order, all of them L2 hits - the xAq panel (LDS-DMA into its own region:
+  // the epilogue's side product reads it from there), this tile's side-product operands (B^T fragments: kept for the epilogue; xAq
+  // fragments in k_bout_amax's layout), the row and column constants; then the ring's other steps.  The products run behind the requests -
+  // one switch around both halves, so that only the registers of the (limbs, slices) case at hand are live across the fill
   float xmx[4] = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (XCH_OK) {
-    if (xch) {
-      using std::integral_constant;
-      auto pre = [&](auto nl_c, auto nsl_c) {
-        xch_load_s(tn, nl_c, nsl_c);
-        ring_fill();
-        xch_compute_s(xmx, nl_c, nsl_c);
-      };
-      switch (xch_key) {
-        case 16 + 1: pre(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
-        case 16 + 2: pre(integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
-        case 16 + 4: pre(integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
-        case 32 + 1: pre(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
-        case 32 + 2: pre(integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
-        default: pre(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+  if constexpr (XCH) {
+    using std::integral_constant;
+    // request order: [the xAq panel, the B^T fragments, row / column constants] [ring steps 0, 1, 2 - 15 requests per wave, no branch].
+    // The first group is small (48 KiB per workgroup) and lands a ring step's transfer time ahead of step 0: the row maxima are computed,
+    // reduced and published while the ring fills.
+    {
+      const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xaq + (int64_t)m0 * g.xaq_ld), 0, BM * g.xaq_ld * 2, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        const int row = wave * (8 * NPA) + i * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + G::EP_XAQ + wave * (8 * NPA) * 128 + i * 1024), 16,
+                                                 row * g.xaq_ld * 2 + chunk * 16, 0, 0, 0);
       }
-    } else {
-      ring_fill();
     }
+    // (fragments the (limbs, slices) case at hand does not have stay undefined - nothing reads them; a zero fill would have to wait for
+    // the requests in flight before it may write their registers)
+    switch (xch_key) {
+      case 16 + 1: xch_load_s(tn, integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+      case 16 + 2: xch_load_s(tn, integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
+      case 16 + 4: xch_load_s(tn, integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+      case 32 + 1: xch_load_s(tn, integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+      case 32 + 2: xch_load_s(tn, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+      default: xch_load_s(tn, integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+    }
+    load_tables(m0);
+    {
+      const int n_ = n0 + wave * 32 + l31;
+      ws_x = ((const float*)(g.w8 + (size_t)g.tiles_n * nk * (W8 ? 2 * W8_SLOT : I8_WBLOCK)))[n_];
+      bv_x = g.bias ? g.bias[n_] : 0.f;
+    }
+#ifdef LQER_CLOCKPROBE
+    I8_STAMP(cp_p[0], cp_x);
+#endif
+    ring_fill_head();
+    ring_fill_tail();  // (its table writes wait for this lane's row constant: the youngest request of the first group)
+    // the first group has landed for this wave (the ring's requests - W4: 15, W8 codes into registers: 18 - may stay in flight), then for all
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(W8D ? 18 : 15) : "memory");
+#ifdef LQER_CLOCKPROBE
+    I8_STAMP(cp_p[1], cp_x);
+#endif
+    switch (xch_key) {
+      case 16 + 1: xch_compute_s(xmx, integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+      case 16 + 2: xch_compute_s(xmx, integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
+      case 16 + 4: xch_compute_s(xmx, integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+      case 32 + 1: xch_compute_s(xmx, integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+      case 32 + 2: xch_compute_s(xmx, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+      default: xch_compute_s(xmx, integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+    }
+#ifdef LQER_CLOCKPROBE
+    asm volatile("" ::"v"(xmx[0]), "v"(xmx[3]));
+    I8_STAMP(cp_p[2], cp_x);
+#endif
   } else {
     ring_fill();
   }
@@ -672,6 +775,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         }
       }
       if (tid == 0) asm volatile("ds_write_b32 %0, %1 offset:1020" ::"v"(lds0 + EP_TAB), "v"(0u) : "memory");
+#ifdef LQER_CLOCKPROBE
+      I8_STAMP(cp_p[3], cp_x);
+#endif
     }
   }
 
@@ -1234,6 +1340,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       }
     }
   };
+  int tile_mode = I8_MODE_NONE;  // (workgroup-uniform)
+  if constexpr (SHIFT) tile_mode = __builtin_amdgcn_readfirstlane((int)((mode_word >> mode_sh) & 0xffu));
   if constexpr (!SHIFT) {
     main_loop(integral_constant<int, I8_MODE_NONE>{});
   } else {
@@ -1258,7 +1366,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // the next tile of this workgroup: its first step goes into ring slot 0 NOW (one panel of xAq: the epilogue keeps out of
   // slot 0), its row constants are requested; the second step follows when the epilogue has released slot 1
   const int vb_next = vb + (int)gridDim.x;
-  const bool has_next = vb_next < nt;  // (workgroup-uniform)
+  const bool has_next = !XCH && vb_next < nt;  // (workgroup-uniform; XCH: one round by construction)
   int m0_next = 0, n0_next = 0, tn_next = 0;
   if (has_next) {
     const int tile_n = tile_of(vb_next);
@@ -1274,6 +1382,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       if (one_panel) issue_step(xq8 + (int64_t)m0_next * Kp8, g.w8 + (size_t)tn_next * nk * I8_WBLOCK, 0, 0);
     }
     load_tables(m0_next);
+    load_mode(tn_next);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------------------
@@ -1308,7 +1417,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + OFF_A + 3 * A_SLOT + wave * 2048 + j * 1024), 16,
-                                                 (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16, 0, 0, 16);
+                                                 (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16, 0, 0,
+                                                 XCH_GATHER_AUX);
     }
   }
   bf16x8 sb[LOWRANK ? 8 : 1];
@@ -1317,7 +1427,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int nslices = LOWRANK ? g.rp / 16 : 0;  // 16-deep slices per limb
   const bf16_t* const bt_lane = LOWRANK ? g.bt + (int64_t)n * g.rp + 8 * lh : nullptr;  // + l * Np * rp + 16 ks
   const int64_t bt_limb = (int64_t)g.Np * g.rp;
-  if constexpr (LOWRANK) {
+  if constexpr (LOWRANK && !XCH) {
     // (exact range: the 128-byte pieces of a narrow xAq run into the next row, past the last row of the buffer they read 0)
     const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xaq + (int64_t)m0 * g.xaq_ld), 0, BM * g.xaq_ld * 2, 0x00020000);
     const int npanel = (g.rp + 63) >> 6;
@@ -1339,7 +1449,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       for (int ks = 0; ks < NSL; ++ks) sb[l * NSL + ks] = *(const bf16x8*)(bt_lane + l * bt_limb + ks * 16);
   };
   const int side_key = LOWRANK ? g.b_limbs * 16 + nslices : 0;  // (wave-uniform)
-  if constexpr (LOWRANK) {
+  if constexpr (LOWRANK && !XCH) {
     using std::integral_constant;
     switch (side_key) {
       case 16 + 1: load_sb(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
@@ -1352,8 +1462,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       default: break;
     }
   }
-  const float ws = wscale[n];
-  const float bv = g.bias ? g.bias[n] : 0.f;
+  const float ws = XCH ? ws_x : wscale[n];
+  const float bv = XCH ? bv_x : (g.bias ? g.bias[n] : 0.f);
 #ifdef LQER_CLOCKPROBE
   I8_STAMP(cp_a, cp_x);
 #endif
@@ -1422,6 +1532,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
           all = all && (2 * j >= ntile || gq[j][1] == xtag) && (2 * j + 1 >= ntile || gq[j][3] == xtag);
         if (all) break;
+#ifdef LQER_CLOCKPROBE
+        cp_tries = (unsigned long long)(tries + 1);
+#endif
         if (tries == XCH_SWEEPS) {
           ok = false;
           break;
@@ -1496,6 +1609,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) xaddr[c] = ep_stage + swz(l31, 2 * c + lh);
   // the side product of token tile i: static code for the common (limbs, slices per limb) pairs
+  auto sbf = [&](int i) -> bf16x8 {  // (XCH: the fragments the prologue requested)
+    if constexpr (XCH) return sbx[i];
+    else return sb[i];
+  };
   auto side_static = [&](int i, auto nl_c, auto nsl_c) {
     constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value;
     f32x16 sp;
@@ -1506,9 +1623,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         const bf16x8 xf = *(const bf16x8*)(smem + xaddr[ks & 3] + (ks >> 2) * PANEL + i * 4096);
         if (l == 0 && ks == 0) {
           const f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sb[0], z, 0, 0, 0);
+          sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sbf(0), z, 0, 0, 0);
         } else {
-          sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sb[l * NSL + ks], sp, 0, 0, 0);
+          sp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, sbf(l * NSL + ks), sp, 0, 0, 0);
         }
       }
     return sp;
@@ -1662,7 +1779,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   I8_STAMP(cp_c[3], cp_r[3]);
   if (g_i8_stamp_buf && lane_k == 0) {  // (the workgroup's LAST tile)
-    unsigned long long* o = g_i8_stamp_buf + ((size_t)blockIdx.x * 8 + wave_k) * 8;
+    unsigned long long* o = g_i8_stamp_buf + ((size_t)blockIdx.x * 8 + wave_k) * 16;
+    o[8] = cp_p[0] - cp_c[0], o[9] = cp_p[1] - cp_c[0], o[10] = cp_p[2] - cp_c[0], o[11] = cp_p[3] - cp_c[0];  // prologue sections (XCH)
+    o[12] = cp_tries, o[13] = cp_r[0], o[14] = cp_r[3], o[15] = cp_c[0];  // polls of the gather; absolute 100 MHz ticks at start / end
     o[0] = cp_c[2] - cp_c[1], o[1] = cp_r[2] - cp_r[1];  // main loop: cycles, 100 MHz ticks
     o[2] = cp_c[1] - cp_c[0];                            // prologue (ring fill)
     o[3] = ((cp_a - cp_c[2]) & 0xffff) | (((cp_b - cp_a) & 0xffff) << 16) | (((cp_cc - cp_b) & 0xffff) << 32) | (((cp_e1 - cp_cc) & 0xffff) << 48);
@@ -1690,6 +1809,15 @@ static int launch_w8(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
     lds_once.set((const void*)k_lqer_gemm_i8<DT, LR, BO, false, NT, true>, KERNEL_LDS);             \
     k_lqer_gemm_i8<DT, LR, BO, false, NT, true><<<grid, 512, KERNEL_LDS, st>>>(g);                  \
   } while (0)
+  if constexpr (NT == 4) {
+    if (g.bout_xch) {  // one round, the B_out row maxima exchanged inside the launch: its own instantiation
+      constexpr int LDS_X = Geo<NT>::KERNEL_LDS_XCH;
+      static LdsLimitOnce lds_once;
+      lds_once.set((const void*)k_lqer_gemm_i8<DT, true, 2, false, NT, true, true>, LDS_X);
+      k_lqer_gemm_i8<DT, true, 2, false, NT, true, true><<<grid, 512, LDS_X, st>>>(g);
+      return check_launch("lqer_gemm_i8 (8-bit weights, exchange)");
+    }
+  }
   if (!lowrank)
     LQER_I8_LAUNCH8(false, 0);
   else if (bout == 2)
@@ -1721,6 +1849,21 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
       k_lqer_gemm_i8<DT, LR, BO, false, NT><<<grid, 512, KERNEL_LDS, st>>>(g);                      \
     }                                                                                             \
   } while (0)
+  if constexpr (NT == 4) {
+    if (g.bout_xch) {  // one round, the B_out row maxima exchanged inside the launch: its own instantiation
+      constexpr int LDS_X = Geo<NT>::KERNEL_LDS_XCH;
+      if (g.i8_shift) {
+        static LdsLimitOnce lds_once;
+        lds_once.set((const void*)k_lqer_gemm_i8<DT, true, 2, true, NT, false, true>, LDS_X);
+        k_lqer_gemm_i8<DT, true, 2, true, NT, false, true><<<grid, 512, LDS_X, st>>>(g);
+      } else {
+        static LdsLimitOnce lds_once;
+        lds_once.set((const void*)k_lqer_gemm_i8<DT, true, 2, false, NT, false, true>, LDS_X);
+        k_lqer_gemm_i8<DT, true, 2, false, NT, false, true><<<grid, 512, LDS_X, st>>>(g);
+      }
+      return check_launch("lqer_gemm_i8 (exchange)");
+    }
+  }
   if (!lowrank)
     LQER_I8_LAUNCH(false, 0);
   else if (bout == 2)

@@ -69,6 +69,9 @@ class _LinearBase(nn.Linear):
         self._setup_lqer(l_config)
         # activation quantizers whose blocks can span token rows ([R, L] tiles, skip_first_dim = false): the tile route below
         self._tiles = any(getattr(self._fmt.get(r), "act_tiles", None) is not None for r in ("x", "A_out", "B_out"))
+        # ... on EVERY tensor (skip_first_dim = false: a 2-D input is tiled like a weight); with skip_first_dim = true a 2-D input is
+        # blocked per row and runs the fused kernels, so such a module still has packed images to save and load
+        self._tiles_only = any(getattr(self._fmt.get(r), "act_tiles", (0, 0, True))[2] is False for r in ("x", "A_out", "B_out"))
         self.__dict__["_inner"] = None  # (the tile route's main-product Linear: not a registered submodule - it shares this module's parameters)
 
     # -- configuration -------------------------------------------------------------------------
@@ -261,7 +264,7 @@ class _LinearBase(nn.Linear):
     def packed_state(self) -> dict:
         """The packed operands as flat tensors: 4-bit weight panels with their block exponents, the used bf16 limbs
         of A^T and B^T, the quantized bias, and an int32 header (version, K, N, rank, limb counts, formats)."""
-        if self._tiles:
+        if self._tiles_only:
             raise NotImplementedError("packed checkpoints hold the fused path's images: a module whose activation blocks span token rows "
                                       "(the tile route) keeps its dense state_dict")
         self.pack()
@@ -284,7 +287,7 @@ class _LinearBase(nn.Linear):
     def load_packed_state(self, state: dict, device: torch.device) -> None:
         """Attach images written by packed_state(); the dense weight / A / B parameters are not consulted afterwards
         (they may be left uninitialised).  Raises if the file does not match this module's shape or quantizers."""
-        if self._tiles:
+        if self._tiles_only:
             raise NotImplementedError("packed checkpoints hold the fused path's images: not for a module on the tile route")
         hdr = [int(v) for v in state["header"].tolist()]
         want = [self.PACKED_FORMAT_VERSION, self.in_features, self.out_features, self.rank]
@@ -411,6 +414,9 @@ class _LinearBase(nn.Linear):
         f = self._fmt
         if x.dim() < 2 or x.dim() > 3:
             raise RuntimeError(f"Unsupported x.ndim = {x.dim()}")  # (quantizers/utils.py:284)
+        if self._packed_only:
+            raise NotImplementedError("this input's activation blocks span token rows (the tile route), which works from the dense "
+                                      "parameters - the module was loaded from a packed checkpoint and holds the fused path's images only")
 
         def q(role, t):
             fm = f.get(role)
@@ -442,8 +448,21 @@ class _LinearBase(nn.Linear):
             y = y + q("B_out", torch.matmul(xaq, prm["B"]))
         return y
 
+    def _needs_tiles(self, x: torch.Tensor) -> bool:
+        """Some activation format of this module MAY span token rows (`_tiles`): does it for THIS tensor?  The reference reads
+        block_size against the tensor's rank at call time (quantizers/utils.py:261-284): [R, L] / a lone [L] with skip_first_dim = true
+        are per-row blocks on a 2-D tensor, and tiles of one token row (T = 1, R = 1) are per-row blocks as well - those calls keep the
+        fused kernels.  Whatever the reference raises for the rank is raised by the tile route."""
+        if x.dim() < 2 or x.dim() > 3:
+            return True
+        f = self._fmt
+        try:
+            return any(ops.act_rows_per_block(f.get(r), x.shape) != 1 for r in ("x", "A_out", "B_out"))
+        except (NotImplementedError, RuntimeError):
+            return True
+
     def _forward_on_current_device(self, x: torch.Tensor) -> torch.Tensor:
-        if self._tiles:
+        if self._tiles and self._needs_tiles(x):
             return self._forward_tiles(x)
         self._written_in_place()
         if self._packed is None or self.w_is_quantized is False:

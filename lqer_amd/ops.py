@@ -57,8 +57,9 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
     1-D bias), because the reference right-aligns `block_size` to the tensor and `skip_first_dim` picks the blocking
     routine (quantizers/utils.py:42-67, :261-284).  The HIP path implements blocks that run along the last dim within
     one row: [1, L], or a one-entry [L] / [-1] where the reference reads it per row (activations and weights with
-    skip_first_dim = true - the default, block_fp.py:111-118 - and the bias), and for the WEIGHT also 2-D tiles [R, L]
-    (skip_first_dim = false; a lone [L] then means all rows x L).  Anything else raises instead of being silently read per row.
+    skip_first_dim = true on 2-D tensors, and the bias), and for the WEIGHT also 2-D tiles [R, L] (skip_first_dim = false; a lone
+    [L] then means all rows x L); activation formats whose blocks can span token rows (incl. a lone [L] on a 3-D tensor: all T
+    rows x L) are recorded as `act_tiles` and take the module's tile route.  Anything else raises instead of being silently read per row.
     An `integer` WEIGHT (fixed point, signed, width 2..4) is packed as two's-complement nibbles and runs the 128-row tile kernel."""
     if cfg is None:
         raise KeyError("quantizer config missing")
@@ -92,12 +93,16 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
             block_rows = int(bs[-2]) if len(bs) >= 2 else -1
             if block_rows == 0:
                 raise ValueError(f"block_size {bs}: a block of 0 rows")
-        elif role in ("x", "A_out", "B_out") and (not skip or (len(bs) >= 2 and bs[-2] != 1)):
+        elif role in ("x", "A_out", "B_out") and (not skip or len(bs) == 1 or bs[-2] != 1):
             # an activation whose blocks can span token rows (quantizers/utils.py:211-237: [R, L] tiles over (tokens, features) of
             # every batch element of a 3-D tensor; :261-270: a 2-D tensor with skip_first_dim = false is blocked like a weight, a
             # lone [L] then means all rows x L).  What the tiles are depends on the tensor's rank at call time (a 2-D tensor with
             # skip_first_dim = true is blocked per row whatever R says, utils.py:127-144): the module's tile route decides there
             # (linear.py `_forward_tiles`, ops.quantize_act_tiles) - the fused kernels never see this format.
+            # A ONE-entry [L] with skip_first_dim = true - the reference quantizer's own default, block_fp.py:111-118 - is such a
+            # format too: right-aligned to a [batch, tokens, features] tensor it reads [1, T, L], one exponent for ALL token rows x L
+            # columns of a batch element (_infer_block_shape prepends -1, utils.py:56-66; _block_3d_activation :211-237); on a 2-D
+            # tensor the same entry means per-row blocks of L and runs the fused kernels (the module decides per call).
             act_tiles = (int(bs[-2]) if len(bs) >= 2 else -1, int(bs[-1]), skip)
         elif any(b != 1 for b in bs[:-1]):
             raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path for '{role}'")
@@ -110,6 +115,16 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
     if role != "b" and act_tiles is not None:
         fmt.act_tiles = act_tiles    # (R, L, skip_first_dim) as configured - a Python attribute, see above
     return fmt
+
+
+def act_rows_per_block(fmt: Optional[QFmt], shape) -> int:
+    """Token rows one exponent of an activation format spans on a tensor of `shape` (1: blocks run along the last dim within one row -
+    the fused kernels' layout).  Raises what act_tile_shape raises."""
+    if fmt is None or getattr(fmt, "act_tiles", None) is None:
+        return 1
+    R, _ = act_tile_shape(fmt, len(shape))
+    rows = int(shape[-2])
+    return rows if R <= 0 or R > rows else R
 
 
 def act_tile_shape(fmt: QFmt, ndim: int):

@@ -226,6 +226,14 @@ def main():
         ("acttile_r_on_2d", (9, 64), 64, 48, 16, False, dict(mxint_q, x_quantizer=bfp_cfg(8, [4, 16], True)), abq, False),  # R is read per row
         ("acttile_whole", (2, 6, 64), 64, 48, 16, False, dict(mxint_q, x_quantizer=bfp_cfg(8, [-1, -1], True)), abq, False),  # one exponent per batch element
         ("acttile_bout", (2, 6, 64), 64, 48, 16, False, dict(mxint_q, B_out_quantizer=bfp_cfg(8, [2, 16], True)), abq, False),  # only B_out tiled
+        # (round 6) the quantizer's DEFAULT block_size - a lone [16] with skip_first_dim = true - on a 3-D tensor: right-aligned it reads
+        # [1, T, 16], one exponent per batch element, ALL T token rows and 16 columns (utils.py:56-66, :211-237); on a 2-D tensor: per row
+        ("acttile_lone3d", (2, 20, 176), 176, 64, 16, True, dict(mxint_q, x_quantizer=bfp_cfg(8, [16], True)), abq, False),
+        ("acttile_lone2d", (9, 64), 64, 48, 16, False, dict(mxint_q, x_quantizer=bfp_cfg(8, [16], True)), abq, False),
+        # (round 6) the reference's weight-only sweep (experiments/pipeline/sweep_lqer_act_w-only.sh:74-77, the paper's "W3A16" row): 3-bit
+        # weights in blocks of [1, 32], pass-through activations / bias / A / B, rank 64
+        ("w3b32_a16_r64", (9, 256), 256, 96, 64, False, dict(a16_q, w_quantizer=bfp_cfg(3, [1, 32], False)), None, True),
+        ("w3b32_a16_r64_3d", (2, 5, 192), 192, 160, 64, True, dict(a16_q, w_quantizer=bfp_cfg(3, [1, 32], False)), None, False),
     ]
     f = {}
     for name, xs, K, N, r, has_b, qc, abc, use_s in cases:

@@ -174,7 +174,8 @@ def _module_from_case(g, cfgs, name, dtype=torch.float32):
 
 
 FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "ragged", "int128", "introw", "a16", "a16row", "a16mix", "tile8", "tileall",
-             "w8row", "w8g128", "w8b16", "w6b32"]  # (w8*: weights of 5..8 bits as three 4-bit limbs, round 5)
+             "w8row", "w8g128", "w8b16", "w6b32",  # (w8*: weights of 5..8 bits as three 4-bit limbs, round 5)
+             "w3b32_a16_r64", "w3b32_a16_r64_3d"]  # (round 6: the W3A16 weight-only sweep, sweep_lqer_act_w-only.sh:74-77)
 
 
 @pytest.mark.parametrize("name", FWD_CASES)
@@ -192,7 +193,8 @@ def test_forward_vs_reference_vectors(ops, golden_fwd, name):
         assert torch.equal(mod.bias.detach().cpu(), t("bq"))
 
 
-ACT_TILE_CASES = ["acttile3d", "acttile_ragged", "acttile2d", "acttile2d_all", "acttile_r_on_2d", "acttile_whole", "acttile_bout"]
+ACT_TILE_CASES = ["acttile3d", "acttile_ragged", "acttile2d", "acttile2d_all", "acttile_r_on_2d", "acttile_whole", "acttile_bout",
+                  "acttile_lone3d", "acttile_lone2d"]  # (round 6: the default block_size [16] - [1, T, 16] on a 3-D tensor, per row on a 2-D one)
 
 
 @pytest.mark.parametrize("name", ACT_TILE_CASES)

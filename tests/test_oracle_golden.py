@@ -79,7 +79,10 @@ def test_integer_quantizer(golden_q):
 FWD_CASES = ["m1", "m7", "m64", "b2s5", "r128", "int128", "introw", "ragged", "a16", "a16row", "a16mix", "intx", "intx70", "tile8", "tileall",
              "w8row", "w8g128", "w8b16", "w6b32",  # (w8*: weights of 5..8 bits, round 5)
              # activation blocks that span token rows (round 5): [R, L] tiles of 3-D tensors, 2-D tensors blocked like a weight
-             "acttile3d", "acttile_ragged", "acttile2d", "acttile2d_all", "acttile_r_on_2d", "acttile_whole", "acttile_bout"]
+             "acttile3d", "acttile_ragged", "acttile2d", "acttile2d_all", "acttile_r_on_2d", "acttile_whole", "acttile_bout",
+             # (round 6) the quantizer's default block_size [16] on a 3-D tensor (all token rows x 16 columns) and on a 2-D one (per row);
+             # the W3A16 weight-only sweep (sweep_lqer_act_w-only.sh:74-77): 3-bit weights in blocks of 32, pass-through activations, rank 64
+             "acttile_lone3d", "acttile_lone2d", "w3b32_a16_r64", "w3b32_a16_r64_3d"]
 
 
 @pytest.mark.parametrize("name", FWD_CASES)

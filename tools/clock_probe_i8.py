@@ -14,6 +14,7 @@ ap.add_argument("--K", type=int, default=5120)
 ap.add_argument("--N", type=int, default=5120)
 ap.add_argument("--r", type=int, default=64)
 ap.add_argument("--wblock", type=int, default=128)
+ap.add_argument("--slots", type=int, default=16, help="u64 stamps per wave the build writes (round-5 builds: 8)")
 ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0, help="lqer_linear_desc_t.tuning, e.g. 0x80000: the pre-pass with segment partials instead of the in-GEMM exchange")
 a = ap.parse_args()
 from lqer_amd import _lib
@@ -36,7 +37,8 @@ assert mod._x_i8
 L.lqer_gemm_tile_rows.argtypes = [C.c_void_p, C.c_int64, C.c_int]
 BMt = L.lqer_gemm_tile_rows(C.byref(mod._desc()), M, _lib.F16)  # 128- or 256-row tiles of the int8 kernel
 tiles = (-(-M // BMt)) * (-(-N // 256))
-buf = torch.zeros(tiles * 8 * 8, dtype=torch.int64, device=dev)
+S = a.slots
+buf = torch.zeros(tiles * 8 * S, dtype=torch.int64, device=dev)
 assert L.lqer_debug_set_i8_stamp_buffer(buf.data_ptr()) == 0
 desc = mod._desc()
 desc.tuning = a.tuning
@@ -58,7 +60,7 @@ e0.record()
 for _ in range(20): launch()
 e1.record(); torch.cuda.synchronize()
 nb = min(tiles, 256)  # persistent grid: one workgroup per CU, the stamps are those of its last tile
-b = buf.cpu().view(tiles, 8, 8)[:nb].double()
+b = buf.cpu().view(tiles, 8, S)[:nb].double()
 steps = -(-K // 128)
 cyc, rt = b[:, :, 0], b[:, :, 1]
 clk = (cyc / rt * 100e6).median().item()
@@ -66,10 +68,18 @@ med = lambda t: t.median().item()
 print(f"M={M} K={K} N={N} r={r} wblock={a.wblock} tuning={a.tuning:#x} tile rows {BMt}: call (pre-pass + GEMM) {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, {tiles} tiles = {tiles / 256:.2f} rounds")
 print(f"  main loop   {med(cyc):9.0f} cycles = {med(cyc) / steps:6.0f} per 128-k step ({BMt * 8} = MFMA-bound), {med(rt) / 100:7.2f} us; clock {clk / 1e9:.3f} GHz")
 print(f"  ring fill   {med(b[:, :, 2]):9.0f} cycles")
-pk = buf.cpu().view(tiles, 8, 8)[:nb, :, 3]
+pk = buf.cpu().view(tiles, 8, S)[:nb, :, 3]
 parts = [((pk >> (16 * i)) & 0xffff).double() for i in range(4)]
 for w in (0, 4):
     print(f"  wave {w}: issue of DMA + loads {parts[0][:, w].median().item():.0f}, conversion pass {parts[1][:, w].median().item():.0f}, "
           f"vmcnt(0) {parts[2][:, w].median().item():.0f}, barrier {parts[3][:, w].median().item():.0f} cycles")
 print(f"  epilogue    {med(b[:, :, 4]):9.0f} cycles, {med(b[:, :, 5]) / 100:7.2f} us")
 print(f"     of which staging + barrier {med(b[:, :, 6]):7.0f} cycles, math of the first two token tiles {med(b[:, :, 7]):7.0f} cycles")
+if S >= 16 and float(b[:, :, 8].max()) > 0:  # round 6: the exchange instantiation's prologue sections, cycles from the wave's start
+    for w in (0, 4):
+        print(f"  wave {w} prologue: first request out {med(b[:, w, 8]):.0f}, all requests out + tables {med(b[:, w, 9]):.0f}, row maxima computed "
+              f"{med(b[:, w, 10]):.0f}, reduced + published {med(b[:, w, 11]):.0f}, main loop starts {med(b[:, w, 2]):.0f}")
+    tr = b[:, :2, 12]
+    print(f"  gather polls (waves 0-1): median {tr.median().item():.0f}, max {tr.max().item():.0f}, workgroups that polled {(tr.max(dim=1)[0] > 0).sum().item()} of {nb}")
+    t0, t1 = b[:, 0, 13], b[:, 0, 14]
+    print(f"  workgroup start spread {(t0.max() - t0.min()).item() / 100:.2f} us, end spread {(t1.max() - t1.min()).item() / 100:.2f} us, first start to last end {(t1.max() - t0.min()).item() / 100:.2f} us")
