@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 11
+#define LQER_ABI_VERSION 12
 
 /* error codes */
 #define LQER_OK 0
@@ -128,6 +128,12 @@ typedef struct lqer_linear_desc {
                                          GEMM - its workgroups sum the partial tiles of x A for their own rows (lqer_tile_partials).
                                          Off by default: measured slower (C2: the GEMM grows by 5.3 us, the launch it saves took
                                          4.9 us - 16 partial tiles at K = 4096, summed in front of the main loop, whose accumulators it opens)           */
+#define LQER_TUNE_ACT8_SPLIT 0x200000 /* int8 route (LQER_Q_MXINT_I8), lqer_quantize_act_xa / lqer_linear_forward: quantizer, split-K side GEMM
+                                         and reduce as three launches even where the one-launch kernel applies (16-bit tensors, a_limbs =
+                                         -1, padded rank 16 / 32 / 64, M <= 4096): bit-identical int8 image and row scales, x A summed in
+                                         another order (A_out of it inside the summation-order envelope)                            */
+#define LQER_TUNE_ACT8_FUSED 0x400000 /* ... the one-launch kernel at every token count (default: M <= 4096 - every workgroup of 8 token
+                                         rows streams the whole A^T image)                                                          */
 #define LQER_TUNE_DECODE_NO_POLL 0x10000 /* one-launch decode route: no wait for the producers' tiles - every weight-streaming
                                          workgroup computes the partial tiles of x A itself (the bounded wait's fall-back)     */
 
@@ -357,7 +363,10 @@ int lqer_desc_limbs(const lqer_linear_desc_t* desc, int* act_limbs, int* xa_limb
 /* fp16 tensors have a faster exact route: x_fmt.kind = LQER_Q_PASSTHROUGH_F16.  The activation image is then the
  * fp16 tensor itself ([Mp][Kp], one copy of w_packed), the main loops expand the weights to fp16 and run the fp16 MFMA
  * (products exact, fp32 accumulation - the reference's F.linear on fp16 tensors), and the side GEMM reads A as ONE
- * fp16 image a_t = [rp][Kp] fp16 written by this call from the limb image of lqer_pack_lowrank.  Allowed only when
+ * fp16 image a_t = [rp][Kp] fp16 written by this call from the limb image of lqer_pack_lowrank - followed (ABI 12) by its
+ * FRAGMENT-MAJOR copy for the int8 route's one-launch activation kernel (per 32-k step and 16-rank tile 64 lanes x 8 halves, the B
+ * operand of v_mfma_f32_16x16x32_f16, over ceil(K / 128) * 128 columns): a_t_f16 must hold lqer_a_f16_image_bytes(K, r) bytes.
+ * Allowed only when
  * this call leaves flags[0] (a weight block scale outside the fp16 range 2^-24 .. 2^13) and flags[1] (an element of
  * A that is not an fp16 number) at zero (device int32[2]); otherwise use LQER_Q_PASSTHROUGH with width 11.
  * A_out / xaq / b_t are as for LQER_Q_PASSTHROUGH.  Calls take dtype = LQER_F16.  A dense tensor (ldx == K) with
@@ -365,6 +374,9 @@ int lqer_desc_limbs(const lqer_linear_desc_t* desc, int* act_limbs, int* xa_limb
  * then skips the copy, and the split API accepts xq == x in lqer_quantize_act_xa / lqer_linear_gemm. */
 int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t_limbs, int a_limbs, int64_t r,
                      void* a_t_f16, int32_t* flags, void* stream);
+/* bytes of the fp16 image of A^T that lqer_f16_prepare writes (the [rp][Kp] image every a_limbs = -1 consumer reads + its
+ * fragment-major copy); the reference has nothing to replace here - A is an fp16 nn.Parameter (quantized_layers/linear.py:142) */
+size_t lqer_a_f16_image_bytes(int64_t K, int64_t r);
 
 /* ---- weights of 5..8 bits (the reference's no-LQER baseline: W8A8 block_fp with one block per row and per token,
  * experiments/pipeline/sweep_baseline_no_lqer.sh:73-76, through LinearFlexible, quantized_layers/linear.py:50-64) ---------------

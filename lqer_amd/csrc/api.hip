@@ -524,6 +524,15 @@ static int quantize_act_xa_single(const lqer_linear_desc_t* d, const void* x, in
     if (!passthrough_width_ok(d->x_fmt, "x_quantizer")) return LQER_E_INVALID;
     rc = split_act_dispatch(x, dtype, M, d->in_features, ldx, act_limbs(d), (bf16_t*)xq, (hipStream_t)stream);
   } else if (x_is_i8(d)) {
+    // one launch for quantizer + x A + A_out where the fused kernel applies (act8_fused.hip: 16-bit tensor, fp16 image of A^T with
+    // its fragment-major copy, small token counts); else quantizer, split-K side GEMM and reduce as three launches
+    if (d->rank > 0 && a_t && xaq && a_limbs == -1) {
+      lqer_qfmt_t fx = d->x_fmt;
+      fx.kind = LQER_Q_MXINT, fx.block = -1;
+      rc = act8_fused_dispatch(x, dtype, M, d->in_features, ldx, make_qp(fx), xq, a_t, d->rank, make_qp(d->a_out_fmt), (bf16_t*)xaq,
+                               d->tuning, (hipStream_t)stream);
+      if (rc != LQER_E_UNSUPPORTED) return rc;
+    }
     rc = lqer_quantize_act_i8(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
   } else {
     rc = lqer_quantize_act_mxint(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
@@ -841,7 +850,13 @@ int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t
     set_error("f16_prepare: bad argument");
     return LQER_E_INVALID;
   }
-  return f16_prepare_dispatch(w_packed, N, K, a_t_limbs, a_limbs, r, a_t_f16, flags, (hipStream_t)stream);
+  const int rc = f16_prepare_dispatch(w_packed, N, K, a_t_limbs, a_limbs, r, a_t_f16, flags, (hipStream_t)stream);
+  if (rc || r <= 0) return rc;
+  return a_frag_dispatch(a_t_f16, K, r, (hipStream_t)stream);  // the fragment-major copy behind [rp][Kp] (lqer_a_f16_image_bytes)
+}
+
+size_t lqer_a_f16_image_bytes(int64_t K, int64_t r) {
+  return (K > 0 && r > 0) ? a_f16_image_bytes(K, r) : 0;
 }
 
 size_t lqer_matmul_q_workspace_bytes(int64_t batch, int64_t K, int64_t S2) {

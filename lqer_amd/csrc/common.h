@@ -414,6 +414,69 @@ __host__ inline size_t i8_weight8_image_bytes(int64_t N, int64_t K) {
 #define LQER_AMAX_NSEG 16  // column-segment partials per row of a one-block-per-row B_out (int8 route: k_bout_amax -> k_lqer_gemm_i8)
 #endif
 
+// ---- the int8 image of per-token activations: one row's 16-byte chunks of 8 sixteen-bit elements (k_quant_row8 in quantize.hip and
+// the fused int8-route activation kernel in act8_fused.hip share this arithmetic: same codes, same scales) ---------------------------
+// the largest |element| of the MAXCH chunks a lane holds (packed 16-bit maxima for fp16)
+template <int DT, int MAXCH>
+__device__ __forceinline__ float row8_amax(const u32x4 (&raw)[MAXCH]) {
+  float amax = 0.f;
+  if constexpr (DT == LQER_F16) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    h2 m = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m = __builtin_elementwise_max(m, __builtin_bit_cast(h2, raw[u][j] & 0x7fff7fffu));
+    amax = fmaxf((float)m[0], (float)m[1]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        amax = fmaxf(amax, fmaxf(__uint_as_float((raw[u][j] << 16) & 0x7fffffffu), __uint_as_float(raw[u][j] & 0x7fff0000u)));
+  }
+  return amax;
+}
+// one chunk -> its 8 int8 mantissas (live = false: zeros).  FAST: the packed signed arithmetic of mxint16_i8_fast with
+// s = 2^(mbits - e), es = 1e-9 s (needs mxint16_fast_ok(e, q)); else element by element through mxint_mantissa.
+template <int DT, bool FAST>
+__device__ __forceinline__ u32x2 row8_chunk(const u32x4 raw, bool live, int e, const QP& q, float s, float es) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  const float lo = -q.mneg, hi = q.mmax;
+  const f2 magic = {12582912.0f, 12582912.0f};
+  uint32_t h[4] = {0, 0, 0, 0};  // pairs of int16 mantissas
+  if (live) {
+    // (plain words first: indexing raw[j] with the unrolled j directly made hipcc reuse word 0 for all four pairs)
+    const uint32_t wd[4] = {raw[0], raw[1], raw[2], raw[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f2 xv;
+      if constexpr (DT == LQER_F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const h2 hv = __builtin_bit_cast(h2, wd[j]);
+        xv = (f2){(float)hv[0], (float)hv[1]};
+      } else {
+        xv = (f2){__uint_as_float(wd[j] << 16), __uint_as_float(wd[j] & 0xffff0000u)};
+      }
+      f2 r;
+      if constexpr (FAST) {
+        const f2 cc = {copysignf(es, xv[0]), copysignf(es, xv[1])};
+        r = (__builtin_elementwise_fma(xv, (f2){s, s}, cc) + magic) - magic;
+        r[0] = __builtin_amdgcn_fmed3f(r[0], lo, hi);
+        r[1] = __builtin_amdgcn_fmed3f(r[1], lo, hi);
+        if constexpr (DT != LQER_F16) {  // (fp16 cannot hold a non-zero |x| <= 1e-8)
+          r[0] = fabsf(xv[0]) <= 1e-8f ? 0.0f : r[0];
+          r[1] = fabsf(xv[1]) <= 1e-8f ? 0.0f : r[1];
+        }
+      } else {
+        r = (f2){mxint_mantissa(xv[0], e, q), mxint_mantissa(xv[1], e, q)};
+      }
+      h[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)r[0], (int)r[1]));
+    }
+  }
+  return (u32x2){__builtin_amdgcn_perm(h[1], h[0], 0x06040200u), __builtin_amdgcn_perm(h[3], h[2], 0x06040200u)};
+}
+
 // ---- cross-file declarations ----------------------------------------------------------------------
 struct QuantOut {
   float* deq;      // [rows, cols] or null
@@ -482,6 +545,14 @@ int bias_passthrough_dispatch(const void* b, int dtype, int64_t N, float* out, h
 int lowrank_xa_dispatch(const bf16_t* xq, int64_t M, int64_t K, int x_limbs, const bf16_t* a_t, int a_limbs, int64_t r,
                         const QP& q, int xa_limbs, bf16_t* xaq, float* scratch, size_t scratch_bytes, hipStream_t st);
 int copy_act_f16_dispatch(const void* x, int64_t M, int64_t K, int64_t ldx, bf16_t* xq, hipStream_t st);
+// the int8 route's activation side in one launch (act8_fused.hip); LQER_E_UNSUPPORTED = not its case
+#ifndef LQER_ACT8_FUSED_MAX_M
+#define LQER_ACT8_FUSED_MAX_M 4096
+#endif
+int act8_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, void* xq_i8, const void* a_f16, int64_t r,
+                        const QP& qa, bf16_t* xaq, int tuning, hipStream_t st);
+size_t a_f16_image_bytes(int64_t K, int64_t r);
+int a_frag_dispatch(void* a_f16, int64_t K, int64_t r, hipStream_t st);
 int f16_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, const void* a_limbs_img, int a_limbs, int64_t r, void* a_f16,
                          int32_t* flags, hipStream_t st);
 int split_act_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, int limbs, bf16_t* xq, hipStream_t st);

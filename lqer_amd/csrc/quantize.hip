@@ -200,22 +200,7 @@ __global__ __launch_bounds__(256) void k_quant_row8(const void* __restrict__ x, 
   u32x4 raw[MAXCH];
 #pragma unroll
   for (int u = 0; u < MAXCH; ++u) raw[u] = lane + 64 * u < nch ? p[lane + 64 * u] : (u32x4){0, 0, 0, 0};
-  float amax = 0.f;
-  if constexpr (DT == LQER_F16) {
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-    h2 m = {(_Float16)0.f, (_Float16)0.f};
-#pragma unroll
-    for (int u = 0; u < MAXCH; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m = __builtin_elementwise_max(m, __builtin_bit_cast(h2, raw[u][j] & 0x7fff7fffu));
-    amax = fmaxf((float)m[0], (float)m[1]);
-  } else {
-#pragma unroll
-    for (int u = 0; u < MAXCH; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        amax = fmaxf(amax, fmaxf(__uint_as_float((raw[u][j] << 16) & 0x7fffffffu), __uint_as_float(raw[u][j] & 0x7fff0000u)));
-  }
+  float amax = row8_amax<DT, MAXCH>(raw);
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
   const bool any = amax > 0.f;
@@ -224,46 +209,14 @@ __global__ __launch_bounds__(256) void k_quant_row8(const void* __restrict__ x, 
   int8_t* const dst = xq8 + row * cols_p8;
   const bool fast = mxint16_fast_ok(e, q);  // (wave-uniform)
   const float s = __uint_as_float((uint32_t)(127 + (fast ? q.mbits - e : 0)) << 23);
-  const float es = 1e-9f * s, lo = -q.mneg, hi = q.mmax;
-  const f2 magic = {12582912.0f, 12582912.0f};
+  const float es = 1e-9f * s;
   auto emit = [&](auto fast_c) {  // (two copies under ONE wave-uniform branch: as a select the slow arithmetic ran for every element)
     constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
     for (int u = 0; u < MAXCH; ++u) {
       const int c = lane + 64 * u;
       if (c >= nch_p) continue;
-      uint32_t h[4] = {0, 0, 0, 0};  // pairs of int16 mantissas
-      if (c < nch && any) {
-        // (plain words first: indexing raw[u][j] with the unrolled j directly made hipcc reuse word 0 for all four pairs)
-        const uint32_t wd[4] = {raw[u][0], raw[u][1], raw[u][2], raw[u][3]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f2 xv;
-          if constexpr (DT == LQER_F16) {
-            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-            const h2 hv = __builtin_bit_cast(h2, wd[j]);
-            xv = (f2){(float)hv[0], (float)hv[1]};
-          } else {
-            xv = (f2){__uint_as_float(wd[j] << 16), __uint_as_float(wd[j] & 0xffff0000u)};
-          }
-          f2 r;
-          if constexpr (FAST) {
-            const f2 cc = {copysignf(es, xv[0]), copysignf(es, xv[1])};
-            r = (__builtin_elementwise_fma(xv, (f2){s, s}, cc) + magic) - magic;
-            r[0] = __builtin_amdgcn_fmed3f(r[0], lo, hi);
-            r[1] = __builtin_amdgcn_fmed3f(r[1], lo, hi);
-            if constexpr (DT != LQER_F16) {  // (fp16 cannot hold a non-zero |x| <= 1e-8)
-              r[0] = fabsf(xv[0]) <= 1e-8f ? 0.0f : r[0];
-              r[1] = fabsf(xv[1]) <= 1e-8f ? 0.0f : r[1];
-            }
-          } else {
-            r = (f2){mxint_mantissa(xv[0], e, q), mxint_mantissa(xv[1], e, q)};
-          }
-          h[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16((int)r[0], (int)r[1]));
-        }
-      }
-      const u32x2 w = {__builtin_amdgcn_perm(h[1], h[0], 0x06040200u), __builtin_amdgcn_perm(h[3], h[2], 0x06040200u)};
-      *(u32x2*)(dst + (int64_t)c * 8) = w;
+      *(u32x2*)(dst + (int64_t)c * 8) = row8_chunk<DT, FAST>(raw[u], c < nch && any, e, q, s, es);
     }
   };
   if (fast)

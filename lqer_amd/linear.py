@@ -69,9 +69,9 @@ class _LinearBase(nn.Linear):
         self._setup_lqer(l_config)
         # activation quantizers whose blocks can span token rows ([R, L] tiles, skip_first_dim = false): the tile route below
         self._tiles = any(getattr(self._fmt.get(r), "act_tiles", None) is not None for r in ("x", "A_out", "B_out"))
-        # ... on EVERY tensor (skip_first_dim = false: a 2-D input is tiled like a weight); with skip_first_dim = true a 2-D input is
-        # blocked per row and runs the fused kernels, so such a module still has packed images to save and load
-        self._tiles_only = any(getattr(self._fmt.get(r), "act_tiles", (0, 0, True))[2] is False for r in ("x", "A_out", "B_out"))
+        # ... on EVERY tensor, unless the only such formats are the quantizer's default lone [L] with skip_first_dim = true: per-row blocks
+        # of L on a 2-D tensor - the fused kernels' layout -, [1, T, L] tiles on a 3-D one.  Such a module still has packed images.
+        self._tiles_only = any(not getattr(self._fmt.get(r), "act_tiles", (0, 0, True, True))[3] for r in ("x", "A_out", "B_out"))
         self.__dict__["_inner"] = None  # (the tile route's main-product Linear: not a registered submodule - it shares this module's parameters)
 
     # -- configuration -------------------------------------------------------------------------
@@ -130,9 +130,11 @@ class _LinearBase(nn.Linear):
                 p = dict(p)
                 p["w"] = w2
                 # unquantized fp16 A (two bf16 limbs): the side GEMM of the int8 route takes it as ONE fp16 image on the fp16
-                # MFMA (int8 mantissas are exact in fp16) - half the A^T bytes and MFMAs of the limb pair
-                if self.rank > 0 and int(p.get("a_limbs", 0)) == 2 and self.i8_a_f16:
-                    ok16, a16 = ops.a_f16_image(w2, self.out_features, K, p["a_t"], 2, self.rank)
+                # MFMA (int8 mantissas are exact in fp16) - half the A^T bytes and MFMAs of the limb pair.  Round 6: also an A of ONE
+                # bf16 limb that fp16 holds exactly (bf16 modules, 8-bit block_fp A): the image carries the fragment-major copy that the
+                # one-launch activation kernel reads (act8_fused.hip)
+                if self.rank > 0 and int(p.get("a_limbs", 0)) in (1, 2) and self.i8_a_f16:
+                    ok16, a16 = ops.a_f16_image(w2, self.out_features, K, p["a_t"], int(p["a_limbs"]), self.rank)
                     if ok16:
                         p["a_t_f16"] = a16
         if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native
@@ -450,10 +452,10 @@ class _LinearBase(nn.Linear):
 
     def _needs_tiles(self, x: torch.Tensor) -> bool:
         """Some activation format of this module MAY span token rows (`_tiles`): does it for THIS tensor?  The reference reads
-        block_size against the tensor's rank at call time (quantizers/utils.py:261-284): [R, L] / a lone [L] with skip_first_dim = true
-        are per-row blocks on a 2-D tensor, and tiles of one token row (T = 1, R = 1) are per-row blocks as well - those calls keep the
-        fused kernels.  Whatever the reference raises for the rank is raised by the tile route."""
-        if x.dim() < 2 or x.dim() > 3:
+        block_size against the tensor's rank at call time (quantizers/utils.py:261-284): a lone [L] with skip_first_dim = true means
+        per-row blocks of L on a 2-D tensor and on a 3-D tensor with ONE token row (T = 1: decode steps) - those calls keep the fused
+        kernels -, [1, T, L] tiles otherwise.  Every other tiled format stays on the tile route whatever the tensor."""
+        if self._tiles_only or x.dim() < 2 or x.dim() > 3:
             return True
         f = self._fmt
         try:

@@ -103,7 +103,8 @@ def make_qfmt(cfg: Optional[dict], role: str = "x") -> QFmt:
             # format too: right-aligned to a [batch, tokens, features] tensor it reads [1, T, L], one exponent for ALL token rows x L
             # columns of a batch element (_infer_block_shape prepends -1, utils.py:56-66; _block_3d_activation :211-237); on a 2-D
             # tensor the same entry means per-row blocks of L and runs the fused kernels (the module decides per call).
-            act_tiles = (int(bs[-2]) if len(bs) >= 2 else -1, int(bs[-1]), skip)
+            # (4th entry: the format is that lone [L] - the only tiled format whose 2-D reading the fused kernels serve)
+            act_tiles = (int(bs[-2]) if len(bs) >= 2 else -1, int(bs[-1]), skip, skip and len(bs) == 1)
         elif any(b != 1 for b in bs[:-1]):
             raise NotImplementedError(f"block_size {bs}: only blocks along the last dim are implemented on the HIP path for '{role}'")
     ew = int(cfg.get("exponent_width", 8))
@@ -133,7 +134,7 @@ def act_tile_shape(fmt: QFmt, ndim: int):
     t = getattr(fmt, "act_tiles", None)
     if t is None:
         return 1, int(fmt.block)
-    R, L, skip = t
+    R, L, skip = t[:3]
     if ndim == 2:
         return (1, L) if skip else (R, L)  # utils.py:127-144 infers the block against ONE row; :161-183 tiles the matrix
     if ndim == 3:
@@ -273,7 +274,7 @@ def f16_prepare(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: Optional[torc
     L = _lib.lib()
     dev = w_packed.device
     flags = torch.zeros(2, dtype=torch.int32, device=dev)
-    a16 = torch.empty(L.lqer_padded_r(r) * L.lqer_padded_k(K), dtype=torch.float16, device=dev) if r > 0 else None
+    a16 = torch.empty(L.lqer_a_f16_image_bytes(K, r) // 2, dtype=torch.float16, device=dev) if r > 0 else None  # ([rp][Kp] + fragment-major copy)
     check(L.lqer_f16_prepare(w_packed.data_ptr(), N, K, _ptr(a_t_limbs), a_limbs, r, _ptr(a16), flags.data_ptr(), _stream(dev)), "lqer_f16_prepare")
     fl = flags.tolist()
     return (fl[0] == 0 and fl[1] == 0), a16
@@ -287,7 +288,7 @@ def a_f16_image(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: torch.Tensor,
     L = _lib.lib()
     dev = w_packed.device
     flags = torch.zeros(2, dtype=torch.int32, device=dev)
-    a16 = torch.empty(L.lqer_padded_r(r) * L.lqer_padded_k(K), dtype=torch.float16, device=dev)
+    a16 = torch.empty(L.lqer_a_f16_image_bytes(K, r) // 2, dtype=torch.float16, device=dev)  # ([rp][Kp] + its fragment-major copy)
     check(L.lqer_f16_prepare(w_packed.data_ptr(), N, K, a_t_limbs.data_ptr(), a_limbs, r, a16.data_ptr(), flags.data_ptr(), _stream(dev)),
           "lqer_f16_prepare")
     return flags.tolist()[1] == 0, a16

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--lib", default=None, help="path of another build of liblqer_hip.so")
     ap.add_argument("--amax", action="store_true", help="with --rows: 128-row tiles with segment-partial row maxima against atomicMax cells + memset")
     ap.add_argument("--rows", action="store_true", help="compare the int8 kernel's 128-row and 256-row tiles (pinned) and the bf16 route")
+    ap.add_argument("--split", action="store_true", help="(round 6) also the int8 route with its activation side pinned to the three launches (LQER_TUNE_ACT8_SPLIT)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     M, K, N, r = a.M, a.K, a.N, a.r
@@ -49,6 +50,10 @@ def main():
     Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
     routes = {}
     variants = [("int8", mod._desc()), ("bf16", mod._desc(plain=True))]
+    if a.split:
+        d3 = mod._desc()
+        d3.tuning = _lib.TUNE_ACT8_SPLIT
+        variants = [("int8", mod._desc()), ("i8-3l", d3)]
     if a.rows:  # the int8 kernel's two tile heights, pinned (same bits)
         d128, d256 = mod._desc(), mod._desc()
         d128.tuning, d256.tuning = _lib.TUNE_I8_ROWS_128, _lib.TUNE_I8_ROWS_256
@@ -73,7 +78,10 @@ def main():
         routes[name] = dict(desc=desc, ws=ws, xq=xq, xaq=xaq, scr=scr, nscr=nscr, gscr=gscr, route=L.lqer_gemm_route(C.byref(desc), M, _lib.F16))
 
     def quant(rt):
-        _lib.check(L.lqer_quantize_act_xa(C.byref(rt["desc"]), xd.data_ptr(), _lib.F16, M, K, p["a_t"].data_ptr(), p["a_limbs"], rt["xq"],
+        # (the int8 route's side GEMM takes A^T as ONE fp16 image, a_limbs = -1 - what the module passes at these token counts)
+        i8 = rt["route"] == 3 and "a_t_f16" in p
+        _lib.check(L.lqer_quantize_act_xa(C.byref(rt["desc"]), xd.data_ptr(), _lib.F16, M, K, (p["a_t_f16"] if i8 else p["a_t"]).data_ptr(),
+                                          -1 if i8 else p["a_limbs"], rt["xq"],
                                           rt["xaq"], rt["scr"], rt["nscr"], st), "quantize_act_xa")
 
     def gemm(rt):
