@@ -65,7 +65,7 @@ from benchlib.cpu_baseline import cpu_baseline  # noqa: E402,F401
 from benchlib.hipevents import HipEvent  # noqa: E402,F401
 from benchlib.launcher import dry_run_cpu, launch_ranks  # noqa: E402
 from benchlib.workloads import (A16_Q, BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, INT8_MFMA_PEAK_TOPS, INT_Q, INTROW_Q,  # noqa: E402,F401
-                                LLAMA13B, MXINT_Q, OPT_Q, UNQUANTIZED_AB, W8A8_Q, WORKLOADS, _bfp, _snap_mxint8_dim0, check_rows, flops,
+                                LLAMA13B, MXINT_Q, OPT_Q, UNQUANTIZED_AB, W3A16_Q, W8A8_Q, WORKLOADS, _bfp, _snap_mxint8_dim0, check_rows, flops,
                                 make_case, make_weights, make_x)
 
 # every other BASELINE configuration, carried by the default line: (workload, steps, warm-up steps, decoder layers: 0 = the whole
@@ -133,6 +133,7 @@ def config_layers(ctx, args):
                          "peak": rl["peak"], "achieved": rl["achieved"], "roofline_unit": rl["unit"],
                          "avg_launch_us": rl["avg_launch_us"], "launches": rl["launches"], "per_shape": rl["per_shape"],
                          "sustained_mhz": rl.get("sustained_mhz"), "frac_at_sustained_clock": rl.get("frac_at_sustained_clock"),
+                         "inside_load": rl.get("inside_load"),
                          "layers": rec["config"]["layers_per_rank"][0], "weights": rec["config"]["weights"],
                          "parity_rel_l2": rec["parity_rel_l2"], "parity_rows": rec["parity_rows"]}
         except (Exception, SystemExit) as e:  # noqa: BLE001

@@ -28,7 +28,10 @@ W8A8_Q = dict(INT_Q, w_quantizer=_bfp(8, [1, -1], False))
 # the INT templates as shipped (llama-7b-int.toml q_config.linear): pass-through fp16 activations ("W4A16"), A_out and
 # B_out falling back to the same pass-through (linear.py:115-124), A/B unquantized
 A16_Q = dict(INT_Q, x_quantizer=dict(name="passthrough", width=16, frac_width=12))
-UNQUANTIZED_AB = (INT_Q, INTROW_Q, A16_Q, W8A8_Q)
+# the reference's weight-only sweep (experiments/pipeline/sweep_lqer_act_w-only.sh:74-77, the paper's "W3A16" row): 3-bit weights in
+# blocks of [1, 32], pass-through activations / bias, A / B unquantized, rank 64
+W3A16_Q = dict(A16_Q, w_quantizer=_bfp(3, [1, 32], False))
+UNQUANTIZED_AB = (INT_Q, INTROW_Q, A16_Q, W8A8_Q, W3A16_Q)
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 INT8_MFMA_PEAK_TOPS = 5000.0    # 2x bf16 per clock (same guide, "Matrix cores", I8 row)
@@ -64,6 +67,9 @@ WORKLOADS = {
            [(4096, 4096, 4), (4096, 16384, 1), (16384, 4096, 1)], 32),
     "c4a16": ("Llama-13B 7 projections x 40 layers rank64 W4(block128)A16 (the reference's INT template as shipped) M=16384",
               16384, 64, False, A16_Q, LLAMA13B, 40),
+    # (round 6, VERDICT r5 missing 3) the W3A16 weight-only sweep at the Llama-7B shapes: fp16 MFMA main loop over 3-bit codes
+    "c3w3a16": ("Llama-7B 7 projections x 32 layers rank64 W3(block32)A16 M=2048 (sweep_lqer_act_w-only.sh:74-77)", 2048, 64, False,
+                W3A16_Q, LLAMA7B, 32),
     "d1a16": ("LqerLinear 4096x4096 rank32 W4(block128)A16 M=1 (decode)", 1, 32, False, A16_Q, [(4096, 4096, 1)], 1),
     # decode sizes (HBM-bound on the packed weight; roofline quoted in GB/s): the small-M kernel
     "d1": ("LqerLinear 4096x4096 rank32 W4A8-MXINT16 M=1 (decode)", 1, 32, False, MXINT_Q, [(4096, 4096, 1)], 1),

@@ -414,7 +414,9 @@ size_t lqer_a_f16_image_bytes(int64_t K, int64_t r);
  *    themselves - per (256-row tile, 64-k half-step) 256 rows x 64 B, then one scale per row - and the main loop is LDS-DMA, one
  *    16-byte LDS read per weight fragment and the MFMA: no expand.  It needs ONE exponent per weight row (block_size [1,-1], or
  *    coarser blocks whose exponents happen to agree): lqer_i8_prepare sets flags[0] otherwise, and such a weight keeps the limb
- *    route (exact, three times the work).  256-row tiles only (lqer_gemm_tile_rows). */
+ *    route (exact, three times the work).  128- or 256-row tiles (lqer_gemm_tile_rows says which): on 128-row tiles a wave's codes go
+ *    straight from this image into registers (four coalesced 16-byte loads per lane and step, no LDS), on 256-row tiles through a
+ *    half-step LDS ring. */
 int lqer_i8_prepare(void* w_packed, int64_t N, int64_t K, const lqer_qfmt_t* w_fmt, int32_t* flags, void* stream);
 /* Test hooks: the int8 weight image (inside w_packed) -> dequantized fp32 [N,K]; x [M,K] -> the int8 activation image. */
 int lqer_unpack_weight_i8(const void* w_packed, int64_t N, int64_t K, float* w_f32, void* stream);

@@ -85,7 +85,10 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
         f[i][t] = s_begin < s_end ? fr[((int64_t)s * RT + t) * 64] : (u32x4){0, 0, 0, 0};
       }
   };
+  // (rows of up to 6144 elements: the registers also hold the SECOND batch from the start - at K = 4096 that is all of a wave's A^T)
+  constexpr bool TWO = MAXCH <= 8 || (MAXCH <= 12 && DT == LQER_F16);  // (bf16 rows of 12 chunks: the wider conversion would spill)
   load_batch(fa, s_begin);
+  if constexpr (TWO) load_batch(fb, s_begin + SB);
 
   // ---- phase 1: the row -> int8 image + LDS slab (k_quant_row8's arithmetic)
   float amax = row8_amax<DT, MAXCH>(raw);
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
     }
   };
   for (int s0 = s_begin; s0 < s_end; s0 += 2 * SB) {
-    if (s0 + SB < s_end) load_batch(fb, s0 + SB);
+    if (!(TWO && s0 == s_begin) && s0 + SB < s_end) load_batch(fb, s0 + SB);
     compute_batch(fa, s0);
     if (s0 + 2 * SB < s_end) load_batch(fa, s0 + 2 * SB);
     if (s0 + SB < s_end) compute_batch(fb, s0 + SB);

@@ -70,7 +70,10 @@ struct Geo {
   // XCH instantiation: the tile's one panel of xAq lives behind the tables from the prologue on (requested right behind the first ring
   // step, read by the epilogue's side product - nothing is staged after the main loop)
   static constexpr int EP_XAQ = KERNEL_LDS;
-  static constexpr int KERNEL_LDS_XCH = KERNEL_LDS + PANEL;
+  // ... and the 4 KiB of gathered granules (32 row quads x 16 column tiles x {bytes, tag}), outside the ring: the gather is requested
+  // from INSIDE the main loop, in the request slots of the first step past the end of K (step4)
+  static constexpr int EP_GATHER = EP_XAQ + PANEL;
+  static constexpr int KERNEL_LDS_XCH = EP_GATHER + 4096;
   static_assert(KERNEL_LDS_XCH <= 160 * 1024 || NT == 8, "LDS of the exchange instantiation");
   // one panel of xAq: the epilogue lives in ring slots 1.. (stage: activation slot 1; output transposes: the activation slots
   // behind it, waves 6 and 7 in weight slot 2), so that slot 0 can take the next tile's first step meanwhile
@@ -93,7 +96,11 @@ extern "C" __device__ unsigned long long lqer_dispatch_id() __asm("llvm.amdgcn.d
 #define LQER_XCH_GATHER_AUX 1
 #endif
 constexpr int XCH_GATHER_AUX = LQER_XCH_GATHER_AUX;
-constexpr int XCH_SWEEPS = 64;  // polls of a missing granule (~1 us each) before the workgroup computes the band's maxima itself
+// polls of a missing granule (s_sleep 8 + an agent-scope re-read: ~1.5 us each) before the workgroup computes the band's maxima itself.
+// Round 6: 6 instead of 64 - every workgroup publishes in its prologue and gathers ~25 us later, so a granule that is still missing
+// belongs to a workgroup that is not resident (another stream holds its CU): waiting longer than the fall-back costs (the band's side
+// products: tiles_n x 16 MFMAs, a few us) buys nothing, and every late tile paid the full bound
+constexpr int XCH_SWEEPS = 6;
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -368,6 +375,14 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   I8_STAMP(cp_c[0], cp_r[0]);
 #endif
 
+  if constexpr (XCH) {
+    // every kernel argument the prologue and the epilogue read, asked for in ONE batch of scalar loads (an empty asm that names them all:
+    // they must be in registers here, so the loads go out together and are awaited once) - left to itself hipcc requested them where
+    // first used, five dependent scalar round trips in front of the first ring request
+    asm volatile("" ::"s"(g.xq), "s"(g.w8), "s"(g.xaq), "s"(g.bt), "s"(g.bias), "s"(g.xscale), "s"(g.bout_amax), "s"(g.y), "s"(g.ldy), "s"(g.M),
+                 "s"(g.N), "s"(g.Np), "s"(g.Kp), "s"(g.rp), "s"(g.b_limbs), "s"(g.xaq_ld), "s"(g.tiles_m), "s"(g.tiles_n), "s"(g.xch_nonce),
+                 "s"(g.tuning), "s"(g.bout.mbits), "s"(g.bout.emin), "s"(g.bout.emax));
+  }
   const int nt = g.tiles_m * g.tiles_n;
   // XCD-aware tile order of a virtual block id (blocks b, b + 8, ... share an XCD; the grid is a multiple of 8 or covers nt)
   auto tile_of = [&](int b) {
@@ -603,13 +618,21 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int ks = 0; ks < NSL; ++ks) asm volatile("" : "+v"(pxf[u][ks]));
+      // (the four row groups' chains of NL x NSL dependent MFMAs run interleaved - each accumulator keeps k_bout_amax's order, limb-major,
+      // slices ascending -: one chain after the other left the matrix pipe waiting out every MFMA's latency, ~1,300 cycles in front of
+      // the main loop)
+      f32x16 acc4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc4[u] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int ks = 0; ks < NSL; ++ks)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc4[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sbx[l * NSL + ks], pxf[u][ks], acc4[u], 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-          for (int ks = 0; ks < NSL; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sbx[l * NSL + ks], pxf[u][ks], acc, 0, 0, 0);
+        const f32x16 acc = acc4[u];
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[k])), fabsf(acc[k + 1]));
@@ -654,6 +677,24 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // the side product's fragments, column scale and bias) - loads return in issue order, so the counted waits below, which leave only the
   // TAIL's requests in flight, cover it.  TAIL: the steps behind the first (past the end of K: dropped by the buffer range check) and the
   // tables' LDS writes.
+  // The gather of the epilogue, requested EARLY (round 6): the main loop's last three LOADs request steps past the end of K - dead
+  // requests that only keep the counted waits uniform.  In the FIRST of them (step nk) waves 0 and 1 send their two activation pieces'
+  // requests to the granules instead: same instruction, same count, other descriptor / offset / LDS address - the agent-scope round trip
+  // (~3.9 k cycles, which waves 0-1 used to wait out behind the conversion pass with the other six at the barrier) passes under the last
+  // three steps.  By then (K >= 2048: > 15 steps = 10 us after the prologue's publish) every resident workgroup has published; shorter K
+  // keep the request at the epilogue.
+#ifndef LQER_XCH_EARLY_GATHER
+#define LQER_XCH_EARLY_GATHER 0  // 1: the form above (measured, round 6: the epilogue gains nothing - what waves 0-1 spend behind the
+                                   // conversion pass is the tag test's instructions, not the round trip - and the operand selects cost the
+                                   // main loop 5-6 %: 24.7 vs 23.4 us at K = 4096, profiles/r06_i8_timeline.txt); 0: requested at the epilogue
+#endif
+  const bool xg_early = LQER_XCH_EARLY_GATHER && XCH && !W8 && nk >= 16;  // (uniform)
+  const u32x4 xg_rs = make_rs((const uint8_t*)g.bout_amax, XCH ? (uint32_t)(xch_Mp / 4 * LQER_AMAX_NSEG * 8) : 0u);
+  int xg_voff[2] = {0, 0};
+  if constexpr (XCH) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xg_voff[j] = (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16;
+  }
   auto ring_fill_head = [&]() {
     using std::integral_constant;
     if constexpr (W8D) {
@@ -1076,9 +1117,19 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       __builtin_amdgcn_sched_barrier(0);
     }
     const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
-    const int a_soff = ktn * I8_BK, w_soff = ktn * I8_WBLOCK;
-    const uint32_t m0a0 = m0_a + slot_new * A_SLOT, m0a1 = m0a0 + 1024;
+    int a_soff = ktn * I8_BK;
+    const int w_soff = ktn * I8_WBLOCK;
+    uint32_t m0a0 = m0_a + slot_new * A_SLOT, m0a1 = m0a0 + 1024;
     const uint32_t m0w0 = m0_w + slot_new * W_SLOT, m0w1 = m0w0 + 1024, m0s = m0_s + slot_new * W_SLOT;
+    u32x4 ars_e = a_rs;
+    int av0_e = a_voff[0], av1_e = a_voff[1];
+    if constexpr (XCH && !W8) {
+      if (xg_early && ktn == nk && wave < 2) {  // (uniform) the step past the end of K: the granules instead of nothing
+        ars_e = xg_rs, a_soff = 0;
+        m0a0 = lds0 + G::EP_GATHER + wave * 2048, m0a1 = m0a0 + 1024;
+        av0_e = xg_voff[0], av1_e = xg_voff[1];
+      }
+    }
     i32x4 xa[4][4];  // [token tile][slice]
     u32x4 wr0, wr1;
     asm volatile(
@@ -1092,6 +1143,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
         "ds_read_b128 %[x32], %[fa2] offset:%c[aimm]+12288\n\tds_read_b128 %[x33], %[fa3] offset:%c[aimm]+12288\n\t"
         "ds_read_b128 %[wr0], %[fwa] offset:%c[wimm]\n\tds_read_b128 %[wr1], %[fwb] offset:%c[wimm]\n\t"
         "ds_read_u8 %[sv], %[fs] offset:%c[wimm]\n\t"
+        // (no cache-policy bits on these two even when they carry the gather: the CU's L1 is invalidated at the launch's start and nobody
+        // on this CU has read the granule lines since; sc0 on every activation piece cost the main loop 17 %)
         "s_mov_b32 m0, %[m0a0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av0], %[ars], %[asoff] offen lds\n\t"
         "s_mov_b32 m0, %[m0a1]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[av1], %[ars], %[asoff] offen lds\n\t"
         "s_mov_b32 m0, %[m0w0]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[wv0], %[wrs], %[wsoff] offen lds\n\t"
@@ -1104,8 +1157,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
           [x22] "=&v"(xa[2][2]), [x23] "=&v"(xa[2][3]), [x30] "=&v"(xa[3][0]), [x31] "=&v"(xa[3][1]), [x32] "=&v"(xa[3][2]),
           [x33] "=&v"(xa[3][3]), [wr0] "=&v"(wr0), [wr1] "=&v"(wr1), [sv] "=&v"(sv)
         : [fa0] "v"(fa_lo[0]), [fa1] "v"(fa_lo[1]), [fa2] "v"(fa_lo[2]), [fa3] "v"(fa_lo[3]), [aimm] "i"(A_IMM), [fwa] "v"(fw_a),
-          [fwb] "v"(fw_b), [fs] "v"(fs_addr), [wimm] "i"(SLOT * W_SLOT), [av0] "v"(a_voff[0]), [av1] "v"(a_voff[1]),
-          [wv0] "v"(w_voff0), [wv1] "v"(w_voff1), [sv4] "v"(s_voff), [ars] "s"(a_rs), [wrs] "s"(w_rs), [m0a0] "s"(m0a0),
+          [fwb] "v"(fw_b), [fs] "v"(fs_addr), [wimm] "i"(SLOT * W_SLOT), [av0] "v"(av0_e), [av1] "v"(av1_e),
+          [wv0] "v"(w_voff0), [wv1] "v"(w_voff1), [sv4] "v"(s_voff), [ars] "s"(ars_e), [wrs] "s"(w_rs), [m0a0] "s"(m0a0),
           [m0a1] "s"(m0a1), [m0w0] "s"(m0w0), [m0w1] "s"(m0w1), [m0s] "s"(m0s), [asoff] "s"(a_soff), [wsoff] "s"(w_soff),
           [wave] "s"(wave)
         : "memory", "scc");
@@ -1413,10 +1466,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // (vmcnt, no barrier).  The round trip passes under the staging and the conversion.
   const int tid_e = wave * 64 + lane;
   if constexpr (XCH_OK) {
-    if (xch && wave < 2) {
+    if (xch && wave < 2 && !xg_early) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + OFF_A + 3 * A_SLOT + wave * 2048 + j * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + G::EP_GATHER + wave * 2048 + j * 1024), 16,
                                                  (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16, 0, 0,
                                                  XCH_GATHER_AUX);
     }
@@ -1515,7 +1568,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     if (xch && wave < 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's requests: the granules - and the xAq pieces, awaited below anyway)
       const int qw = lane >> 2;  // this row's quad within the wave's 16
-      const uint32_t ga = lds0 + OFF_A + 3 * A_SLOT + wave * 2048 + (qw >> 3) * 1024 + (qw & 7) * 128;
+      const uint32_t ga = lds0 + G::EP_GATHER + wave * 2048 + (qw >> 3) * 1024 + (qw & 7) * 128;
       u32x4 gq[LQER_AMAX_NSEG / 2];  // piece p: {bytes, tag} of column tiles 2 p and 2 p + 1
       asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
                    "ds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\tds_read_b128 %6, %8 offset:96\n\t"
@@ -1526,32 +1579,42 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       const int ntile = g.tiles_n;  // (granules of column tiles that do not exist are never looked at)
       const int goff = (int)(((m0 >> 2) + 16 * wave + qw) * (LQER_AMAX_NSEG * 8));
       bool ok = !(g.tuning & LQER_TUNE_AMAX_XCH_MISS);  // (test knob: take the fall-back)
-      for (int tries = 0; ok; ++tries) {
-        bool all = true;
+      // Round 6: the tag test is BRANCH-FREE (one xor / and / or per granule under wave-uniform masks) and the poll loop sits behind one
+      // wave-uniform ballot - the short-circuit form compiled to a chain of exec-mask branches that cost waves 0-1 (and, at the barrier
+      // below, everybody) ~2,000 cycles per tile with every granule present.
+      auto stale = [&]() {
+        uint32_t bad = 0;
 #pragma unroll
-        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
-          all = all && (2 * j >= ntile || gq[j][1] == xtag) && (2 * j + 1 >= ntile || gq[j][3] == xtag);
-        if (all) break;
-#ifdef LQER_CLOCKPROBE
-        cp_tries = (unsigned long long)(tries + 1);
-#endif
-        if (tries == XCH_SWEEPS) {
-          ok = false;
-          break;
+        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j) {
+          const uint32_t v0 = 2 * j < ntile ? ~0u : 0u, v1 = 2 * j + 1 < ntile ? ~0u : 0u;  // (uniform)
+          bad |= ((gq[j][1] ^ xtag) & v0) | ((gq[j][3] ^ xtag) & v1);
         }
-        __builtin_amdgcn_s_sleep(8);
+        return bad;
+      };
+      uint32_t bad = stale();
+      if (ok && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {  // (rare: some granule of this wave's 64 rows is not there yet)
+        for (int tries = 0; tries < XCH_SWEEPS && __builtin_amdgcn_ballot_w64(bad != 0) != 0; ++tries) {
+#ifdef LQER_CLOCKPROBE
+          cp_tries = (unsigned long long)(tries + 1);
+#endif
+          __builtin_amdgcn_s_sleep(8);
+          if (bad != 0) {
 #pragma unroll
-        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
-          if ((2 * j < ntile && gq[j][1] != xtag) || (2 * j + 1 < ntile && gq[j][3] != xtag))
-            gq[j] = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc, goff + j * 16, 0, 16);  // sc1
+            for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
+              if ((2 * j < ntile && gq[j][1] != xtag) || (2 * j + 1 < ntile && gq[j][3] != xtag))
+                gq[j] = __builtin_amdgcn_raw_buffer_load_b128(xch_rsrc, goff + j * 16, 0, 16);  // sc1
+          }
+          bad = stale();
+        }
+        ok = bad == 0;
       }
       if (ok) {
         const int sh = 8 * (lane & 3);
         uint32_t eb = 0;  // (exponent bytes are >= 0: e - emin)
 #pragma unroll
-        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j) {
-          if (2 * j < ntile) eb = max(eb, (gq[j][0] >> sh) & 0xffu);
-          if (2 * j + 1 < ntile) eb = max(eb, (gq[j][2] >> sh) & 0xffu);
+        for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j) {  // (uniform masks again: no branches)
+          const uint32_t v0 = 2 * j < ntile ? 0xffu : 0u, v1 = 2 * j + 1 < ntile ? 0xffu : 0u;
+          eb = max(eb, max((gq[j][0] >> sh) & v0, (gq[j][2] >> sh) & v1));
         }
         xch_tables((int)eb + g.bout.emin);
       } else {

@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256) void k_w_pack8(const void* __restrict__ W, int
     int e = 0;
     if (row < N && k0 < K) {
       const int es = scratch[row * nblk + k0 / L];
-      if (es != -128) {
+      // (a block whose lowest limb's exponent byte e - mbits + 127 would leave [1, 254] keeps all-zero digits: the three limbs' clamped
+      // bytes would no longer stand 2^3 apart.  Nothing is lost: such a block has e <= mbits - 127, every |w| <= 2^e < 1e-8 - the
+      // range packed images flush to 0 anyway (mxint_mantissa's `tiny`); the upper end cannot clamp, e <= 128)
+      if (es != -128 && es - q.mbits + 127 >= 1) {
         e = es;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

@@ -392,13 +392,17 @@ template <int DT>
 static int launch_tiles(const void* x, int64_t batches, int64_t rows, int64_t cols, int64_t R, int64_t L, const QP& q, float* out,
                         float* amax, hipStream_t st) {
   const int64_t tr = (rows + R - 1) / R, tc = (cols + L - 1) / L;
-  (void)hipMemsetAsync(amax, 0, (size_t)(batches * tr * tc) * sizeof(float), st);
+  if (hipMemsetAsync(amax, 0, (size_t)(batches * tr * tc) * sizeof(float), st) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("quantize_mxint_tiles: zero fill of the tile maxima failed");
+    return LQER_E_LAUNCH;
+  }
   const int64_t segs = batches * rows * tc, total = batches * rows * cols;
   const unsigned g1 = (unsigned)((segs + 3) / 4 < 65536 ? (segs + 3) / 4 : 65536);
   const unsigned g2 = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   k_tile_amax<DT><<<g1, 256, 0, st>>>(x, batches, rows, cols, R, L, tr, tc, (unsigned int*)amax);
   k_tile_quant<DT><<<g2, 256, 0, st>>>(x, batches, rows, cols, R, L, tr, tc, amax, q, out);
-  return LQER_OK;
+  return check_launch("quantize_mxint_tiles");
 }
 
 int quantize_tiles_dispatch(const void* x, int dtype, int64_t batches, int64_t rows, int64_t cols, int64_t R, int64_t L, const QP& q,

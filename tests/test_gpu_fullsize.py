@@ -120,3 +120,14 @@ def test_c4_a16_template_full_size(lq):
 
     mod, _ = _run(lq, 16384, 5120, 5120, 64, A16_Q, False, False, seed=43)
     assert mod._x_f16
+
+
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (11008, 4096)])
+def test_w3a16_weight_only_sweep_full_size(lq, K, N):
+    """The reference's weight-only sweep (experiments/pipeline/sweep_lqer_act_w-only.sh:74-77, the paper's "W3A16" row): 3-bit weights in
+    blocks of [1, 32], pass-through fp16 activations, rank 64, at the Llama-7B shapes of the bench's c3w3a16 workload - the fp16 MFMA main
+    loop over 3-bit codes (round 6; pinned at small sizes by the reference-generated `w3b32_a16_r64` vectors)."""
+    from bench import W3A16_Q
+
+    mod, _ = _run(lq, 2048, K, N, 64, W3A16_Q, False, False, seed=71)
+    assert mod._x_f16

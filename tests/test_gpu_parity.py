@@ -119,6 +119,26 @@ def test_pack_unpack_weight_bit_exact(ops, golden_q):
             assert torch.equal(packed.cpu(), want), name
 
 
+def test_pack_unpack_8bit_weight_with_tiny_rows(ops):
+    """An 8-bit weight travels as three 4-bit limbs whose exponent bytes stand 2^3 apart (pack.hip k_w_pack8).  Rows of |w| < 2^-120 sit
+    where the lowest limb's byte would clamp: their blocks pack as zeros - the declared |w| <= 1e-8 flush of packed images - and the
+    other rows read back as the oracle's quantizer, bit for bit (round 6)."""
+    from oracle import lqer_oracle as O
+
+    g = torch.Generator().manual_seed(5)
+    W = 0.02 * torch.randn(48, 256, generator=g)
+    W[3] = torch.randn(256, generator=g) * 2.0 ** -124
+    W[7, :64] = torch.randn(64, generator=g) * 2.0 ** -121
+    W[9] = 0.0
+    for block in (16, 64, -1):
+        cfg = dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[1, block], skip_first_dim=False)
+        fmt = ops.make_qfmt(cfg, "w")
+        w = ops.unpack_weight(ops.pack_weight(W.to(DEV), fmt), 48, 256, fmt).cpu()
+        ref = O.get_quantizer(cfg)(W.clone())
+        assert torch.equal(w, torch.where(W.abs() <= 1e-8, torch.zeros_like(ref), ref)), block
+        assert float(w[3].abs().max()) == 0.0 and float(w[9].abs().max()) == 0.0
+
+
 def test_pack_weight_2d_tiles_bit_exact(ops, golden_q):
     """Weight tiles of R rows x L k (block_size [R, L], skip_first_dim = false; a lone [L] = all rows x L): the packed image,
     read back, against the reference's vectors - ragged tiles in both dims included (quantizers/utils.py:161-183)."""
