@@ -100,7 +100,10 @@ constexpr int XCH_GATHER_AUX = LQER_XCH_GATHER_AUX;
 // Round 6: 6 instead of 64 - every workgroup publishes in its prologue and gathers ~25 us later, so a granule that is still missing
 // belongs to a workgroup that is not resident (another stream holds its CU): waiting longer than the fall-back costs (the band's side
 // products: tiles_n x 16 MFMAs, a few us) buys nothing, and every late tile paid the full bound
-constexpr int XCH_SWEEPS = 6;
+#ifndef LQER_XCH_SWEEPS
+#define LQER_XCH_SWEEPS 6
+#endif
+constexpr int XCH_SWEEPS = LQER_XCH_SWEEPS;
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
@@ -385,8 +388,16 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   }
   const int nt = g.tiles_m * g.tiles_n;
   // XCD-aware tile order of a virtual block id (blocks b, b + 8, ... share an XCD; the grid is a multiple of 8 or covers nt)
+  // g.xcd_bm > 0 (round 6, LQER_TUNE_XCD_BLOCK; host-checked: nt % 8 == 0 and the grid divides): an XCD's nt / 8 tiles form a BLOCK of
+  // xcd_bm token tiles x (nt / 8 / xcd_bm) weight tiles instead of whole rows of weight tiles - 16 x 16 tiles as 4 x 8 blocks read
+  // 2 + 4.2 MB per XCD instead of 1 + 8.5 (K = 4096)
   auto tile_of = [&](int b) {
     const int xcd = b & 7, q8 = nt >> 3, r8 = nt & 7;
+    if (g.xcd_bm > 0) {
+      const int bn = q8 / g.xcd_bm, gx = g.tiles_n / bn;  // block width in weight tiles; XCD blocks per row of blocks
+      const int xr = xcd / gx, xc = xcd - xr * gx, i = b >> 3, r = i / bn, c = i - r * bn;
+      return (xr * g.xcd_bm + r) * g.tiles_n + xc * bn + c;
+    }
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   };
   const int Kp8 = g.Kp;  // (the int8 image's row stride)
@@ -1467,11 +1478,18 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int tid_e = wave * 64 + lane;
   if constexpr (XCH_OK) {
     if (xch && wave < 2 && !xg_early) {
+      if (g.xcd_bm > 0) {  // (XCD blocks: a row band's column tiles sit on several XCDs - agent scope from the first read on)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + G::EP_GATHER + wave * 2048 + j * 1024), 16,
-                                                 (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16, 0, 0,
-                                                 XCH_GATHER_AUX);
+        for (int j = 0; j < 2; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + G::EP_GATHER + wave * 2048 + j * 1024), 16,
+                                                   (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16, 0, 0, 16);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xch_rsrc, (lds_void*)(smem + G::EP_GATHER + wave * 2048 + j * 1024), 16,
+                                                   (int)(((m0 >> 2) + 16 * wave + 8 * j + (lane >> 3)) * (LQER_AMAX_NSEG * 8)) + (lane & 7) * 16, 0, 0,
+                                                   XCH_GATHER_AUX);
+      }
     }
   }
   bf16x8 sb[LOWRANK ? 8 : 1];
@@ -1857,6 +1875,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
 template <int DT, int NT>
 static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st);
 
+// LQER_TUNE_XCD_BLOCK(t) for the int8 kernel: t token tiles per XCD block, applied only where the tile grid divides - every XCD gets
+// nt / 8 tiles (nt % 8 == 0), a block is t x (nt / 8 / t) tiles, blocks tile the grid (tiles_m % t == 0, tiles_n % bn == 0) and there
+// are exactly 8 of them.  0 = rows of weight tiles (the default map).
+static int i8_xcd_block(const GemmArgs& g, int nt) {
+  const int t = (g.tuning >> 4) & 0x3f;
+  if (t <= 0 || nt % 8 != 0 || (nt / 8) % t != 0 || g.tiles_m % t != 0) return 0;
+  const int bn = (nt / 8) / t;
+  if (bn <= 0 || g.tiles_n % bn != 0 || (g.tiles_m / t) * (g.tiles_n / bn) != 8) return 0;
+  return t;
+}
+
 // 8-bit weight codes: 128-row tiles with the codes straight into registers, or 256-row tiles with a half-step weight ring in LDS
 template <int DT, int NT>
 static int launch_w8(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
@@ -1866,6 +1895,7 @@ static int launch_w8(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
   constexpr int CUS = 256;
   const int nt_all = g.tiles_m * g.tiles_n;
   const unsigned grid = (unsigned)(nt_all < CUS ? nt_all : CUS);
+  g.xcd_bm = i8_xcd_block(g, nt_all);
 #define LQER_I8_LAUNCH8(LR, BO)                                                                   \
   do {                                                                                            \
     static LdsLimitOnce lds_once;                                                                 \
@@ -1900,6 +1930,7 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
   constexpr int CUS = 256;
   const int nt_all = g.tiles_m * g.tiles_n;
   const unsigned grid = (unsigned)(nt_all < CUS ? nt_all : CUS);
+  g.xcd_bm = i8_xcd_block(g, nt_all);
 #define LQER_I8_LAUNCH(LR, BO)                                                                    \
   do {                                                                                            \
     if (g.i8_shift) {                                                                             \

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--lib", default=None, help="path of another build of liblqer_hip.so")
     ap.add_argument("--amax", action="store_true", help="with --rows: 128-row tiles with segment-partial row maxima against atomicMax cells + memset")
     ap.add_argument("--rows", action="store_true", help="compare the int8 kernel's 128-row and 256-row tiles (pinned) and the bf16 route")
+    ap.add_argument("--xcd", type=int, nargs="*", default=[], help="(round 6) also the int8 route with XCD-local tile BLOCKS of this many token tiles "
+                    "(LQER_TUNE_XCD_BLOCK: applied where the tile grid divides, e.g. 4 or 8 at 16 x 16 tiles)")
+    ap.add_argument("--only", default=None, help="time only this variant (counter passes: one map per process)")
     ap.add_argument("--split", action="store_true", help="(round 6) also the int8 route with its activation side pinned to the three launches (LQER_TUNE_ACT8_SPLIT)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -54,6 +57,12 @@ def main():
         d3 = mod._desc()
         d3.tuning = _lib.TUNE_ACT8_SPLIT
         variants = [("int8", mod._desc()), ("i8-3l", d3)]
+    for t in a.xcd:
+        dx = mod._desc()
+        dx.tuning = (t & 0x3f) << 4
+        variants.append((f"xcd{t}", dx))
+    if a.only:
+        variants = [v for v in variants if v[0] == a.only]
     if a.rows:  # the int8 kernel's two tile heights, pinned (same bits)
         d128, d256 = mod._desc(), mod._desc()
         d128.tuning, d256.tuning = _lib.TUNE_I8_ROWS_128, _lib.TUNE_I8_ROWS_256
@@ -96,7 +105,10 @@ def main():
         torch.cuda.synchronize()
         outs[name] = y.clone()
     i8n = "i8r128" if a.rows else ("i8xch" if a.amax else "int8")
-    if "bf16" in outs:
+    for t in a.xcd:
+        if f"xcd{t}" in outs and "int8" in outs:
+            print(f"XCD blocks of {t} token tiles bit-identical to the default map:", bool(torch.equal(outs[f"xcd{t}"], outs["int8"])))
+    if "bf16" in outs and i8n in outs:
         d = (outs[i8n].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()
         print(f"int8 vs bf16 route: rel-L2 {float(d):.2e}, differing fp16 elements {float((outs[i8n] != outs['bf16']).float().mean()):.2e}")
     if a.amax and not a.rows:
