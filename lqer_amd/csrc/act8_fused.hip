@@ -25,6 +25,12 @@ namespace a8f {
 
 constexpr int ROWS = 8, WAVES = 8;
 
+#ifdef LQER_CLOCKPROBE
+// diagnostic build (tools/clock_probe_a8.py): shader cycles at the phase boundaries of every wave, written to a buffer nothing else reads
+__device__ unsigned long long* g_a8_stamp_buf = nullptr;
+#define A8_STAMP(c) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c)::"memory")
+#endif
+
 __host__ __device__ inline int pitch_of(int64_t cols_p8) { return (int)cols_p8 + 32; }
 __host__ inline size_t lds_bytes(int64_t cols_p8, int rp) {
   return (size_t)ROWS * pitch_of(cols_p8) + (size_t)WAVES * ROWS * rp * sizeof(float) + ROWS * sizeof(float);
@@ -57,6 +63,10 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef LQER_CLOCKPROBE
+  unsigned long long cp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  A8_STAMP(cp[0]);
+#endif
   const int pitch = pitch_of(cols_p8);
   unsigned char* const xb = smem;                                    // [ROWS][pitch] int8 mantissas
   float* const red = (float*)(smem + (size_t)ROWS * pitch);          // [WAVES][ROWS][RP] partial tiles
@@ -68,9 +78,14 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
   // ---- requests: the row, then the first batch of this wave's A^T fragments (independent of the row: their latency passes under the
   // quantizer's arithmetic)
   const u32x4* p = (const u32x4*)((const bf16_t*)x + row * ld);
+  // register u of lane l holds chunk 2 l + (u & 1) + 128 (u >> 1): a lane's registers 2 v, 2 v + 1 are NEIGHBOURING chunks, so their 16
+  // mantissas leave as ONE 16-byte store (a KiB per wave instruction, to the image and to the LDS slab) - half the store instructions
+  // of k_quant_row8's lane + 64 u order, which cost the texture path a full slot for 512 bytes each
+  static_assert(MAXCH % 2 == 0, "chunk pairs");
+  auto chunk_of = [&](int u) { return 2 * lane + (u & 1) + 128 * (u >> 1); };
   u32x4 raw[MAXCH];
 #pragma unroll
-  for (int u = 0; u < MAXCH; ++u) raw[u] = (live_row && lane + 64 * u < nch) ? p[lane + 64 * u] : (u32x4){0, 0, 0, 0};
+  for (int u = 0; u < MAXCH; ++u) raw[u] = (live_row && chunk_of(u) < nch) ? p[chunk_of(u)] : (u32x4){0, 0, 0, 0};
   const int steps = (int)(cols_p8 / 32);
   const int spw = (steps + WAVES - 1) / WAVES;  // steps per wave
   const int s_begin = wave * spw, s_end = s_begin + spw < steps ? s_begin + spw : steps;
@@ -85,15 +100,26 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
         f[i][t] = s_begin < s_end ? fr[((int64_t)s * RT + t) * 64] : (u32x4){0, 0, 0, 0};
       }
   };
-  // (rows of up to 6144 elements: the registers also hold the SECOND batch from the start - at K = 4096 that is all of a wave's A^T)
+  // The CU's texture path moves 64 B per cycle and this kernel is bound by it (352 KiB per workgroup at K = 4096: 64 of rows, 256 of A^T
+  // fragments, 32 of image stores); its queue is shallow, so a wave that issues 32 fragment requests in a row stands still until the
+  // path has taken them - requested beside the row (in front of it or, behind an issue barrier, after it) they held the quantizer back by
+  // ~3,500 cycles (tools/clock_probe_a8.py).  Order kept: the row; once its maximum is known the first batch of fragments, which streams
+  // under the quantizer's arithmetic; the second batch behind the image stores, under the barrier and the first batch's MFMAs.
+  // (rows of up to 6144 elements: the registers also hold the SECOND batch - at K = 4096 that is all of a wave's A^T)
   constexpr bool TWO = MAXCH <= 8 || (MAXCH <= 12 && DT == LQER_F16);  // (bf16 rows of 12 chunks: the wider conversion would spill)
-  load_batch(fa, s_begin);
-  if constexpr (TWO) load_batch(fb, s_begin + SB);
 
   // ---- phase 1: the row -> int8 image + LDS slab (k_quant_row8's arithmetic)
+#ifdef LQER_CLOCKPROBE
+  A8_STAMP(cp[1]);  // requests out
+#endif
   float amax = row8_amax<DT, MAXCH>(raw);
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
+#ifdef LQER_CLOCKPROBE
+  asm volatile("" ::"v"(amax));
+  A8_STAMP(cp[2]);  // the row has landed, its maximum is known
+#endif
+  load_batch(fa, s_begin);
   const bool any = amax > 0.f;
   const int e = any ? block_exponent(amax, qx) : 0;
   const float rs = any ? ldexpf(1.0f, e - qx.mbits) : 1.0f;
@@ -106,22 +132,40 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
   const bool fast = mxint16_fast_ok(e, qx);  // (wave-uniform)
   const float sc = __uint_as_float((uint32_t)(127 + (fast ? qx.mbits - e : 0)) << 23);
   const float es = 1e-9f * sc;
+  // (nch_p is even - the image is padded to 128 k -, so a pair of chunks is inside it or outside it as a whole)
+  auto put = [&](int c0, const u32x2 w0, const u32x2 w1) {
+    const u32x4 w = {w0[0], w0[1], w1[0], w1[1]};
+    if (live_row) *(u32x4*)(dst + (int64_t)c0 * 8) = w;
+    *(u32x4*)(xrow + c0 * 8) = w;
+  };
   auto emit = [&](auto fast_c) {
     constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-    for (int u = 0; u < MAXCH; ++u) {
-      const int c = lane + 64 * u;
+    for (int u = 0; u < MAXCH; u += 2) {
+      const int c = chunk_of(u);
       if (c >= nch_p) continue;
-      const u32x2 w = row8_chunk<DT, FAST>(raw[u], c < nch && any, e, qx, sc, es);
-      if (live_row) *(u32x2*)(dst + (int64_t)c * 8) = w;
-      *(u32x2*)(xrow + c * 8) = w;
+      put(c, row8_chunk<DT, FAST>(raw[u], c < nch && any, e, qx, sc, es), row8_chunk<DT, FAST>(raw[u + 1], c + 1 < nch && any, e, qx, sc, es));
     }
   };
-  if (fast)
+  if (DT == LQER_F16 && any && row8_h16_ok(e, qx)) {  // (wave-uniform) packed half arithmetic: same bytes, a third of the instructions
+#pragma unroll
+    for (int u = 0; u < MAXCH; u += 2) {
+      const int c = chunk_of(u);
+      if (c >= nch_p) continue;
+      put(c, row8_chunk_h16(raw[u], c < nch, e, qx), row8_chunk_h16(raw[u + 1], c + 1 < nch, e, qx));
+    }
+  } else if (fast)
     emit(std::true_type{});
   else
     emit(std::false_type{});
+  if constexpr (TWO) load_batch(fb, s_begin + SB);
+#ifdef LQER_CLOCKPROBE
+  A8_STAMP(cp[3]);  // quantized, stores issued
+#endif
   __syncthreads();
+#ifdef LQER_CLOCKPROBE
+  A8_STAMP(cp[4]);  // every row's slab is in LDS
+#endif
 
   // ---- phase 2: this wave's steps of x_q A on the fp16 MFMA (int8 mantissas are exact halves; the row scale comes last)
   typedef __attribute__((ext_vector_type(2))) _Float16 h2;
@@ -133,10 +177,13 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
 #pragma unroll
   for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto compute_batch = [&](const u32x4 (&f)[SB][RT], int s0) {
+    u32x2 tb8[SB];  // the batch's token fragments first (one LDS round trip for all of them, not one per step)
+#pragma unroll
+    for (int i = 0; i < SB; ++i) tb8[i] = *(const u32x2*)(tok + 32 * (s0 + i < s_end ? s0 + i : s_end - 1));
 #pragma unroll
     for (int i = 0; i < SB; ++i) {
       if (s0 + i >= s_end) break;  // (wave-uniform)
-      const u32x2 b8 = *(const u32x2*)(tok + 32 * (s0 + i));
+      const u32x2 b8 = tb8[i];
       u32x4 hf;  // bytes -> 8 halves (i8x32_to_f16's arithmetic: 0x6400 | (b ^ 0x80) = 1024 + 128 + b, then - 1152)
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
@@ -155,6 +202,10 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
     if (s0 + 2 * SB < s_end) load_batch(fa, s0 + 2 * SB);
     if (s0 + SB < s_end) compute_batch(fb, s0 + SB);
   }
+#ifdef LQER_CLOCKPROBE
+  asm volatile("" ::"v"(acc[0][0]));
+  A8_STAMP(cp[5]);  // this wave's steps multiplied
+#endif
   // D layout: column n = lane & 15, rows 4 g + j: token rows 0-7 live in g = 0, 1
   if (g < 2) {
 #pragma unroll
@@ -163,6 +214,15 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
       for (int j = 0; j < 4; ++j) red[(wave * ROWS + 4 * g + j) * RP + 16 * t + (lane & 15)] = acc[t][j];
   }
   __syncthreads();
+#ifdef LQER_CLOCKPROBE
+  A8_STAMP(cp[6]);
+  if (g_a8_stamp_buf && lane == 0) {
+    unsigned long long* o = g_a8_stamp_buf + ((size_t)blockIdx.x * WAVES + wave) * 8;
+#pragma unroll
+    for (int i = 1; i < 7; ++i) o[i] = cp[i] - cp[0];
+    o[0] = cp[0];
+  }
+#endif
 
   // ---- phase 3: fixed-order sum of the 8 partial tiles, row scale, A_out (k_xa_reduce4's arithmetic), bf16 store
   const int tid = threadIdx.x;
@@ -217,6 +277,10 @@ static int launch(const void* x, int64_t M, int64_t K, int64_t ld, const QP& qx,
 }
 
 }  // namespace a8f
+
+#ifdef LQER_CLOCKPROBE
+extern "C" int lqer_debug_set_a8_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(a8f::g_a8_stamp_buf), &p, sizeof(p)); }
+#endif
 
 size_t a_f16_image_bytes(int64_t K, int64_t r) {  // [rp][Kp] fp16, then its fragment-major copy over padded_k8(K) / 32 steps
   const int64_t rp = lqer_padded_r(r);

@@ -477,6 +477,33 @@ __device__ __forceinline__ u32x2 row8_chunk(const u32x4 raw, bool live, int e, c
   return (u32x2){__builtin_amdgcn_perm(h[1], h[0], 0x06040200u), __builtin_amdgcn_perm(h[3], h[2], 0x06040200u)};
 }
 
+// fp16 rows whose exponent allows it (row8_h16_ok): the same 8 mantissas in PACKED HALF arithmetic, 2.25 vector instructions per element
+// instead of 6.25 - t = x 2^(mbits - e) is exact in fp16 (a power-of-two scale inside the half range; what underflows rounds to 0 either
+// way), the clamp comes first (t >= mmax + 0.5 would round to 2^mbits), and t + 1536 rounds to nearest even at ulp 1 and leaves the
+// two's-complement mantissa in the low byte of the half (1536 + r = 0x6600 + r).  Where is this the fp32 path's result bit for bit?  That
+// path rounds fl32(t +- 1e-9 2^(mbits - e)): the epsilon only ever matters for an exact tie t = k + 1/2 whose fp32 half-ulp it reaches -
+// ties below 2^(mbits - 5 - e), i.e. none when e >= mbits - 4 (a tie is at least 1/2); fp16 holds no non-zero |x| <= 1e-8.
+__device__ __forceinline__ bool row8_h16_ok(int e, const QP& q) {
+  return q.kind == LQER_Q_MXINT && q.mbits <= 7 && e >= q.mbits - 4 && e <= 16 && q.mneg == q.mmax;  // (2^(mbits - e) in [2^-9, 2^4])
+}
+__device__ __forceinline__ u32x2 row8_chunk_h16(const u32x4 raw, bool live, int e, const QP& q) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+  const _Float16 s1 = __builtin_bit_cast(_Float16, (unsigned short)((15 + q.mbits - e) << 10));  // 2^(mbits - e)
+  const _Float16 m1 = (_Float16)q.mmax;
+  const h2 s2 = {s1, s1}, hi = {m1, m1}, lo = {-m1, -m1}, magic = {(_Float16)1536.0f, (_Float16)1536.0f};
+  uint32_t u[4] = {0, 0, 0, 0};
+  if (live) {
+    const uint32_t wd[4] = {raw[0], raw[1], raw[2], raw[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h2 t = __builtin_bit_cast(h2, wd[j]) * s2;
+      t = __builtin_elementwise_max(__builtin_elementwise_min(t, hi), lo);
+      u[j] = __builtin_bit_cast(uint32_t, t + magic);
+    }
+  }
+  return (u32x2){__builtin_amdgcn_perm(u[1], u[0], 0x06040200u), __builtin_amdgcn_perm(u[3], u[2], 0x06040200u)};
+}
+
 // ---- cross-file declarations ----------------------------------------------------------------------
 struct QuantOut {
   float* deq;      // [rows, cols] or null

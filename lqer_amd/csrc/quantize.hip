@@ -219,7 +219,14 @@ __global__ __launch_bounds__(256) void k_quant_row8(const void* __restrict__ x, 
       *(u32x2*)(dst + (int64_t)c * 8) = row8_chunk<DT, FAST>(raw[u], c < nch && any, e, q, s, es);
     }
   };
-  if (fast)
+  if (DT == LQER_F16 && any && row8_h16_ok(e, q)) {  // (wave-uniform; round 6) packed half arithmetic: same bytes, a third of the instructions
+#pragma unroll
+    for (int u = 0; u < MAXCH; ++u) {
+      const int c = lane + 64 * u;
+      if (c >= nch_p) continue;
+      *(u32x2*)(dst + (int64_t)c * 8) = row8_chunk_h16(raw[u], c < nch, e, q);
+    }
+  } else if (fast)
     emit(std::true_type{});
   else
     emit(std::false_type{});

@@ -158,3 +158,26 @@ def test_a_out_in_blocks_of_16(lq):
     s64 = (img1[:, :K].double().cpu().numpy() @ A.half().double().numpy()) * sc1.double().cpu().numpy()[:, None]
     for xa in (xa1, xa3):
         assert envelope_check(s64, xa[:, :r].cpu().numpy(), 16, 7, max(16.0, math.sqrt(K))) == 0
+
+
+def test_ties_at_every_exponent_through_the_one_launch_kernel(lq):
+    """The packed-half quantizer of fp16 rows (common.h row8_chunk_h16) inside the one-launch kernel: rows whose maximum is 2^n for n from
+    -12 to 15, filled with multiples of max / 256 (ties k + 1/2, the clamp), image and scales against the oracle bit for bit."""
+    M, K, N, r = 56, 1024, 256, 32
+    mod, x, W, A, B, qc = _module(lq, K, N, r, torch.float16, seed=5, M=M)
+    g = torch.Generator().manual_seed(7)
+    x = torch.zeros(M, K)
+    for i in range(M):
+        amax = 2.0 ** (i // 2 - 12)
+        j = torch.randint(0, 257, (K,), generator=g).float()
+        x[i] = torch.where(torch.rand(K, generator=g) < 0.5, -1.0, 1.0) * amax * j / 256.0
+        x[i, i % K] = amax
+    xd = x.half().to(DEV)
+    mod(xd)
+    img, sc, xa = _act_side(mod, xd, 0)
+    ref = O.get_quantizer(qc["x_quantizer"])(x)
+    assert torch.equal((img[:, :K].float() * sc[:, None]).cpu(), torch.where(x.abs() <= 1e-8, torch.zeros_like(ref), ref))
+    from lqer_amd import _lib
+
+    img3, sc3, _ = _act_side(mod, xd, _lib.TUNE_ACT8_SPLIT)
+    assert torch.equal(img, img3) and torch.equal(sc, sc3)

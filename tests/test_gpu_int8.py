@@ -112,6 +112,33 @@ def _mod(lq, K, N, r, qc, bias, seed, dtype, M):
     return mod.to(DEV).to(dtype), x, W, A, B, b
 
 
+def test_int8_activation_image_ties_at_every_exponent(lq):
+    """fp16 rows take a packed-half quantizer where their exponent allows it (round 6, common.h row8_chunk_h16: rows with e >= 3, no tie
+    the reference's +1e-9 could tip) and the fp32 arithmetic elsewhere: rows whose maximum is 2^n for every n from -12 to 15, filled
+    with multiples of max / 256 - every second one lands exactly on a rounding tie k + 1/2, the largest ones on the clamp - against the
+    oracle bit for bit, through the standalone quantizer and through the one-launch activation kernel's image."""
+    from lqer_amd import ops
+
+    rows, K = 28, 1024
+    g = torch.Generator().manual_seed(99)
+    x = torch.zeros(rows, K)
+    for i in range(rows):
+        amax = 2.0 ** (i - 12)
+        j = torch.randint(0, 257, (K,), generator=g).float()
+        sgn = torch.where(torch.rand(K, generator=g) < 0.5, -1.0, 1.0)
+        x[i] = sgn * amax * j / 256.0
+        x[i, 0] = amax          # the row's maximum: an exact power of two (e = i - 12), rounds to 2^mbits, clamps
+        x[i, 1] = -amax * 255 / 256
+    xh = x.half()
+    assert torch.equal(xh.float(), x)  # (every value is exact in fp16)
+    cfg = dict(name="block_fp", width=8, exponent_width=8, exponent_bias=None, block_size=[1, -1], skip_first_dim=True)
+    fmt = ops.make_qfmt(cfg, "x")
+    q8, sc = ops.quantize_act_i8(xh.to(DEV), fmt)
+    ref = O.get_quantizer(cfg)(x)
+    want = torch.where(x.abs() <= 1e-8, torch.zeros_like(ref), ref)
+    assert torch.equal(q8[:rows, :K].float().cpu() * sc[:rows, None].cpu(), want)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 5e-3)])
 @pytest.mark.parametrize("M,K,N,r,wblock,bias", [(2048, 512, 8192, 64, 128, False), (2304, 200, 8000, 32, -1, True),
                                                  (4096, 1000, 4352, 16, 128, False), (2100, 384, 8192, 128, 256, True)])
