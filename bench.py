@@ -94,6 +94,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle comparison of the timed outputs")
     ap.add_argument("--no-module", action="store_true", help="skip the second timed region through the nn.Module")
+    ap.add_argument("--tuning", type=lambda v: int(v, 0), default=0,
+                    help="lqer_linear_desc_t.tuning for every Linear (LQER_TUNE_* bits of include/lqer_hip.h: kernel-variant A/B, same bits), "
+                         "e.g. 0x800000 = the block-16 activation side as two launches, 0x200000 = the int8 route's as three")
     ap.add_argument("--prewarm-ms", type=float, default=300.0, help="untimed device clock ramp before the warm-up steps (0 = none)")
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="capture G consecutive steps in one hipGraph and replay it steps/G times (launch-bound decode sizes; "
@@ -190,7 +193,7 @@ def main():
     opts = Opts(workload=args.workload, steps=args.steps, warmup=args.warmup, layers=args.layers, sweep=args.sweep, shard=args.shard,
                 check=not args.no_check, module=not args.no_module, two_streams=not args.no_two_streams,
                 cpu_base=not args.no_cpu_baseline, prewarm_ms=args.prewarm_ms, graph=args.graph, rotate=args.rotate,
-                shared_weights=args.shared_weights)
+                shared_weights=args.shared_weights, tuning=args.tuning)
     out = run_workload(ctx, opts)
     default_line = (world == 1 and args.workload == "c2" and args.layers == 0 and args.shard == "none" and not args.graph
                     and not args.no_configs)

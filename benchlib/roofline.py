@@ -11,7 +11,7 @@ import torch
 from .workloads import BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, INT8_MFMA_PEAK_TOPS, MXINT_Q
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02")  # newest committed PMC summary wins
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02")  # newest committed PMC summary wins
 NOMINAL_MHZ = 2400.0  # the clock the peaks are priced at (MI355X_MICROARCH.md: max clock)
 
 

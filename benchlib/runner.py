@@ -47,6 +47,7 @@ class Opts:
     rotate: Optional[int] = None
     shared_weights: bool = False
     uninstrumented: bool = True  # a second timed region without event pairs
+    tuning: int = 0              # lqer_linear_desc_t.tuning of every module (LQER_TUNE_*: kernel-variant A/B on one box, same bits)
 
 
 def timed_region(ctx: Ctx, fn, steps):
@@ -130,6 +131,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
             sd["bias"] = wts[3][n0:n1]
         mod.load_state_dict(sd)
         mod = mod.to(dev).half()
+        mod.tuning = o.tuning
         y = mod(xs[K])  # packs the operands (one-time, like the reference's first forward)
         mods.append((mod, xs[K], K, Nl, cnt * layers_here, y, wts, N))
     torch.cuda.synchronize()
@@ -195,14 +197,12 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         gscr = L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
         if L.lqer_decode_partials(C.byref(desc), M):
             xaq, gscr = None, nscr  # decode route: the GEMM reduces the partial tiles of x A left in the scratch itself
-        a_t, a_limbs = p["a_t"].data_ptr(), p["a_limbs"]
-        if mod._x_i8 and "a_t_f16" in p and L.lqer_gemm_route(C.byref(desc), M, _lib.F16) == _lib.ROUTE_I8:
-            a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # the int8 route's side GEMM: A as one fp16 image (as the module passes it)
+        a_t, a_limbs = mod._side_image(M, desc, _lib.F16)  # (the image the module itself passes at this token count)
         # model sweeps: every Linear of the model owns its packed operands (same values, distinct addresses - layers differ
         # in values, not in cost, but a weight that is re-read from the Infinity Cache 32 times is not what a model does)
         copies = []
         if distinct and reps > 1:
-            a_key = "a_t_f16" if a_limbs == -1 else "a_t"
+            a_key = {-1: "a_t_f16", -2: "a_t_b16"}.get(a_limbs, "a_t")
             for _ in range(reps - 1):
                 cw, ca, cb = p["w"].clone(), p[a_key].clone(), p["b_t"].clone()
                 cbias = p["bias"].clone() if p.get("bias") is not None else None
@@ -378,6 +378,10 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
             if gemm_events else elapsed / steps
         per_step_launches = sum(reps for reps, _, _, _ in calls_for(stream))
         sustained_mhz = _sustained_clock(ctx, L, run_gemm_only, steps, gemm_s * per_step_launches)
+        # (the GEMM-only launches multiplied whatever images the last quantizer call of a shape left - Linears that share a workspace got
+        # each other's x A: one whole step puts every output buffer back to what the parity check below expects)
+        step(False)
+        torch.cuda.synchronize()
 
     # decode workloads: the same steps once more on ONE resident weight (what rounds 1-2 reported: an upper bound)
     resident_fig = None

@@ -134,6 +134,11 @@ typedef struct lqer_linear_desc {
                                          another order (A_out of it inside the summation-order envelope)                            */
 #define LQER_TUNE_ACT8_FUSED 0x400000 /* ... the one-launch kernel at every token count (default: M <= 4096 - every workgroup of 8 token
                                          rows streams the whole A^T image)                                                          */
+#define LQER_TUNE_ACT16_SPLIT 0x800000 /* block-16 MXINT activations with a_limbs = -2: the quantizer + split-K kernel and the reduce as two
+                                         launches even where the one-launch kernel applies (act16_fused.hip; same image, x A in another
+                                         summation order)                                                                            */
+#define LQER_TUNE_ACT16_FUSED 0x1000000 /* ... the one-launch kernel at every token count (default: 1024 <= M <= 4096; the same window
+                                         applies to LQER_TUNE_ACT8_FUSED's kernel)                                                    */
 #define LQER_TUNE_DECODE_NO_POLL 0x10000 /* one-launch decode route: no wait for the producers' tiles - every weight-streaming
                                          workgroup computes the partial tiles of x A itself (the bounded wait's fall-back)     */
 
@@ -377,6 +382,14 @@ int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t
 /* bytes of the fp16 image of A^T that lqer_f16_prepare writes (the [rp][Kp] image every a_limbs = -1 consumer reads + its
  * fragment-major copy); the reference has nothing to replace here - A is an fp16 nn.Parameter (quantized_layers/linear.py:142) */
 size_t lqer_a_f16_image_bytes(int64_t K, int64_t r);
+/* The same for block-16 MXINT activations (x_fmt block_fp [1, 16], the llama-7b.toml / opt-6.7b.toml templates) and an A of ONE bf16 limb
+ * (8-bit block_fp A, llama-7b.toml:60-73): lqer_a_b16_prepare copies limb 0 of lqer_pack_lowrank's a_t ([rp][Kp] bf16) into `out` and
+ * writes its fragment-major copy (the B operand of v_mfma_f32_16x16x32_bf16) behind it; out holds lqer_a_b16_image_bytes(K, r) bytes.
+ * Passed as a_t with a_limbs = -2 to lqer_quantize_act_xa / lqer_linear_forward, it lets quantizer + x A + A_out run as ONE launch
+ * (csrc/act16_fused.hip) for 16-bit, 16-byte aligned tensors with K % 16 == 0, padded rank 16 / 32 / 64 and 1024 <= M <= 4096; every
+ * other call reads the image's first part exactly like a_limbs = 1.  Reference: linear.py:154-156 (x_quantizer, matmul, A_out_quantizer). */
+size_t lqer_a_b16_image_bytes(int64_t K, int64_t r);
+int lqer_a_b16_prepare(const void* a_t_limbs, int64_t K, int64_t r, void* out, void* stream);
 
 /* ---- weights of 5..8 bits (the reference's no-LQER baseline: W8A8 block_fp with one block per row and per token,
  * experiments/pipeline/sweep_baseline_no_lqer.sh:73-76, through LinearFlexible, quantized_layers/linear.py:50-64) ---------------

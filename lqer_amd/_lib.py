@@ -19,6 +19,7 @@ K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
 ROUTE_SMALLM, ROUTE_TILE128, ROUTE_TILE256, ROUTE_I8 = 0, 1, 2, 3
 TUNE_TILE_ROWS_128, TUNE_TILE_ROWS_64, TUNE_DECODE_NO_POLL, TUNE_XA_REDUCE_IN_GEMM = 0x1, 0x2, 0x10000, 0x20000
 TUNE_I8_ROWS_128, TUNE_I8_ROWS_256, TUNE_AMAX_ATOMIC, TUNE_AMAX_PARTS = 0x4, 0x8, 0x40000, 0x80000
+TUNE_ACT16_SPLIT, TUNE_ACT16_FUSED = 0x800000, 0x1000000  # block-16 MXINT activation side: two launches / the one-launch kernel at every M
 TUNE_ACT8_SPLIT, TUNE_ACT8_FUSED = 0x200000, 0x400000  # int8 route's activation side: three launches / the one-launch kernel at every M
 TUNE_AMAX_XCH_MISS = 0x100000  # int8 route's in-GEMM exchange of the B_out row maxima: every workgroup takes its fall-back
 
@@ -99,6 +100,8 @@ SIGNATURES = {
     "lqer_gemm_tile_rows": (_i, [_dp, _i64, _i]),
     "lqer_f16_prepare": (_i, [_vp, _i64, _i64, _vp, _i, _i64, _vp, _vp, _vp]),
     "lqer_a_f16_image_bytes": (C.c_size_t, [_i64, _i64]),
+    "lqer_a_b16_image_bytes": (C.c_size_t, [_i64, _i64]),
+    "lqer_a_b16_prepare": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "lqer_i8_prepare": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),
     "lqer_unpack_weight_i8": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "lqer_unpack_weight_i8_fmt": (_i, [_vp, _i64, _i64, _qp, _vp, _vp]),

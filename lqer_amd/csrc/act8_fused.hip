@@ -316,8 +316,9 @@ int act8_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t 
   if (rp % L != 0 || L % 4 != 0 || (G & (G - 1)) != 0 || G > 64) return LQER_E_UNSUPPORTED;
   // every workgroup streams the whole A^T image: worth it while the token count is small (M = 2048: 64 MB through L2 against three
   // launches; at M = 16384 the split-K kernels read A^T once per 128 rows)
-  const int64_t max_m = (tuning & LQER_TUNE_ACT8_FUSED) ? (int64_t)1 << 40 : LQER_ACT8_FUSED_MAX_M;
-  if (M > max_m) return LQER_E_UNSUPPORTED;
+  // (... and large enough for its grid of M / 8 workgroups to cover the chip's better half: below, the split-K kernels spread the same
+  // rows over more CUs)
+  if (!(tuning & LQER_TUNE_ACT8_FUSED) && (M > LQER_ACT8_FUSED_MAX_M || M < LQER_ACT8_FUSED_MIN_M)) return LQER_E_UNSUPPORTED;
   const int64_t cols_p8 = padded_k8(K);
   const int64_t nch_p = cols_p8 / 8;
   if (a8f::lds_bytes(cols_p8, (int)rp) > 160 * 1024) return LQER_E_UNSUPPORTED;

@@ -488,6 +488,17 @@ int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, 
 
 static int quantize_act_xa_single(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
                                   int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream) {
+  if (a_limbs == -2) {
+    // the bf16 image of A^T with its fragment-major copy (lqer_a_b16_prepare): block-16 MXINT activations run quantizer + x A + A_out as
+    // ONE launch where act16_fused.hip applies; everything else reads the image's first part as the one-limb image it is
+    if (d->rank > 0 && a_t && xaq && xq && d->x_fmt.kind == LQER_Q_MXINT && fmt_ok(&d->x_fmt, "x_quantizer", 9) &&
+        fmt_ok(&d->a_out_fmt, "A_out_quantizer", 9)) {
+      const int rc = act16_fused_dispatch(x, dtype, M, d->in_features, ldx, make_qp(d->x_fmt), (bf16_t*)xq, a_t, d->rank, make_qp(d->a_out_fmt),
+                                          (bf16_t*)xaq, d->tuning, (hipStream_t)stream);
+      if (rc != LQER_E_UNSUPPORTED) return rc;
+    }
+    a_limbs = 1;
+  }
   if (d->rank > 0 && a_t && !xaq) {  // partial tiles only: the GEMM reduces them (decode sizes)
     if (!decode_partials_ok(d, M) && !tile_partials_ok(d, M, dtype)) {
       set_error("quantize_act_xa: xaq == NULL needs M <= 64 or the 128-row tile kernel's token counts with fp16 / bf16 tensors, "
@@ -853,6 +864,16 @@ int lqer_f16_prepare(const void* w_packed, int64_t N, int64_t K, const void* a_t
   const int rc = f16_prepare_dispatch(w_packed, N, K, a_t_limbs, a_limbs, r, a_t_f16, flags, (hipStream_t)stream);
   if (rc || r <= 0) return rc;
   return a_frag_dispatch(a_t_f16, K, r, (hipStream_t)stream);  // the fragment-major copy behind [rp][Kp] (lqer_a_f16_image_bytes)
+}
+
+size_t lqer_a_b16_image_bytes(int64_t K, int64_t r) { return (K > 0 && r > 0) ? a_b16_image_bytes(K, r) : 0; }
+
+int lqer_a_b16_prepare(const void* a_t_limbs, int64_t K, int64_t r, void* out, void* stream) {
+  if (!a_t_limbs || !out || K <= 0 || r <= 0) {
+    set_error("a_b16_prepare: bad argument");
+    return LQER_E_INVALID;
+  }
+  return a_b16_prepare_dispatch(a_t_limbs, K, r, out, (hipStream_t)stream);
 }
 
 size_t lqer_a_f16_image_bytes(int64_t K, int64_t r) {

@@ -182,15 +182,16 @@ __device__ __forceinline__ float mxint_value(float x, int e, const QP& q) {
 // like an unsigned one (|u| <= 2^mbits), v_med3_f32 clamps both ends, and the bf16 image is the high half of r 2^(e-mbits)
 // with its own sign (a negative x that rounds to zero gives -0, as the sign transplant did).  Nine vector instructions per
 // pair of elements (two v_bfi, three packed fp32 ops, two v_med3, one packed multiply, one v_perm) instead of fourteen.
-template <bool FLUSH_TINY>  // false when the input type cannot hold a non-zero |x| <= 1e-8 (fp16)
-__device__ __forceinline__ void mxint16_bf16_fast(const float (&v)[16], int e, const QP& q, uint32_t (&w)[8]) {
+template <bool FLUSH_TINY, int N = 16>  // FLUSH_TINY false when the input type cannot hold a non-zero |x| <= 1e-8 (fp16); N values (a block of
+                                       // 16, or the 8 of it that one lane of act16_fused.hip holds)
+__device__ __forceinline__ void mxint16_bf16_fast(const float (&v)[N], int e, const QP& q, uint32_t (&w)[N / 2]) {
   typedef __attribute__((ext_vector_type(2))) float f2;
   const float s = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
   const float inv = __uint_as_float((uint32_t)(127 + e - q.mbits) << 23);
   const float es = 1e-9f * s, lo = -q.mneg, hi = q.mmax;
   const f2 magic = {12582912.0f, 12582912.0f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < N / 2; ++i) {
     const f2 x = {v[2 * i], v[2 * i + 1]};
     const f2 c = {copysignf(es, x[0]), copysignf(es, x[1])};
     f2 r = (__builtin_elementwise_fma(x, (f2){s, s}, c) + magic) - magic;
@@ -576,6 +577,14 @@ int copy_act_f16_dispatch(const void* x, int64_t M, int64_t K, int64_t ldx, bf16
 #ifndef LQER_ACT8_FUSED_MAX_M
 #define LQER_ACT8_FUSED_MAX_M 4096
 #endif
+#ifndef LQER_ACT8_FUSED_MIN_M
+#define LQER_ACT8_FUSED_MIN_M 1024
+#endif
+// the block-16 MXINT activation side in one launch (act16_fused.hip): a_b16 = the bf16 image [rp][Kp] + its fragment-major copy
+int act16_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, bf16_t* xq, const void* a_b16, int64_t r,
+                         const QP& qa, bf16_t* xaq, int tuning, hipStream_t st);
+size_t a_b16_image_bytes(int64_t K, int64_t r);
+int a_b16_prepare_dispatch(const void* a_t_limbs, int64_t K, int64_t r, void* out, hipStream_t st);
 int act8_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, void* xq_i8, const void* a_f16, int64_t r,
                         const QP& qa, bf16_t* xaq, int tuning, hipStream_t st);
 size_t a_f16_image_bytes(int64_t K, int64_t r);

@@ -64,6 +64,7 @@ class _LinearBase(nn.Linear):
         self._x_i8 = False         # per-token 8-bit activations on the int8 MFMA route (decided when the images are built)
         self.i8_a_f16 = True       # int8 route: fp16 A as one fp16 image for the side GEMM (False: the bf16 limb pair)
         self.a8_native = True      # False: keep them on the bf16 route
+        self.a16_fused = True      # block-16 MXINT activations: build the image the one-launch activation kernel reads (a_limbs = -2)
         self.tuning = 0            # lqer_linear_desc_t.tuning (_lib.TUNE_*): per-call kernel-variant knobs of tests, same bits
         self._setup_quantizers(q_config)
         self._setup_lqer(l_config)
@@ -137,6 +138,14 @@ class _LinearBase(nn.Linear):
                     ok16, a16 = ops.a_f16_image(w2, self.out_features, K, p["a_t"], int(p["a_limbs"]), self.rank)
                     if ok16:
                         p["a_t_f16"] = a16
+        fa_ = self._fmt.get("A_out")
+        if (self.a16_fused and not self._x_i8 and self.rank > 0 and int(p.get("a_limbs", 0)) == 1 and fx.kind == _lib.Q_MXINT and fx.block == 16
+                and fx.width <= 9 and fa_ is not None and fa_.kind == _lib.Q_MXINT and fa_.width <= 9
+                and _lib.lib().lqer_padded_r(self.rank) in (16, 32, 64)):
+            # block-16 MXINT activations with an A of one bf16 limb (the llama-7b.toml / opt-6.7b.toml templates): the bf16 image of A^T with
+            # its fragment-major copy - quantizer + x A + A_out then run as ONE launch at prefill sizes (act16_fused.hip, a_limbs = -2)
+            p = dict(p)
+            p["a_t_b16"] = ops.a_b16_image(p["a_t"], K, self.rank)
         if (self._fmt["x"].kind == _lib.Q_PASSTHROUGH and self.weight.dtype == torch.float16 and self.a16_native
                 and fw.kind == _lib.Q_MXINT and fw.width <= 4):
             # (integer weights - two's-complement nibbles - have no fp16 main loop, weights of 5..8 bits travel as three 4-bit limbs
@@ -497,10 +506,7 @@ class _LinearBase(nn.Linear):
             if len(self._fw_cache) > 64:
                 self._fw_cache = {}
             # (plain data only: the module must stay deep-copyable and picklable)
-            a_t, a_limbs = ops._ptr(p.get("a_t")), p.get("a_limbs", 0)
-            if self._x_i8 and "a_t_f16" in p and \
-                    _lib.lib().lqer_gemm_route(C.byref(desc), M, ops.dtype_code(x2)) == _lib.ROUTE_I8:
-                a_t, a_limbs = p["a_t_f16"].data_ptr(), -1  # (the int8 kernel's token counts only: elsewhere the bf16 kernels run)
+            a_t, a_limbs = self._side_image(M, desc, ops.dtype_code(x2))
             ent = self._fw_cache[key] = (desc, ops.linear_sizes(desc, M).workspace, ops.dtype_code(x2),
                                          (p["w"].data_ptr(), a_t, ops._ptr(p.get("b_t")),
                                           a_limbs, p.get("b_limbs", 0), ops._ptr(p.get("bias"))))
@@ -513,6 +519,19 @@ class _LinearBase(nn.Linear):
         if rc:
             check(rc, "lqer_linear_forward")
         return y.reshape(*x.shape[:-1], N)
+
+    def _side_image(self, M: int, desc, dt_code: int):
+        """(pointer, a_limbs) of the A^T image a forward of M tokens is handed (also what bench.py passes through the C ABI): the limb
+        image of lqer_pack_lowrank, or - at the token counts where their kernels run - the int8 route's single fp16 image (a_limbs = -1) /
+        the block-16 route's bf16 image with its fragment-major copy (a_limbs = -2; beyond decode sizes only: the one-launch decode kernel
+        and the groups take the plain one-limb image)."""
+        p = self._packed
+        a_t, a_limbs = ops._ptr(p.get("a_t")), p.get("a_limbs", 0)
+        if self._x_i8 and "a_t_f16" in p and _lib.lib().lqer_gemm_route(C.byref(desc), M, dt_code) == _lib.ROUTE_I8:
+            return p["a_t_f16"].data_ptr(), -1  # (the int8 kernel's token counts only: elsewhere the bf16 kernels run)
+        if "a_t_b16" in p and M > 64 and not self._x_i8:
+            return p["a_t_b16"].data_ptr(), -2
+        return a_t, a_limbs
 
     def __repr__(self):
         return "{}(in_features={}, out_features={}, bias={}, is_ptq={}, rank={}, backend=hip/gfx950)".format(

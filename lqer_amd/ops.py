@@ -295,6 +295,17 @@ def a_f16_image(w_packed: torch.Tensor, N: int, K: int, a_t_limbs: torch.Tensor,
 
 
 @_on_tensor_device
+def a_b16_image(a_t_limbs: torch.Tensor, K: int, r: int) -> torch.Tensor:
+    """Limb 0 of `lqer_pack_lowrank`'s A^T image [rp][Kp] followed by its fragment-major copy (include/lqer_hip.h, lqer_a_b16_prepare):
+    what the one-launch activation kernel of block-16 MXINT configurations reads (a_limbs = -2)."""
+    L = _lib.lib()
+    dev = a_t_limbs.device
+    out = torch.empty(L.lqer_a_b16_image_bytes(K, r) // 2, dtype=torch.bfloat16, device=dev)
+    check(L.lqer_a_b16_prepare(a_t_limbs.data_ptr(), K, r, out.data_ptr(), _stream(dev)), "lqer_a_b16_prepare")
+    return out
+
+
+@_on_tensor_device
 def i8_prepare(w_packed: torch.Tensor, N: int, K: int, w_fmt: QFmt):
     """Eligibility of the int8 MFMA route (include/lqer_hip.h "int8 route") for one packed weight: returns (ok, buffer) -
     `buffer` holds the sign-magnitude image followed by the int8 main loop's image; ok is False when some row's integer

@@ -94,11 +94,12 @@ def test_one_launch_against_three(lq, M, K, N, r, dtype):
     xd[5] = 0  # an all-zero row (scale 1, zero image, zero x A)
     mod(xd[:128])  # builds the images
     img3, sc3, xa3 = _act_side(mod, xd, _lib.TUNE_ACT8_SPLIT)
-    img1, sc1, xa1 = _act_side(mod, xd, 0)
-    # (the one-launch kernel really ran: its x A is summed in another order than the split-K partial tiles - not bit-equal in general -,
-    # and pinning it at any M gives the default's bits)
-    imgf, scf, xaf = _act_side(mod, xd, _lib.TUNE_ACT8_FUSED)
-    assert torch.equal(img1, imgf) and torch.equal(sc1, scf) and torch.equal(xa1, xaf)
+    img1, sc1, xa1 = _act_side(mod, xd, _lib.TUNE_ACT8_FUSED)  # the one launch, at every token count
+    # the default takes it from 1024 to 4096 tokens (below, a grid of M / 8 workgroups leaves most CUs idle; above, every workgroup's
+    # pass over A^T costs more than the launches): the default's bits are those of the route it names
+    imgd, scd, xad = _act_side(mod, xd, 0)
+    want = (img1, sc1, xa1) if 1024 <= M <= 4096 else (img3, sc3, xa3)
+    assert torch.equal(imgd, want[0]) and torch.equal(scd, want[1]) and torch.equal(xad, want[2])
     # (1) image and scales: bit for bit
     assert torch.equal(img1, img3)
     assert torch.equal(sc1, sc3)
@@ -120,7 +121,7 @@ def test_one_launch_against_three(lq, M, K, N, r, dtype):
     if xa1.shape[1] > r:
         assert float(xa1[:, r:].abs().max()) == 0.0  # padded rank columns
     # (3) run-to-run bit stability (fixed summation order)
-    img2, sc2, xa2 = _act_side(mod, xd, 0)
+    img2, sc2, xa2 = _act_side(mod, xd, _lib.TUNE_ACT8_FUSED)
     assert torch.equal(img2, img1) and torch.equal(sc2, sc1) and torch.equal(xa2, xa1)
 
 
@@ -152,7 +153,7 @@ def test_a_out_in_blocks_of_16(lq):
     mod, x, W, A, B, qc = _module(lq, K, N, r, torch.float16, seed=11, M=M, aout=aout)
     xd = x.half().to(DEV)
     mod(xd[:128])
-    img1, sc1, xa1 = _act_side(mod, xd, 0)
+    img1, sc1, xa1 = _act_side(mod, xd, _lib.TUNE_ACT8_FUSED)
     img3, sc3, xa3 = _act_side(mod, xd, _lib.TUNE_ACT8_SPLIT)
     assert torch.equal(img1, img3) and torch.equal(sc1, sc3)
     s64 = (img1[:, :K].double().cpu().numpy() @ A.half().double().numpy()) * sc1.double().cpu().numpy()[:, None]
@@ -173,11 +174,11 @@ def test_ties_at_every_exponent_through_the_one_launch_kernel(lq):
         x[i] = torch.where(torch.rand(K, generator=g) < 0.5, -1.0, 1.0) * amax * j / 256.0
         x[i, i % K] = amax
     xd = x.half().to(DEV)
-    mod(xd)
-    img, sc, xa = _act_side(mod, xd, 0)
-    ref = O.get_quantizer(qc["x_quantizer"])(x)
-    assert torch.equal((img[:, :K].float() * sc[:, None]).cpu(), torch.where(x.abs() <= 1e-8, torch.zeros_like(ref), ref))
     from lqer_amd import _lib
 
+    mod(xd)
+    img, sc, xa = _act_side(mod, xd, _lib.TUNE_ACT8_FUSED)
+    ref = O.get_quantizer(qc["x_quantizer"])(x)
+    assert torch.equal((img[:, :K].float() * sc[:, None]).cpu(), torch.where(x.abs() <= 1e-8, torch.zeros_like(ref), ref))
     img3, sc3, _ = _act_side(mod, xd, _lib.TUNE_ACT8_SPLIT)
     assert torch.equal(img, img3) and torch.equal(sc, sc3)
