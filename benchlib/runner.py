@@ -599,9 +599,15 @@ def _sustained_clock(ctx, L, run_abi, steps, s_per_step):
         if not mhz:
             return None
         load_ms, probe_end_to_load_end = ev[2].elapsed_time(ev[3]), ev[1].elapsed_time(ev[3])
+        # (two streams can share a hardware queue: the load then waits BEHIND the probe, which reads the idle clock - 2404 MHz in
+        # configs.c5 of round 5 and of the first round-6 run - while every other sign says "inside".  The load's start event tells: it
+        # completes at once when the streams run side by side, only after the probe when they are serialized)
+        start_lag_ms = ev[0].elapsed_time(ev[2])
+        side_by_side = start_lag_ms < 0.25 * dur_us * 1e-3
         return {"median_mhz": round((mhz[(len(mhz) - 1) // 2] + mhz[len(mhz) // 2]) / 2, 1), "min_mhz": round(mhz[0], 1),
                 "max_mhz": round(mhz[-1], 1), "probe_us": dur_us, "steps_under_probe": n, "load_ms": round(load_ms, 3),
-                "inside_load": bool(probe_end_to_load_end >= 0.0 and load_ms * 1e3 >= dur_us),
+                "inside_load": bool(side_by_side and probe_end_to_load_end >= 0.0 and load_ms * 1e3 >= dur_us),
+                "load_start_lag_ms": round(start_lag_ms, 3),
                 "how": "lqer_clock_probe: 4 one-wave workgroups on a side stream, d(s_memtime) / d(s_memrealtime) x 100 MHz over the last "
                        "3/4 of the probe window, back-to-back launches of the dominant GEMM alone (no quantizer launches, the images of the "
                        "last timed step) running beside it right behind the timed region; null when the window missed the load"}

@@ -54,5 +54,3 @@ names = ["requests out", "row landed, maximum known", "quantized, stores issued"
 print(f"M={M} K={K} r={r}: call {e0.elapsed_time(e1) / 20 * 1e3:.1f} us, {wgs} workgroups of 8 rows")
 for i, n in enumerate(names, 1):
     print(f"  {n:32s} {med(b[:, :, i]):8.0f} cycles (min {b[:, :, i].min().item():.0f}, max {b[:, :, i].max().item():.0f})")
-s0 = b[:, 0, 0]
-print(f"  workgroup start spread {(s0.max() - s0.min()).item():.0f} cycles (s_memtime)")
