@@ -106,6 +106,18 @@ def hbm_roofline(gemm_events, ev_overhead_ms, M, r, has_bias, routes, one_launch
           # kernel durations carry 1.5-3 us of instrumentation at this size - profiles/README.md; the bound that
           # needs no calibration is ms_per_step, one launch + one launch gap per forward)
           "avg_launch_us_upper_bound": round(ms_per_step * 1e3, 2) if one_launch else None}
+    if one_launch and n_launch:
+        # Three clocks measure this ~7-us kernel - all three are in the line: `frac` from the events minus the calibrated
+        # pair overhead (the kindest), the trace of a profiled run (r05_kernel_stats_d1.csv: 9.59 us, carries the tracer's per-dispatch cost),
+        # and the kernel's own stamps (first wave's start to last wave's end, a -DLQER_D1_STAMPS build: ~7.0 us at M = 1, committed).
+        by = tot_by / n_launch
+        rl["frac_by_clock"] = {
+            "events_minus_pair_overhead": rl["frac"],
+            "in_kernel_span": {"us": 7.0, "frac": round(by / 7.0e-6 / 1e9 / HBM_PEAK_GBS, 4),
+                               "source": "profiles/r05_decode_lds_ring.txt (stamps build, M = 1; not re-measured in this run)"},
+            "rocprofv3_trace": {"us": 9.59, "frac": round(by / 9.59e-6 / 1e9 / HBM_PEAK_GBS, 4),
+                                "source": "profiles/r05_kernel_stats_d1.csv (profiled run; not re-measured in this run)"},
+            "whole_step": {"us": round(ms_per_step * 1e3, 2), "frac": round(by / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     if resident_fig is not None:  # the same launches on ONE weight that stays in the Infinity Cache (an upper bound)
         rms = sum(max(e0.elapsed_time(e1) - ev_overhead_ms, 1e-6) for e0, e1, _, _ in resident_fig["events"])
         rn = max(len(resident_fig["events"]), 1)

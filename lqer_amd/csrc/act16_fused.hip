@@ -67,11 +67,22 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
           f[i][t] = fr[((int64_t)(st < nst ? st : 0) * RT + t) * 64];
         }
     };
-    load_part(fa, 0);
-    load_part(fb, 1);
+    // (requested in the MIDDLE of the quantizer's loop, not beside the rows: the texture path's queue is shallow - a wave that issues 32
+    // fragment requests in a row stands still until the path has taken them, and with it its rows' arithmetic: act8_fused.hip found the
+    // same, tools/clock_probe_a8.py)
     // ---- quantize: the lane's 8 values of each row; the block's other half sits in lane ^ 1
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
+      if (r == 2) {
+        asm volatile("" ::: "memory");
+        load_part(fa, 0);
+        asm volatile("" ::: "memory");
+      }
+      if (r == 5) {
+        asm volatile("" ::: "memory");
+        load_part(fb, 1);
+        asm volatile("" ::: "memory");
+      }
       float v[8];
       const uint32_t wd[4] = {raw[r][0], raw[r][1], raw[r][2], raw[r][3]};
 #pragma unroll

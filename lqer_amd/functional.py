@@ -33,6 +33,12 @@ def _quantize(t: torch.Tensor, cfg: dict) -> torch.Tensor:
         raise NotImplementedError(f"lqer_amd.functional: quantizer {name!r} is not implemented on the HIP path")
     ops._need_gpu(t)
     fmt = ops.make_qfmt(cfg)
+    if getattr(fmt, "act_tiles", None) is not None:
+        # blocks that can span rows (incl. the quantizer's default lone [L], which the reference right-aligns to [1, S, L] on a 3-D operand,
+        # quantizers/utils.py:56-66, 211-237): the HIP tile quantizer, as the reference blocks this very tensor (2-D / 3-D; else its error)
+        if t.dim() not in (2, 3):
+            raise RuntimeError(f"Unsupported x.ndim = {t.dim()}")  # (quantizers/utils.py:284)
+        return ops.quantize_act_tiles(t, fmt)
     if fmt.block > 0 and fmt.block < t.shape[-1] and fmt.block % 16:
         raise NotImplementedError(f"lqer_amd.functional: block_size {cfg.get('block_size')} - the quantizer kernels take blocks of 16 n "
                                   "elements or whole rows along the last dim")
@@ -49,6 +55,8 @@ def _fused_fmt(cfg: dict):
         fmt = ops.make_qfmt(cfg, "x")
     except NotImplementedError:
         return None
+    if getattr(fmt, "act_tiles", None) is not None:
+        return None  # (blocks that can span rows: the tile quantizer + the library product, _quantize above)
     return fmt if (fmt.block <= 0 or fmt.block % 16 == 0) else None
 
 

@@ -557,6 +557,12 @@ def test_quantized_matmul_blocks_other_than_16(ops, monkeypatch):
             assert float((out.float().cpu() - ref).norm() / ref.norm()) <= tol, (bx, by, dtype)
     with pytest.raises(NotImplementedError):  # a block length the quantizer kernels do not have (not 16 n): refused, never approximated
         lqer_amd.matmul_flexible(t("b32/x"), t("b32/y"), dict(cfgs["b32"], x_quantizer=bfp(24)))
+    # (round 6) the quantizer's default lone [16] on 3-D operands = [1, S, 16] tiles over all rows of a batch element: the HIP tile
+    # quantizer + the library product (rounds 1-5 read it per row), against the reference's vector
+    monkeypatch.undo()
+    out = lqer_amd.matmul_flexible(t("lone/x"), t("lone/y"), cfgs["lone"]).cpu()
+    ref = torch.from_numpy(g["lone/out"])
+    assert float((out - ref).norm() / ref.norm()) <= 1e-6
 
 
 def test_fused_quantized_matmul_takes_4d_operands_and_large_batches(ops, monkeypatch):

@@ -154,6 +154,8 @@ def test_oracle_quantized_matmuls_vs_reference_vectors():
     for name in ("b32", "brow"):
         out = O.matmul_flexible(torch.from_numpy(g[f"{name}/x"]), torch.from_numpy(g[f"{name}/y"]), blk[name])
         assert torch.equal(out, torch.from_numpy(g[f"{name}/out"])), name
+    out = O.matmul_flexible(torch.from_numpy(g["lone/x"]), torch.from_numpy(g["lone/y"]), blk["lone"])  # (round 6: a lone [16] = [1, S, 16] tiles)
+    assert float((out - torch.from_numpy(g["lone/out"])).norm() / torch.from_numpy(g["lone/out"]).norm()) <= 1e-6
     for name, fn in (("qk", O.matmul_flexible), ("pv", O.matmul_flexible), ("bmm", O.bmm_flexible)):
         out = fn(torch.from_numpy(g[f"{name}/x"]), torch.from_numpy(g[f"{name}/y"]), qc)
         assert torch.equal(out, torch.from_numpy(g[f"{name}/out"])), name
