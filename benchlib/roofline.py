@@ -53,6 +53,21 @@ def _kernel_names(routes, one_launch, _lib):
     return "+".join(kname.get(rt, str(rt)) for rt in routes)
 
 
+# The dominant kernel's MAIN-LOOP clock, from the committed stamp builds (s_memtime / s_memrealtime around the main loop of every wave:
+# tools/clock_probe_i8.py, tools/clock_probe.py).  `sustained_mhz` (the probe beside back-to-back launches) averages a whole launch -
+# prologue and epilogue run without the matrix pipe and clock ~2.1 GHz - so it reads above these; quoted, not re-measured in a bench run.
+MAIN_LOOP_CLOCK_MHZ = {
+    "c2int": (1598, "profiles/r06_i8_timeline.txt (2048 x 4096 x 4096: 1,183 cycles per 128-k step at 1.598 GHz)"),
+    "c2introw": (1598, "profiles/r06_i8_timeline.txt (the same kernel and shape)"),
+    "c3int": (1560, "profiles/r06_i8_timeline.txt (1.598 GHz at K = 4096, 1.488 GHz at K = 11008, ~2.09 GHz on the three-round N = 11008 "
+                    "launch's last tile: the one-round shapes' launch-weighted mean)"),
+    "c4": (1586, "tools/clock_probe_i8.py --M 16384 --K 5120 --N 5120 --r 64 on the round-6 build (2,096 cycles per step at 1.586 GHz; "
+                 "profiles/r04_i8_timeline_block128.txt: 1.61)"),
+    "c4row": (1711, "profiles/r04_i8_timeline_row.txt (one block per row: 2,128 cycles per step at 1.711 GHz)"),
+    "c2": (1570, "profiles/r04_c2_gemm_timeline.txt (1,133 cycles per k-step at 1.570 GHz; the kernel's main loop has not changed since)"),
+}
+
+
 def mfma_roofline(gemm_events, ev_overhead_ms, M, r, routes, int8, one_launch, _lib, workload, ev_flags):
     """Dominant kernel = the fused GEMM; algorithmic FLOPs per launch = 2MKN + 2MrN.  `per_shape`: the same
     per projection shape (K, N) of the workload."""
@@ -79,7 +94,9 @@ def mfma_roofline(gemm_events, ev_overhead_ms, M, r, routes, int8, one_launch, _
             "traffic_source": traffic_source, "kernel": _kernel_names(routes, one_launch, _lib),
             "avg_launch_us": round(tot_ms / max(n_launch, 1) * 1e3, 2), "launches": n_launch, "per_shape": per_shape,
             "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2), "event_flags": hex(ev_flags),
-            "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4)}
+            "frac_of_int8_peak": round(ach / INT8_MFMA_PEAK_TOPS, 4),
+            "main_loop_clock_mhz": (MAIN_LOOP_CLOCK_MHZ.get(workload) or (None, None))[0],
+            "main_loop_clock_source": (MAIN_LOOP_CLOCK_MHZ.get(workload) or (None, None))[1]}
 
 
 def hbm_roofline(gemm_events, ev_overhead_ms, M, r, has_bias, routes, one_launch, _lib, workload, ev_flags, rotate, ms_per_step,
