@@ -579,38 +579,45 @@ def _sustained_clock(ctx, L, run_abi, steps, s_per_step):
         n = max(2, min(steps, int(4e-3 / max(s_per_step, 1e-6)) + 1))
         dur_us = int(min(max(0.6 * n * s_per_step * 1e6, 200.0), 20000.0))
         n = max(n, int(dur_us * 1e-6 / max(s_per_step, 1e-6) * 1.4) + 1)  # (the load outlasts the probe)
-        side = torch.cuda.Stream(dev)
         main = torch.cuda.current_stream(dev)
         buf = torch.zeros(8, dtype=torch.int64, device=dev)
         run_abi(min(n, 4))  # (the clock the load holds, not the ramp from idle)
-        torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record(side)
-        rc = L.lqer_clock_probe(buf.data_ptr(), 4, dur_us, side.cuda_stream)
-        ev[1].record(side)
-        if rc:
-            return None
-        ev[2].record(main)
-        run_abi(n)
-        ev[3].record(main)
-        torch.cuda.synchronize()
-        pairs = buf.cpu().view(4, 2).double()
-        mhz = sorted(float(c / t * 100.0) for c, t in pairs.tolist() if t > 0)
-        if not mhz:
-            return None
-        load_ms, probe_end_to_load_end = ev[2].elapsed_time(ev[3]), ev[1].elapsed_time(ev[3])
-        # (two streams can share a hardware queue: the load then waits BEHIND the probe, which reads the idle clock - 2404 MHz in
-        # configs.c5 of round 5 and of the first round-6 run - while every other sign says "inside".  The load's start event tells: it
-        # completes at once when the streams run side by side, only after the probe when they are serialized)
-        start_lag_ms = ev[0].elapsed_time(ev[2])
-        side_by_side = start_lag_ms < 0.25 * dur_us * 1e-3
-        return {"median_mhz": round((mhz[(len(mhz) - 1) // 2] + mhz[len(mhz) // 2]) / 2, 1), "min_mhz": round(mhz[0], 1),
-                "max_mhz": round(mhz[-1], 1), "probe_us": dur_us, "steps_under_probe": n, "load_ms": round(load_ms, 3),
-                "inside_load": bool(side_by_side and probe_end_to_load_end >= 0.0 and load_ms * 1e3 >= dur_us),
-                "load_start_lag_ms": round(start_lag_ms, 3),
-                "how": "lqer_clock_probe: 4 one-wave workgroups on a side stream, d(s_memtime) / d(s_memrealtime) x 100 MHz over the last "
-                       "3/4 of the probe window, back-to-back launches of the dominant GEMM alone (no quantizer launches, the images of the "
-                       "last timed step) running beside it right behind the timed region; null when the window missed the load"}
+        rec, sides = None, []
+        # Two streams can share a hardware queue: the load then waits BEHIND the probe, which reads the idle clock (2404 MHz in configs.c5
+        # of round 5) while every other sign says "inside".  The load's start event tells - it completes at once when the streams run
+        # side by side, only after the probe when they are serialized -, and a fresh side stream lands on another queue: up to 4 attempts.
+        for attempt in range(4):
+            side = torch.cuda.Stream(dev)
+            sides.append(side)  # (kept alive: a destroyed stream's queue slot would be handed out again)
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record(side)
+            rc = L.lqer_clock_probe(buf.data_ptr(), 4, dur_us, side.cuda_stream)
+            ev[1].record(side)
+            if rc:
+                return None
+            ev[2].record(main)
+            run_abi(n)
+            ev[3].record(main)
+            torch.cuda.synchronize()
+            pairs = buf.cpu().view(4, 2).double()
+            mhz = sorted(float(c / t * 100.0) for c, t in pairs.tolist() if t > 0)
+            if not mhz:
+                return None
+            load_ms, probe_end_to_load_end = ev[2].elapsed_time(ev[3]), ev[1].elapsed_time(ev[3])
+            start_lag_ms = ev[0].elapsed_time(ev[2])
+            side_by_side = start_lag_ms < 0.25 * dur_us * 1e-3
+            rec = {"median_mhz": round((mhz[(len(mhz) - 1) // 2] + mhz[len(mhz) // 2]) / 2, 1), "min_mhz": round(mhz[0], 1),
+                   "max_mhz": round(mhz[-1], 1), "probe_us": dur_us, "steps_under_probe": n, "load_ms": round(load_ms, 3),
+                   "inside_load": bool(side_by_side and probe_end_to_load_end >= 0.0 and load_ms * 1e3 >= dur_us),
+                   "load_start_lag_ms": round(start_lag_ms, 3), "attempts": attempt + 1,
+                   "how": "lqer_clock_probe: 4 one-wave workgroups on a side stream, d(s_memtime) / d(s_memrealtime) x 100 MHz over the last "
+                          "3/4 of the probe window, back-to-back launches of the dominant GEMM alone (no quantizer launches, the images of "
+                          "the last timed step) running beside it right behind the timed region; a fresh side stream per attempt until "
+                          "the load starts beside the probe; null when the window missed the load"}
+            if rec["inside_load"]:
+                break
+        return rec
     except Exception as e:  # noqa: BLE001 (a diagnostic must not cost the bench line)
         print(f"# sustained clock probe failed: {type(e).__name__}: {e}", file=sys.stderr)
         return None

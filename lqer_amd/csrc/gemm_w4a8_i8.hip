@@ -1472,7 +1472,8 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // 16-deep slice) pairs - rank 64 with fp16 A / B, rank 128 with 8-bit A / B -, else re-fetched from L2 for every token
   // tile.  Their latency passes under the conversion of the integer tile (below).
   // exchange: the granules of this tile's 32 row quads x every column tile (4 KiB), requested now by LDS-DMA (no registers held across
-  // the conversion pass; sc1) into activation slot 3: wave w (0, 1) brings quads 16 w .. 16 w + 15 with two requests - request j, lane l:
+  // the conversion pass; first read at sc0 - XCH_GATHER_AUX - or, with XCD tile blocks, sc1) into the gather region behind the xAq panel
+  // (round 6; it was activation slot 3): wave w (0, 1) brings quads 16 w .. 16 w + 15 with two requests - request j, lane l:
   // quad 8 j + l / 8, piece l % 8 (16 B = the granules of column tiles 2 p, 2 p + 1) - and reads back what it requested itself
   // (vmcnt, no barrier).  The round trip passes under the staging and the conversion.
   const int tid_e = wave * 64 + lane;
