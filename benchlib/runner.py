@@ -222,7 +222,12 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
 
     # the C-ABI calls of a step with their arguments bound once per stream (the launch stream, or the capture stream of
     # --graph): at decode sizes the Python that assembles 16 arguments per call costs as much as the kernel it launches
-    fwd, qxa, gemm = L.lqer_linear_forward, L.lqer_quantize_act_xa, L.lqer_linear_gemm
+    # (the split calls are the ABI-13 pair: the hand-over of the GEMM pre-pass's zero fill that lqer_linear_forward does internally)
+    fwd, qxa, gemm = L.lqer_linear_forward, L.lqer_quantize_act_xa_prep, L.lqer_linear_gemm_prepared
+    ready = C.c_size_t(0)  # written by every activation call, read by the GEMM call right behind it (one host thread)
+    ready_ref = C.byref(ready)
+    no_prep = bool(os.environ.get("LQER_BENCH_NO_PREP"))  # (A/B: the GEMM zero-fills its cells itself, as lqer_linear_gemm does)
+    gemm_call = lambda ga, rdy=0: gemm(*ga[:-1], 0 if no_prep else rdy, ga[-1])
     bound = {}
     # event pairs for the sampled launches, created ahead of the timed region (creating one costs more host time than a
     # decode-size kernel runs)
@@ -239,7 +244,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
                 fa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["w"], pl["a_t"], pl["b_t"], pl["a_limbs"], pl["b_limbs"], pl["bias"],
                       pl["y"], N, pl["ws"], pl["ws_bytes"], st)
                 xaq, gscr = (None, pl["nscr"]) if pl["part"] else (pl["xaq"], pl["gscr"])
-                qa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"], pl["xq"], xaq, pl["xscr"], pl["nscr"], st)
+                qa = (pl["dref"], pl["x"], _lib.F16, M, K, pl["a_t"], pl["a_limbs"], pl["xq"], xaq, pl["xscr"], pl["nscr"], pl["xscr"], ready_ref, st)
                 ga = (pl["dref"], pl["xq"], M, pl["w"], xaq, pl["b_t"], pl["b_limbs"], pl["bias"], pl["y"], _lib.F16, N,
                       pl["xscr"], gscr, st)
                 per_unit = [(fa, qa, ga)]
@@ -247,7 +252,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
                     per_unit.append(((pl["dref"], pl["x"], _lib.F16, M, K, cw, ca, cb, pl["a_limbs"], pl["b_limbs"], cbias,
                                       pl["y"], N, pl["ws"], pl["ws_bytes"], st),
                                      (pl["dref"], pl["x"], _lib.F16, M, K, ca, pl["a_limbs"], pl["xq"], xaq, pl["xscr"],
-                                      pl["nscr"], st),
+                                      pl["nscr"], pl["xscr"], ready_ref, st),
                                      (pl["dref"], pl["xq"], M, cw, xaq, cb, pl["b_limbs"], cbias, pl["y"], _lib.F16, N,
                                       pl["xscr"], gscr, st)))
                 rows.append((pl["reps"], K, N, per_unit))
@@ -290,7 +295,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
                 if ev:
                     e0, e1 = ev_pool.pop() if ev_pool else new_pair()
                     e0.record(stream)
-                rc = gemm(*ga)
+                rc = gemm_call(ga, ready.value)
                 if rc:
                     _lib.check(rc, "linear_gemm")
                 if ev:
@@ -368,7 +373,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         for _ in range(n):
             for reps, K, N, per_unit in rows:
                 for u in range(reps):
-                    rc = gemm(*per_unit[u % len(per_unit)][2])
+                    rc = gemm_call(per_unit[u % len(per_unit)][2])
                     if rc:
                         _lib.check(rc, "linear_gemm")
 
@@ -433,7 +438,7 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
     # one-stream figure (a model's Linears form a chain: 8d sums their times)
     two_streams = None
     if o.two_streams and layers_here > 0 and M > 64 and graph is None and world == 1:
-        two_streams = _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm, M, warmup, steps, elapsed)
+        two_streams = _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm_call, ready, M, warmup, steps, elapsed)
 
     # decode workloads (M <= 8): the Linears a model hands the SAME token to - q/k/v - as ONE launch (lqer_linear_forward_group)
     group_fig = None
@@ -671,7 +676,7 @@ def _shared_inputs_region(ctx, live, layers_here, warmup, steps, elapsed):
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 
 
-def _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm, M, warmup, steps, elapsed):
+def _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm_call, ready, M, warmup, steps, elapsed):
     from lqer_amd import _lib, sweep
 
     dev = ctx.dev
@@ -698,7 +703,7 @@ def _two_streams_region(ctx, live, plans, ws, calls_for, qxa, gemm, M, warmup, s
                         on_b.add((i, u % len(pa)))
                     _, qa, ga = (pa if unit_no[0] % 2 == 0 else pb)[u % len(pa)]
                     unit_no[0] += 1
-                    rc = qxa(*qa) or gemm(*ga)
+                    rc = qxa(*qa) or gemm_call(ga, ready.value)
                     if rc:
                         _lib.check(rc, "two-stream step")
 

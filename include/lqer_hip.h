@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LQER_ABI_VERSION 12
+#define LQER_ABI_VERSION 13
 
 /* error codes */
 #define LQER_OK 0
@@ -284,6 +284,23 @@ int lqer_linear_gemm(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_
                      const void* w_packed, const void* xaq_bf16, const void* b_t, int b_limbs,
                      const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
                      size_t scratch_bytes, void* stream);
+/* The zero fill of lqer_linear_gemm's pre-pass, handed to the activation call in front of it (ABI 13).  Launches whose B_out blocks
+ * differ from 16 columns and whose grid is more than one round of tiles start with a pre-pass that folds the row-block maxima of
+ * xAq @ B with atomicMax into cells at the head of `scratch`, which lqer_linear_gemm zero-fills first - a memset launch between two
+ * kernels (4.8 us of a 116-us forward at 2048 x 4096 -> 11008, rank 32).  lqer_quantize_act_xa_prep is lqer_quantize_act_xa which,
+ * where its work runs as the one-launch int8 kernel (csrc/act8_fused.hip: LQER_Q_MXINT_I8, a_limbs = -1, 1024..4096 tokens), lets that
+ * kernel write those zeros to `gemm_scratch` (one store per thread) and reports in *ready_bytes how many bytes at its head are ready -
+ * 0 when nothing was prepared (another route, or a GEMM that needs none).  lqer_linear_gemm_prepared is lqer_linear_gemm which skips
+ * its own zero fill when ready_bytes covers its cells.  The caller's side of the contract: the same gemm_scratch / scratch pointer,
+ * the same stream, and nothing else writing that scratch between the two calls (it may alias the first call's own `scratch`: the
+ * one-launch kernel does not use it).  lqer_linear_forward does this hand-over on its own; same results either way. */
+int lqer_quantize_act_xa_prep(const lqer_linear_desc_t* desc, const void* x, int dtype, int64_t M,
+                              int64_t ldx, const void* a_t, int a_limbs, void* xq_bf16, void* xaq_bf16,
+                              void* scratch, size_t scratch_bytes, void* gemm_scratch, size_t* ready_bytes, void* stream);
+int lqer_linear_gemm_prepared(const lqer_linear_desc_t* desc, const void* xq_bf16, int64_t M,
+                              const void* w_packed, const void* xaq_bf16, const void* b_t, int b_limbs,
+                              const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
+                              size_t scratch_bytes, size_t ready_bytes, void* stream);
 
 /* Which GEMM kernel lqer_linear_gemm launches for `M` tokens of this descriptor and element type (the choice depends on
  * nothing else): LQER_ROUTE_SMALLM (M <= 64: one workgroup per 16 output columns streams its packed weight rows),

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LQER_AMD_LIB") or os.path.join(_HERE, "liblqer_hip.so")
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 F32, F16, BF16 = 0, 1, 2
 Q_PASSTHROUGH, Q_MXINT, Q_PASSTHROUGH_F16, Q_MXINT_I8, Q_INT = 0, 1, 2, 3, 4
 K_ALIGN, M_ALIGN, N_ALIGN, R_ALIGN = 64, 256, 256, 16
@@ -89,6 +89,9 @@ SIGNATURES = {
     "lqer_lowrank_xa": (_i, [_dp, _vp, _i64, _vp, _i, _vp, _vp, _sz, _vp]),
     "lqer_linear_gemm_scratch_bytes": (_sz, [_dp, _i64]),
     "lqer_linear_gemm": (_i, [_dp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),
+    # (ABI 13) the GEMM pre-pass's zero fill written by the one-launch int8 activation kernel in front of it
+    "lqer_quantize_act_xa_prep": (_i, [_dp, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp, _vp, _sz, _vp, C.POINTER(_sz), _vp]),
+    "lqer_linear_gemm_prepared": (_i, [_dp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _sz, _vp]),
     "lqer_linear_gemm_ld": (_i, [_dp, _vp, _i64, _vp, _vp, _i64, _vp, _i, _vp, _vp, _i, _i64, _vp, _sz, _vp]),
     "lqer_desc_limbs": (_i, [_dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lqer_replicate_rows": (_i, [_vp, _vp, _i64, _i64, _i, _vp]),

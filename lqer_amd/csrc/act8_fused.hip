@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_a_frag(const _Float16* __restrict__ a16
 template <int DT, int MAXCH, int RT>
 __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, int64_t M, int64_t K, int64_t ld, QP qx, int8_t* __restrict__ xq8,
                                                      int64_t cols_p8, float* __restrict__ xscale, const _Float16* __restrict__ a_frag, QP qa,
-                                                     int L_aout, bf16_t* __restrict__ xaq) {
+                                                     int L_aout, bf16_t* __restrict__ xaq, float* __restrict__ zero_p, int zero_n) {
   constexpr int RP = 16 * RT;
   constexpr int SB = 16 / RT;  // steps per batch of A^T fragments (16 fragments = 64 registers per set)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -78,6 +78,9 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
   // ---- requests: the row, then the first batch of this wave's A^T fragments (independent of the row: their latency passes under the
   // quantizer's arithmetic)
   const u32x4* p = (const u32x4*)((const bf16_t*)x + row * ld);
+  // (the GEMM's pre-pass behind this launch wants its atomicMax cells zero - gemm_amax_zero_bytes: one store per thread here instead of a
+  // memset launch there)
+  if ((int)(blockIdx.x * 512 + threadIdx.x) < zero_n) zero_p[blockIdx.x * 512 + threadIdx.x] = 0.f;
   // register u of lane l holds chunk 2 l + (u & 1) + 128 (u >> 1): a lane's registers 2 v, 2 v + 1 are NEIGHBOURING chunks, so their 16
   // mantissas leave as ONE 16-byte store (a KiB per wave instruction, to the image and to the LDS slab) - half the store instructions
   // of k_quant_row8's lane + 64 u order, which cost the texture path a full slot for 512 bytes each
@@ -258,14 +261,14 @@ __global__ __launch_bounds__(512) void k_act8_fused(const void* __restrict__ x, 
 
 template <int DT, int MAXCH>
 static int launch(const void* x, int64_t M, int64_t K, int64_t ld, const QP& qx, int8_t* xq8, int64_t cols_p8, float* xscale, const _Float16* a_frag,
-                  const QP& qa, int L, int rp, bf16_t* xaq, hipStream_t st) {
+                  const QP& qa, int L, int rp, bf16_t* xaq, float* zero_p, int zero_n, hipStream_t st) {
   const unsigned grid = (unsigned)((M + ROWS - 1) / ROWS);
   const int lds = (int)lds_bytes(cols_p8, rp);
 #define A8F_LAUNCH(RTv)                                                                                                            \
   do {                                                                                                                             \
     static LdsLimitOnce once;                                                                                                      \
     once.set((const void*)k_act8_fused<DT, MAXCH, RTv>, 160 * 1024);                                                                \
-    k_act8_fused<DT, MAXCH, RTv><<<grid, 512, lds, st>>>(x, M, K, ld, qx, xq8, cols_p8, xscale, a_frag, qa, L, xaq);                  \
+    k_act8_fused<DT, MAXCH, RTv><<<grid, 512, lds, st>>>(x, M, K, ld, qx, xq8, cols_p8, xscale, a_frag, qa, L, xaq, zero_p, zero_n); \
   } while (0)
   switch (rp / 16) {
     case 1: A8F_LAUNCH(1); break;
@@ -299,7 +302,8 @@ int a_frag_dispatch(void* a_f16, int64_t K, int64_t r, hipStream_t st) {
 
 // LQER_E_UNSUPPORTED: not this kernel's case (the caller takes the three-launch route)
 int act8_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, void* xq_i8, const void* a_f16, int64_t r,
-                        const QP& qa, bf16_t* xaq, int tuning, hipStream_t st) {
+                        const QP& qa, bf16_t* xaq, int tuning, hipStream_t st, float* zero_p, size_t zero_bytes, bool* zeroed) {
+  if (zeroed) *zeroed = false;
 #ifdef LQER_NO_ACT8_FUSED
   return LQER_E_UNSUPPORTED;
 #endif
@@ -325,12 +329,17 @@ int act8_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t 
   int8_t* const xq8 = (int8_t*)xq_i8;
   float* const xscale = const_cast<float*>(i8_row_scales(xq_i8, M, K));
   const _Float16* const a_frag = (const _Float16*)a_f16 + rp * lqer_padded_k(K);
+  // zero fill on the GEMM's behalf: one store per thread of the grid, or not at all (the caller keeps its memset)
+  const bool zfit = zero_p && zero_bytes > 0 && zero_bytes / 4 <= (size_t)((M + a8f::ROWS - 1) / a8f::ROWS) * 512;
+  float* const zp = zfit ? zero_p : nullptr;
+  const int zn = zfit ? (int)(zero_bytes / 4) : 0;
+  if (zeroed) *zeroed = zfit;  // (every return below this line that is not LQER_E_UNSUPPORTED has launched the kernel)
 #define A8F_DT(DTv)                                                                                                                       \
   do {                                                                                                                                    \
-    if (nch_p <= 64 * 8) return a8f::launch<DTv, 8>(x, M, K, ldx, qx, xq8, cols_p8, xscale, a_frag, qa, L, (int)rp, xaq, st);               \
-    if (nch_p <= 64 * 12) return a8f::launch<DTv, 12>(x, M, K, ldx, qx, xq8, cols_p8, xscale, a_frag, qa, L, (int)rp, xaq, st);             \
+    if (nch_p <= 64 * 8) return a8f::launch<DTv, 8>(x, M, K, ldx, qx, xq8, cols_p8, xscale, a_frag, qa, L, (int)rp, xaq, zp, zn, st);       \
+    if (nch_p <= 64 * 12) return a8f::launch<DTv, 12>(x, M, K, ldx, qx, xq8, cols_p8, xscale, a_frag, qa, L, (int)rp, xaq, zp, zn, st);     \
     if constexpr (DTv == LQER_F16) /* (bf16 rows beyond 6144 elements: 112 raw registers + the wider conversion spill - three launches) */ \
-      if (nch_p <= 64 * 28) return a8f::launch<DTv, 28>(x, M, K, ldx, qx, xq8, cols_p8, xscale, a_frag, qa, L, (int)rp, xaq, st);           \
+      if (nch_p <= 64 * 28) return a8f::launch<DTv, 28>(x, M, K, ldx, qx, xq8, cols_p8, xscale, a_frag, qa, L, (int)rp, xaq, zp, zn, st);   \
   } while (0)
   if (dtype == LQER_F16) A8F_DT(LQER_F16);
   else if (dtype == LQER_BF16) A8F_DT(LQER_BF16);

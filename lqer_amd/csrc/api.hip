@@ -465,29 +465,64 @@ int lqer_lowrank_xa(const lqer_linear_desc_t* d, const void* xq, int64_t M, cons
                              (bf16_t*)xaq, (float*)scratch, scratch_bytes, (hipStream_t)stream);
 }
 
+// lqer_linear_forward only: the GEMM call behind this one wants `bytes` at the head of the shared scratch zeroed (gemm_amax_zero_bytes);
+// `done` says whether a kernel of this call wrote the zeros (the one-launch int8 activation kernel does, the other routes do not)
+struct AmaxZeroReq {
+  void* p;       // head of the scratch the GEMM call will be handed
+  size_t bytes;
+  bool done;
+};
+static int gemm_shape_args(const lqer_linear_desc_t* d, int64_t M, int dtype, GemmArgs& g);
+// the request for M tokens of this descriptor: bytes > 0 when the GEMM launches a pre-pass on atomicMax cells
+static AmaxZeroReq amax_zero_request(const lqer_linear_desc_t* d, int64_t M, int dtype, int a_limbs, void* gemm_scratch) {
+  AmaxZeroReq zr{gemm_scratch, 0, false};
+  if (d && gemm_scratch && d->rank > 0 && x_is_i8(d) && a_limbs == -1 && M > 0) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    if (gemm_shape_args(d, M, dtype, g) == LQER_OK) zr.bytes = gemm_amax_zero_bytes(g, true);
+  }
+  return zr;
+}
 static int quantize_act_xa_single(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
-                                  int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream);
+                                  int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream, AmaxZeroReq* zr);
+static int quantize_act_xa_impl(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
+                                int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream, AmaxZeroReq* zr);
 
 int lqer_quantize_act_xa(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
                          int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream) {
+  return quantize_act_xa_impl(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, scratch, scratch_bytes, stream, nullptr);
+}
+
+int lqer_quantize_act_xa_prep(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
+                              int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* gemm_scratch,
+                              size_t* ready_bytes, void* stream) {
+  if (ready_bytes) *ready_bytes = 0;
+  AmaxZeroReq zr = amax_zero_request(d, M, dtype, a_limbs, ready_bytes ? gemm_scratch : nullptr);
+  const int rc = quantize_act_xa_impl(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, scratch, scratch_bytes, stream, &zr);
+  if (rc == LQER_OK && ready_bytes && zr.done) *ready_bytes = zr.bytes;
+  return rc;
+}
+
+static int quantize_act_xa_impl(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
+                                int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream, AmaxZeroReq* zr) {
   if (!d || (!x && M > 0) || !xq || M < 0 || ldx < d->in_features) {
     set_error("quantize_act_xa: bad argument");
     return LQER_E_INVALID;
   }
   if (!fmt_ok(&d->w_fmt, "w_quantizer", 8)) return LQER_E_UNSUPPORTED;
   const int wl = w_limbs(d);
-  if (wl == 1) return quantize_act_xa_single(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, scratch, scratch_bytes, stream);
+  if (wl == 1) return quantize_act_xa_single(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, scratch, scratch_bytes, stream, zr);
   // a weight of three 4-bit limbs: the quantizer and the side GEMM work on the single-copy image behind the wide one, which is
   // then written as three copies side by side along k (one per weight limb) for the GEMM
   if (!passthrough_width_ok(d->x_fmt, "x_quantizer")) return LQER_E_INVALID;
   void* const one = act_single_copy(d, xq, M);
-  const int rc = quantize_act_xa_single(d, x, dtype, M, ldx, a_t, a_limbs, one, xaq, scratch, scratch_bytes, stream);
+  const int rc = quantize_act_xa_single(d, x, dtype, M, ldx, a_t, a_limbs, one, xaq, scratch, scratch_bytes, stream, zr);
   if (rc || M == 0) return rc;
   return lqer_replicate_rows(one, xq, M, lqer_padded_k(d->in_features) * 2 * act_limbs(d), wl, stream);
 }
 
 static int quantize_act_xa_single(const lqer_linear_desc_t* d, const void* x, int dtype, int64_t M, int64_t ldx, const void* a_t,
-                                  int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream) {
+                                  int a_limbs, void* xq, void* xaq, void* scratch, size_t scratch_bytes, void* stream, AmaxZeroReq* zr) {
   if (a_limbs == -2) {
     // the bf16 image of A^T with its fragment-major copy (lqer_a_b16_prepare): block-16 MXINT activations run quantizer + x A + A_out as
     // ONE launch where act16_fused.hip applies; everything else reads the image's first part as the one-limb image it is
@@ -540,8 +575,11 @@ static int quantize_act_xa_single(const lqer_linear_desc_t* d, const void* x, in
     if (d->rank > 0 && a_t && xaq && a_limbs == -1) {
       lqer_qfmt_t fx = d->x_fmt;
       fx.kind = LQER_Q_MXINT, fx.block = -1;
+      const bool zreq = zr && zr->bytes > 0 && zr->p;
+      bool zeroed = false;
       rc = act8_fused_dispatch(x, dtype, M, d->in_features, ldx, make_qp(fx), xq, a_t, d->rank, make_qp(d->a_out_fmt), (bf16_t*)xaq,
-                               d->tuning, (hipStream_t)stream);
+                               d->tuning, (hipStream_t)stream, zreq ? (float*)zr->p : nullptr, zreq ? zr->bytes : 0, &zeroed);
+      if (rc == LQER_OK && zr) zr->done = zeroed;
       if (rc != LQER_E_UNSUPPORTED) return rc;
     }
     rc = lqer_quantize_act_i8(x, dtype, M, d->in_features, ldx, &d->x_fmt, xq, stream);
@@ -631,9 +669,31 @@ int lqer_gemm_tile_rows(const lqer_linear_desc_t* d, int64_t M, int dtype) {
   }
 }
 
+static int linear_gemm_impl(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
+                            int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy,
+                            void* scratch, size_t scratch_bytes, void* stream, bool amax_zeroed);
+
 int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
                         int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy,
                         void* scratch, size_t scratch_bytes, void* stream) {
+  return linear_gemm_impl(d, xq, M, w_packed, xaq, xaq_ld, b_t, b_limbs, bias_q, y, dtype, ldy, scratch, scratch_bytes, stream, false);
+}
+
+int lqer_linear_gemm_prepared(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
+                              const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy, void* scratch,
+                              size_t scratch_bytes, size_t ready_bytes, void* stream) {
+  bool zeroed = false;
+  if (d && ready_bytes > 0) {  // (covers this launch's cells?  a_limbs = -1: the request's own condition, met by whoever prepared them)
+    const AmaxZeroReq zr = amax_zero_request(d, M, dtype, -1, scratch);
+    zeroed = zr.bytes > 0 && ready_bytes >= zr.bytes;
+  }
+  return linear_gemm_impl(d, xq, M, w_packed, xaq, d ? lqer_padded_r(d->rank) * xa_limbs(d) : 0, b_t, b_limbs, bias_q, y, dtype, ldy,
+                          scratch, scratch_bytes, stream, zeroed);
+}
+
+static int linear_gemm_impl(const lqer_linear_desc_t* d, const void* xq, int64_t M, const void* w_packed, const void* xaq,
+                            int64_t xaq_ld, const void* b_t, int b_limbs, const float* bias_q, void* y, int dtype, int64_t ldy,
+                            void* scratch, size_t scratch_bytes, void* stream, bool amax_zeroed) {
   if (!d || !xq || !w_packed || !y || M < 0 || ldy < d->out_features) {
     set_error("linear_gemm: bad argument");
     return LQER_E_INVALID;
@@ -680,6 +740,7 @@ int lqer_linear_gemm_ld(const lqer_linear_desc_t* d, const void* xq, int64_t M, 
     g.xa_part = (const float*)scratch;
     g.aout = make_qp(d->a_out_fmt);
   }
+  g.amax_zeroed = amax_zeroed ? 1 : 0;
   return gemm_dispatch(g, dtype, lowrank, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
@@ -766,11 +827,14 @@ int lqer_linear_forward(const lqer_linear_desc_t* d, const void* x, int dtype, i
     return lqer_linear_gemm(d, xq, M, w_packed, nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch, nscr, stream);
   }
 #endif
-  rc = lqer_quantize_act_xa(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, xa_scratch,
-                            lqer_lowrank_xa_scratch_bytes(d, M), stream);
+  // (a pre-pass on atomicMax cells behind the one-launch int8 activation kernel: that kernel zeroes the cells - the two calls share the
+  // scratch, whose size is the larger of their needs - instead of a memset launch between them)
+  AmaxZeroReq zr = amax_zero_request(d, M, dtype, a_limbs, b_t ? xa_scratch : nullptr);
+  const size_t side_bytes = lqer_lowrank_xa_scratch_bytes(d, M), gemm_bytes = lqer_linear_gemm_scratch_bytes(d, M);
+  rc = quantize_act_xa_impl(d, x, dtype, M, ldx, a_t, a_limbs, xq, xaq, xa_scratch, side_bytes, stream, &zr);
   if (rc) return rc;
-  return lqer_linear_gemm(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, b_t, b_limbs, bias_q, y, dtype, ldy, xa_scratch,
-                          lqer_linear_gemm_scratch_bytes(d, M), stream);
+  return linear_gemm_impl(d, xq, M, w_packed, d->rank > 0 ? xaq : nullptr, lqer_padded_r(d->rank) * xa_limbs(d), b_t, b_limbs, bias_q, y, dtype,
+                          ldy, xa_scratch, gemm_bytes, stream, zr.done);
 }
 
 size_t lqer_group_workspace_bytes(int64_t K, int64_t rank_padded_sum) {

@@ -413,6 +413,7 @@ __host__ inline size_t i8_weight8_image_bytes(int64_t N, int64_t K) {
 
 #ifndef LQER_AMAX_NSEG
 #define LQER_AMAX_NSEG 16  // column-segment partials per row of a one-block-per-row B_out (int8 route: k_bout_amax -> k_lqer_gemm_i8)
+#define LQER_AMAX_NSEG_WIDE 32  // ... beyond N = 4096 (more than 8 column tiles per segment otherwise): twice the cells, the same scratch as the exchange's granules
 #endif
 
 // ---- the int8 image of per-token activations: one row's 16-byte chunks of 8 sixteen-bit elements (k_quant_row8 in quantize.hip and
@@ -546,6 +547,7 @@ struct GemmArgs {
   float* bout_amax;     // [Mp][bout_nblk] row-block maxima of xAq @ B (B_out blocks other than 16), else null
   int bout_L, bout_nblk;
   int bout_nseg;        // > 0 (int8 route, one block per row): bout_amax holds [bout_nseg][Mp] column-segment partials (no atomics)
+  int amax_zeroed;      // host side: the atomicMax cells of the pre-pass are zero already (gemm_amax_zero_bytes) - no memset launch
   // int8 route: xq holds the int8 activation image (+ row scales), w8 the two's-complement weight image
   const uint8_t* w8;
   const float* xscale;  // [Mp] row scales 2^(e - mbits) of the int8 activation image
@@ -586,7 +588,8 @@ int act16_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t
 size_t a_b16_image_bytes(int64_t K, int64_t r);
 int a_b16_prepare_dispatch(const void* a_t_limbs, int64_t K, int64_t r, void* out, hipStream_t st);
 int act8_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t ldx, const QP& qx, void* xq_i8, const void* a_f16, int64_t r,
-                        const QP& qa, bf16_t* xaq, int tuning, hipStream_t st);
+                        const QP& qa, bf16_t* xaq, int tuning, hipStream_t st, float* zero_p = nullptr, size_t zero_bytes = 0,
+                        bool* zeroed = nullptr);  // (zero_p: gemm_amax_zero_bytes at the head of the scratch the GEMM call will be handed)
 size_t a_f16_image_bytes(int64_t K, int64_t r);
 int a_frag_dispatch(void* a_f16, int64_t K, int64_t r, hipStream_t st);
 int f16_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, const void* a_limbs_img, int a_limbs, int64_t r, void* a_f16,
@@ -600,6 +603,7 @@ bool xa_fused_partials_ok(const QP& qx, const QP& qa, int64_t r);  // formats th
 void xa_fused_plan(int64_t M, int64_t K, int64_t r, int* nchunk, int64_t* cstride);
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st);
 size_t gemm_scratch_bytes(int64_t m_max, int64_t N, const QP& bout);
+size_t gemm_amax_zero_bytes(GemmArgs g, bool lowrank);
 int gemm_route(const GemmArgs& g, bool lowrank);  // LQER_ROUTE_* the dispatch would take (or an error code)
 int gemm_tile_rows(const GemmArgs& g);  // 128, or 64 for token counts that leave the 128-row grid thin (LQER_ROUTE_TILE128 family)
 bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) rounds with 256 x 256 tiles

@@ -1146,6 +1146,52 @@ int gemm_tile_rows(const GemmArgs& g) {
   return BM;
 }
 
+// How a launch with one or more B_out blocks per row (bout == 2, block_fp; g.bout_nblk set) gets its row-block maxima:
+//   xch   - one round of the int8 kernel's 128-row tiles: exchanged inside the GEMM launch, no pre-pass;
+//   parts - one block per row, consumed by the int8 kernel: every wave of the pre-pass leaves the maximum of ITS column segment in its
+//           own cell [segment][row] (plain stores; at most LQER_AMAX_NSEG segments, the GEMM folds them when it reads a row's
+//           constants) - no atomics, so no zero-fill launch in front (4.7 us of a 62-us step at M = 2048).  Taken while the segments stay
+//           narrow (up to 8 column tiles: beyond N = 4096 wider segments mean half the waves, each twice as long - 2048 x 11008, rank 32:
+//           111.9 us with partials against 104.4 with cells; tools/ab_i8.py --rows --amax), or where the pre-pass would not use more
+//           than LQER_AMAX_NSEG segments anyway (token counts from ~16k: C4 - the same pre-pass grid, minus the zero fill);
+//   else  - one atomicMax cell per (row, block), zeroed first: `need` bytes at the head of the scratch.
+struct AmaxPlan {
+  bool parts, xch;
+  size_t need;
+};
+static AmaxPlan amax_plan(const GemmArgs& g, bool lowrank, int bout) {
+  const int tiles_n32 = g.Np / 32;
+  const bool one = g.w8 && g.bout_nblk == 1;
+  // segments the pre-pass would use with no cap (its LDS variant at rank 64, else the register variant at its default row groups)
+  int64_t uncapped;
+  if (g.rp == 64) {
+    const int64_t wgroups4 = ((((g.M + 31) / 32 + 3) / 4) + 3) / 4;
+    uncapped = (LQER_AMAX_WAVES / 4) / wgroups4;
+  } else {
+    const int RG = g.rp <= 64 ? 4 : (g.rp <= 128 ? 2 : 1);
+    uncapped = LQER_AMAX_WAVES / (((g.M + 31) / 32 + RG - 1) / RG);
+  }
+  AmaxPlan p;
+  p.parts = one && !(g.tuning & LQER_TUNE_AMAX_ATOMIC) &&
+            (tiles_n32 <= 8 * LQER_AMAX_NSEG || uncapped <= LQER_AMAX_NSEG || (g.tuning & LQER_TUNE_AMAX_PARTS));
+  // ... or no pre-pass at all: one round of the int8 kernel's 128-row tiles exchanges the maxima inside the GEMM launch
+  p.xch = one && !(g.tuning & (LQER_TUNE_AMAX_ATOMIC | LQER_TUNE_AMAX_PARTS)) && i8_eligible(g, bout) && i8_amax_exchange_ok(g, lowrank, bout);
+  p.need = (size_t)lqer_padded_m(g.M) * (p.xch ? 2 * LQER_AMAX_NSEG : (p.parts ? LQER_AMAX_NSEG_WIDE : g.bout_nblk)) * sizeof(float);
+  return p;
+}
+
+// Bytes at the head of the GEMM's scratch that the pre-pass of this launch needs zeroed before it runs (0: no pre-pass, segment
+// partials or the in-launch exchange).  lqer_linear_forward lets the one-launch activation kernel of the same forward write the
+// zeros (the two calls are handed the same scratch) and sets g.amax_zeroed - the memset launch in front of the pre-pass cost 4.8 us
+// of the 116-us forward at 2048 x 4096 -> 11008.
+size_t gemm_amax_zero_bytes(GemmArgs g, bool lowrank) {
+  int L = 0;
+  if (g.M == 0 || g.N == 0 || bout_mode(g, lowrank, &L) != 2 || g.bout.kind != LQER_Q_MXINT) return 0;
+  g.bout_L = L, g.bout_nblk = (g.Np + L - 1) / L;
+  const AmaxPlan p = amax_plan(g, lowrank, 2);
+  return (p.parts || p.xch) ? 0 : p.need;
+}
+
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st) {
   if (g.M == 0 || g.N == 0) return LQER_OK;
   int L = 0;
@@ -1157,18 +1203,9 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
       g.bout_L = L;
       g.bout_nblk = (g.Np + L - 1) / L;
       const int tiles_n32 = g.Np / 32;
-      // One block per row, consumed by the int8 kernel: every wave of the pre-pass leaves the maximum of ITS column segment in its
-      // own cell [segment][row] (plain stores; at most LQER_AMAX_NSEG segments, the GEMM folds them when it reads a row's
-      // constants) - no atomics, so no zero-fill launch in front (4.7 us of a 62-us step at M = 2048).  Other block lengths and
-      // the bf16 kernels: one atomicMax cell per (row, block), zeroed first.
-      // (up to 8 column tiles per segment: beyond N = 4096 the wider segments re-read too much of B^T per wave - 2048 x 11008,
-      // rank 32: 111.9 us with partials against 104.4 with cells, where 4096 x 4096 gains 2 us; tools/ab_i8.py --rows --amax)
-      const bool parts = g.w8 && g.bout_nblk == 1 && !(g.tuning & LQER_TUNE_AMAX_ATOMIC) &&
-                         (tiles_n32 <= 8 * LQER_AMAX_NSEG || (g.tuning & LQER_TUNE_AMAX_PARTS));
-      // ... or no pre-pass at all: one round of the int8 kernel's 128-row tiles exchanges the maxima inside the GEMM launch
-      const bool xch = g.w8 && g.bout_nblk == 1 && !(g.tuning & (LQER_TUNE_AMAX_ATOMIC | LQER_TUNE_AMAX_PARTS)) && i8_eligible(g, bout) &&
-                       i8_amax_exchange_ok(g, lowrank, bout);
-      const size_t need = (size_t)lqer_padded_m(g.M) * (xch ? 2 * LQER_AMAX_NSEG : (parts ? LQER_AMAX_NSEG : g.bout_nblk)) * sizeof(float);
+      const AmaxPlan ap = amax_plan(g, lowrank, bout);
+      const bool parts = ap.parts, xch = ap.xch;
+      const size_t need = ap.need;
       if (!scratch || scratch_bytes < need) {
         set_error("linear_gemm: scratch %zu B < %zu B for the B_out row-block maxima", scratch_bytes, need);
         return LQER_E_WORKSPACE;
@@ -1182,11 +1219,11 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
         g.bout_xch = 1;
         g.xch_nonce = xch_calls.fetch_add(1, std::memory_order_relaxed) * 0x9E3779B1u;
       } else {
-      if (!parts) (void)hipMemsetAsync(scratch, 0, need, st);
+      if (!parts && !g.amax_zeroed) (void)hipMemsetAsync(scratch, 0, need, st);  // (amax_zeroed: the activation kernel of the same forward did it)
       // padded rank (x limbs of x A) -> 16-deep slices (a template parameter: exact, no per-slice branch) and row groups per wave
       const int nks = g.rp / 16;
       int RG = g.rp <= 64 ? 4 : (g.rp <= 128 ? 2 : 1);
-      const int nseg_cap = parts ? LQER_AMAX_NSEG : tiles_n32;
+      const int nseg_cap = parts ? (tiles_n32 <= 8 * LQER_AMAX_NSEG ? LQER_AMAX_NSEG : LQER_AMAX_NSEG_WIDE) : tiles_n32;
       // (segment partials cap the column split: fewer row groups per wave keep the grid at about a thousand waves)
       if (parts && nks <= 4)
         while (RG > 1 && (((g.M + 31) / 32 + RG - 1) / RG) * nseg_cap < 1024) RG >>= 1;

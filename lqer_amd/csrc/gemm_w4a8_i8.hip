@@ -567,12 +567,18 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
           // fill; segments past the last one re-read it: max does not mind)
           const float* const cell = g.bout_amax + m0_ + tid;
           const int last = g.bout_nseg - 1;
-          float v[LQER_AMAX_NSEG];
+          auto fold = [&](auto n_c) {
+            constexpr int NC = decltype(n_c)::value;
+            float v[NC];
 #pragma unroll
-          for (int sgi = 0; sgi < LQER_AMAX_NSEG; ++sgi) v[sgi] = cell[(int64_t)(sgi < last ? sgi : last) * Mp];
-          float m = v[0];
+            for (int sgi = 0; sgi < NC; ++sgi) v[sgi] = cell[(int64_t)(sgi < last ? sgi : last) * Mp];
+            float m = v[0];
 #pragma unroll
-          for (int sgi = 1; sgi < LQER_AMAX_NSEG; ++sgi) m = fmaxf(m, v[sgi]);
+            for (int sgi = 1; sgi < NC; ++sgi) m = fmaxf(m, v[sgi]);
+            return m;
+          };
+          const float m = g.bout_nseg > LQER_AMAX_NSEG ? fold(std::integral_constant<int, LQER_AMAX_NSEG_WIDE>{})
+                                                       : fold(std::integral_constant<int, LQER_AMAX_NSEG>{});
           t_amax = m;
         } else {
           t_amax = g.bout_amax[(int64_t)(m0_ + tid) * g.bout_nblk];

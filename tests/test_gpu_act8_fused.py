@@ -182,3 +182,67 @@ def test_ties_at_every_exponent_through_the_one_launch_kernel(lq):
     assert torch.equal((img[:, :K].float() * sc[:, None]).cpu(), torch.where(x.abs() <= 1e-8, torch.zeros_like(ref), ref))
     img3, sc3, _ = _act_side(mod, xd, _lib.TUNE_ACT8_SPLIT)
     assert torch.equal(img, img3) and torch.equal(sc, sc3)
+
+
+def test_gemm_prepass_zero_fill_handed_to_the_activation_kernel(lq):
+    """ABI 13: a GEMM whose grid is several rounds of tiles folds the B_out row maxima in a pre-pass with atomicMax on cells it zero-fills
+    first (a memset launch); lqer_quantize_act_xa_prep lets the one-launch activation kernel in front write those zeros and
+    lqer_linear_gemm_prepared skips the memset.  Same bits as the plain pair - on a scratch full of garbage -, 0 ready bytes where the
+    activation side takes the three launches or the GEMM needs no cells, and lqer_linear_forward (which hands over internally) agrees."""
+    from lqer_amd import _lib, ops
+
+    L = _lib.lib()
+    M, K, N, r = 2048, 512, 11008, 32  # 43 column tiles x 16 row tiles of 128: 2.7 rounds - the pre-pass on atomic cells
+    mod, x, W, A, B, qc = _module(lq, K, N, r, torch.float16, seed=11, M=M)
+    xd = x.half().to(DEV)
+    y_fwd = mod(xd).clone()  # lqer_linear_forward
+    p = mod._packed
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(tuning, prep, fill):
+        desc = mod._desc()
+        desc.tuning = tuning
+        Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
+        ws = torch.full((ops.linear_sizes(desc, M).workspace,), fill, dtype=torch.uint8, device=DEV)
+        xq = ws.data_ptr()
+        xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256
+        scr = xaq + ((Mp * rp * 2 + 255) // 256) * 256
+        nscr, gscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M), L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+        y = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        ready = C.c_size_t(12345)
+        qa = (C.byref(desc), xd.data_ptr(), _lib.F16, M, K, p["a_t_f16"].data_ptr(), -1, xq, xaq, scr, nscr)
+        ga = (C.byref(desc), xq, M, p["w"].data_ptr(), xaq, p["b_t"].data_ptr(), p["b_limbs"], None, y.data_ptr(), _lib.F16, N, scr, gscr)
+        if prep:
+            _lib.check(L.lqer_quantize_act_xa_prep(*qa, scr, C.byref(ready), st), "quantize_act_xa_prep")
+            torch.cuda.synchronize()
+            head = ws[scr - xq: scr - xq + ready.value].clone()
+            _lib.check(L.lqer_linear_gemm_prepared(*ga, ready.value, st), "linear_gemm_prepared")
+        else:
+            head = None
+            _lib.check(L.lqer_quantize_act_xa(*qa, st), "quantize_act_xa")
+            _lib.check(L.lqer_linear_gemm(*ga, st), "linear_gemm")
+        torch.cuda.synchronize()
+        return y, ready.value, head
+
+    y0, _, _ = run(0, False, 0x5A)
+    y1, ready, head = run(0, True, 0xFF)
+    assert ready == L.lqer_padded_m(M) * 4 and int(head.max()) == 0  # one fp32 cell per row (one B_out block per row), zeroed
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16)) and torch.equal(y0.view(torch.int16), y_fwd.view(torch.int16))
+    y2, ready2, _ = run(_lib.TUNE_ACT8_SPLIT, True, 0xFF)  # three launches: nobody prepared anything, the GEMM fills its cells itself
+    assert ready2 == 0 and torch.equal(y0.view(torch.int16), y2.view(torch.int16))
+    ref = O.lqer_linear_forward(x.half().float(), W.half().float(), None, A.half().float(), B.half().float(), qc)
+    assert float((y1.float().cpu() - ref).norm() / ref.norm()) <= 1e-3
+    # a launch that needs no cells (one round of tiles: the in-GEMM exchange): 0 ready bytes
+    mod4, x4, *_ = _module(lq, K, 4096, r, torch.float16, seed=12, M=M)
+    mod4(x4.half().to(DEV)[:128])
+    desc4 = mod4._desc()
+    ws4 = torch.empty(ops.linear_sizes(desc4, M).workspace, dtype=torch.uint8, device=DEV)
+    Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
+    xq = ws4.data_ptr()
+    xaq = xq + ((Mp * Kp * 2 + 255) // 256) * 256
+    scr = xaq + ((Mp * rp * 2 + 255) // 256) * 256
+    rdy = C.c_size_t(7)
+    _lib.check(L.lqer_quantize_act_xa_prep(C.byref(desc4), xd.data_ptr(), _lib.F16, M, K, mod4._packed["a_t_f16"].data_ptr(), -1, xq, xaq, scr,
+                                           L.lqer_lowrank_xa_scratch_bytes(C.byref(desc4), M), scr, C.byref(rdy), st), "quantize_act_xa_prep")
+    torch.cuda.synchronize()
+    assert rdy.value == 0
