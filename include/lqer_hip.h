@@ -139,6 +139,9 @@ typedef struct lqer_linear_desc {
                                          summation order)                                                                            */
 #define LQER_TUNE_ACT16_FUSED 0x1000000 /* ... the one-launch kernel at every token count (default: 1024 <= M <= 4096; the same window
                                          applies to LQER_TUNE_ACT8_FUSED's kernel)                                                    */
+#define LQER_TUNE_BOUT_IN_PROLOGUE 0x2000000 /* 128-row tile kernel, B_out in blocks of 16: re-quantize the side product in front of the main
+                                              loop (rounds 1-5) instead of under its first 16 k-steps with the product added behind the
+                                              last one (default from K = 1024; csrc/gemm_w4a8.hip, DEFER)                               */
 #define LQER_TUNE_DECODE_NO_POLL 0x10000 /* one-launch decode route: no wait for the producers' tiles - every weight-streaming
                                          workgroup computes the partial tiles of x A itself (the bounded wait's fall-back)     */
 

@@ -112,6 +112,9 @@ __device__ __forceinline__ void lds_wait(u32x2& a, int& b) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
 }
 
+#ifndef LQER_DEFER_WHERE
+#define LQER_DEFER_WHERE 0  // DEFER pieces: 0 inside COMPUTE (between its MFMAs), 1 at the head of LOAD
+#endif
 #ifdef LQER_STAMPS
 #define LQER_LOAD_BARRIER ""  // the diagnostic build stamps between the waits and the barrier
 #else
@@ -149,9 +152,17 @@ __device__ unsigned long long* g_stamp_buf = nullptr;  // diagnostic builds only
 // (LQER_TUNE_XA_REDUCE_IN_GEMM): at C2 the launch it saves took 4.9 us and this kernel grows by 5.3 us (1.0 of it the staged
 // route's barriers) - the quantizer leaves one partial tile per 256 k (16 at K = 4096: 256 KB per workgroup, four round trips
 // of four chunks), and the sum sits in front of the main loop, whose accumulators it opens, with nothing to hide behind.
-template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4, bool WTWOS = false, bool XAPART = false>
+// DEFER (round 6): the B_out re-quantization of the side product leaves the prologue.  There it was ~800 vector instructions per wave
+// between the side product's MFMAs and the first k-step with nothing to hide behind: 3.5 of the 5.4 us in front of the main loop at
+// 2048 x 4096 x 4096 (tools/clock_probe.py, "prologue split").  Here the side product stays in registers of its own (sp), the main
+// loop opens on bias alone, its first 16 k-steps each carry one sixteenth of the re-quantization in the vector slots between their
+// MFMAs (even piece: a block's maximum, exponent and scale factors; odd piece: its eight values), and sp is added behind the last
+// k-step - as gemm_smallm.hip and decode1.hip always did.  Same formula (the scale exponent clamped to normal floats, exact while
+// |x| <= 1e-8 passes through: gemm_w4a8_i8.hip's epilogue); blocks of 16, clamps up to 2^22 and K >= 1024 (launch_gemm).
+template <int DT, bool LOWRANK, int BOUT, bool STAGED = false, int MT = 4, bool WTWOS = false, bool XAPART = false, bool DEFER = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   static_assert(MT == 4 || MT == 2, "128- or 64-row tiles");
+  static_assert(!DEFER || (LOWRANK && BOUT == 1 && MT == 4 && !XAPART), "deferred B_out: blocks of 16 on 128-row tiles");
   static_assert(!XAPART || (LOWRANK && STAGED), "the partial tiles of x A enter through the LDS stage");
   static_assert(!WTWOS || DT != LQER_F16X, "integer weights: no fp16 main loop");
   constexpr int BMk = 32 * MT;   // tile rows
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   const int wn = wave;  // 8 waves side by side along n: each owns all 128 token rows x 32 output columns
   const int l31 = lane & 31, lh = lane >> 5;
 #ifdef LQER_CLOCKPROBE
-  unsigned long long cp_rin;  // diagnostic build: the chip-wide 100 MHz counter at the wave's entry
+  unsigned long long cp_rin, cp_rq = 0;  // diagnostic build: the chip-wide 100 MHz counter at the wave's entry / in front of the B_out re-quantization
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_rin)::"memory");
 #endif
 
@@ -384,6 +395,17 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+  f32x16 sp[DEFER ? MT : 1];  // DEFER: the side product, re-quantized in place during the first k-steps
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sp[i][k] = 0.f;
+  }
+  auto side_acc = [&](int i) -> f32x16& {
+    if constexpr (DEFER) return sp[i];
+    else return acc[i];
+  };
 
   // ---- low-rank prologue: acc = Q_Bout(xAq @ B) + bias ----------------------------------------
   if constexpr (LOWRANK) {
@@ -393,7 +415,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
         const int l = two_limbs ? sl : 0, ks = two_limbs ? 0 : sl;
         if (l < g.b_limbs && ks * 16 < g.rp) {
 #pragma unroll
-          for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(db[sl], dx[sl][i], acc[i], 0, 0, 0);
+          for (int i = 0; i < MT; ++i) side_acc(i) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(db[sl], dx[sl][i], side_acc(i), 0, 0, 0);
         }
       }
     }
@@ -426,10 +448,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
             if constexpr (MT == 4) {
               bf16x8 x0 = lds_read128<0>(fa), x1 = lds_read128<4096>(fa), x2 = lds_read128<8192>(fa), x3 = lds_read128<12288>(fa);
               lds_wait(x0, x1, x2, x3);
-              acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x0, acc[0], 0, 0, 0);
-              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x1, acc[1], 0, 0, 0);
-              acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x2, acc[2], 0, 0, 0);
-              acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x3, acc[3], 0, 0, 0);
+              side_acc(0) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x0, side_acc(0), 0, 0, 0);
+              side_acc(1) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x1, side_acc(1), 0, 0, 0);
+              side_acc(2) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x2, side_acc(2), 0, 0, 0);
+              side_acc(3) = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sb[BUF][ks], x3, side_acc(3), 0, 0, 0);
             } else {
               bf16x8 x0 = lds_read128<0>(fa), x1 = lds_read128<4096>(fa);
               lds_wait(x0, x1);
@@ -442,7 +464,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       limb(1, std::integral_constant<int, 1>{});
       limb(2, std::integral_constant<int, 0>{});
     }
-    if constexpr (BOUT != 0) {
+#ifdef LQER_CLOCKPROBE
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp_rq)::"memory");  // side operands landed, MFMAs issued
+#endif
+    if constexpr (BOUT != 0 && !DEFER) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -529,10 +554,63 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
   // while the DMA instructions issue -, then the counted waits.  The step's first weight fragment is expanded in the
   // slack left before the barrier, so that COMPUTE opens with an MFMA.  The loading wave has issue priority over
   // its computing SIMD partner (whose MFMAs only need an issue slot every 32 cycles).
-  auto step = [&](int kt, auto slot_c) {
+  // DEFER piece P of k-step P (0..15): block j = P / 2 = (m tile j / 2, column half j % 2) of the side product.  Straight-line vector
+  // code only (no branch: it has to share the COMPUTE section's scheduling region with the MFMAs it hides behind).
+  float dq_s = 1.f, dq_inv = 1.f;  // scale factors 2^(mbits - e), 2^(e - mbits) of the block between its two pieces
+  auto defer_piece = [&](auto piece_c) {
+    constexpr int P = decltype(piece_c)::value;
+    if constexpr (DEFER && P >= 0) {
+      typedef __attribute__((ext_vector_type(2))) float f2;
+      constexpr int J = P >> 1, I = J >> 1, B8 = 8 * (J & 1);
+      if constexpr ((P & 1) == 0) {
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) amax = fmaxf(fmaxf(amax, fabsf(sp[I][B8 + k])), fabsf(sp[I][B8 + k + 1]));
+        amax = pair32_max(amax);
+        // (mbits - e clamped to the exponents of normal floats: beyond, every element of the block is below 1e-8 and passes through)
+        int up = g.bout.mbits - block_exponent(amax, g.bout);
+        up = up > 126 ? 126 : (up < -126 ? -126 : up);
+        dq_s = __uint_as_float((uint32_t)(127 + up) << 23);
+        dq_inv = __uint_as_float((uint32_t)(127 - up) << 23);
+      } else {
+        const float es = g.bout.eps * dq_s, hi = g.bout.mmax, lo = -g.bout.mneg, tiny = g.bout.tiny;
+        const f2 magic = {12582912.0f, 12582912.0f};
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const f2 x = {sp[I][B8 + k], sp[I][B8 + k + 1]};
+          const f2 c = {copysignf(es, x[0]), copysignf(es, x[1])};
+          f2 r = (__builtin_elementwise_fma(x, (f2){dq_s, dq_s}, c) + magic) - magic;
+          r[0] = __builtin_amdgcn_fmed3f(r[0], lo, hi);
+          r[1] = __builtin_amdgcn_fmed3f(r[1], lo, hi);
+          const f2 val = r * (f2){dq_inv, dq_inv};
+          sp[I][B8 + k] = fabsf(x[0]) <= tiny ? x[0] : val[0];
+          sp[I][B8 + k + 1] = fabsf(x[1]) <= tiny ? x[1] : val[1];
+        }
+      }
+    }
+  };
+  // (the piece's results are needed a k-step later, or behind the loop: without a use inside the section hipcc sinks the whole
+  // computation to that use - all sixteen pieces ended up behind the main loop.  An empty asm that "modifies" them pins them here)
+  auto defer_pin = [&](auto piece_c) {
+    constexpr int P = decltype(piece_c)::value;
+    (void)dq_s, (void)dq_inv, (void)sp;  // (captured here: operands of an asm statement inside a dependent branch do not make a capture)
+    if constexpr (DEFER && P >= 0) {
+      constexpr int J = P >> 1, I = J >> 1, B8 = 8 * (J & 1);
+      if constexpr ((P & 1) == 0) asm volatile("" : "+v"(dq_s), "+v"(dq_inv));
+      else
+        asm volatile("" : "+v"(sp[I][B8]), "+v"(sp[I][B8 + 1]), "+v"(sp[I][B8 + 2]), "+v"(sp[I][B8 + 3]), "+v"(sp[I][B8 + 4]), "+v"(sp[I][B8 + 5]),
+                     "+v"(sp[I][B8 + 6]), "+v"(sp[I][B8 + 7]));
+    }
+  };
+  auto step = [&](int kt, auto slot_c, auto piece_c) {
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr int slot_new = SLOT == 0 ? NSLOT - 1 : SLOT - 1;  // (slot + DEPTH) % NSLOT
     STAMP(7);
+#if LQER_DEFER_WHERE == 1  // (experiment: the piece at the head of LOAD, under the partner wave's MFMAs)
+    defer_piece(piece_c);
+    defer_pin(piece_c);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     __builtin_amdgcn_s_setprio(1);
     const int ktn = __builtin_amdgcn_readfirstlane(kt + DEPTH);
     const int a_soff = ktn * (BK * 2), w_soff = ktn * LQER_PANEL_BYTES;
@@ -627,6 +705,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4);  // expand of the first fragment + barrier
     // ---- COMPUTE(kt)
+#if LQER_DEFER_WHERE == 0
+    defer_piece(piece_c);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       // biased exponent byte ks -> fp32 bits of the block scale 2^(e - mbits)
@@ -635,6 +716,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i] = mfma_32x32x16<XF16>(wb, xa[ks][i], acc[i]);
     }
+#if LQER_DEFER_WHERE == 0
+    defer_pin(piece_c);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     STAMP(5);  // COMPUTE section issue
     asm volatile("s_barrier" ::: "memory");
@@ -642,14 +726,24 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     STAMP(6);  // barrier after COMPUTE
   };
   using std::integral_constant;
-  for (int kt = 0;; kt += NSLOT) {  // 4 steps per trip, slots 0..3; every step is the same branch-free stream
-    step(kt, integral_constant<int, 0>{});
+  constexpr integral_constant<int, -1> no_piece{};
+  int kt0 = 0;
+  if constexpr (DEFER) {  // the first 16 k-steps (launch_gemm: nk >= 16), each with its piece of the re-quantization
+#define LQER_DSTEP(KT) step(KT, integral_constant<int, (KT) % NSLOT>{}, integral_constant<int, KT>{})
+    LQER_DSTEP(0); LQER_DSTEP(1); LQER_DSTEP(2); LQER_DSTEP(3); LQER_DSTEP(4); LQER_DSTEP(5); LQER_DSTEP(6); LQER_DSTEP(7);
+    LQER_DSTEP(8); LQER_DSTEP(9); LQER_DSTEP(10); LQER_DSTEP(11); LQER_DSTEP(12); LQER_DSTEP(13); LQER_DSTEP(14); LQER_DSTEP(15);
+#undef LQER_DSTEP
+    kt0 = 16;
+  }
+  if (kt0 < nk)
+  for (int kt = kt0;; kt += NSLOT) {  // 4 steps per trip, slots 0..3; every step is the same branch-free stream
+    step(kt, integral_constant<int, 0>{}, no_piece);
     if (kt + 1 >= nk) break;
-    step(kt + 1, integral_constant<int, 1>{});
+    step(kt + 1, integral_constant<int, 1>{}, no_piece);
     if (kt + 2 >= nk) break;
-    step(kt + 2, integral_constant<int, 2>{});
+    step(kt + 2, integral_constant<int, 2>{}, no_piece);
     if (kt + 3 >= nk) break;
-    step(kt + 3, integral_constant<int, 3>{});
+    step(kt + 3, integral_constant<int, 3>{}, no_piece);
     if (kt + 4 >= nk) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the prefetches issued past the end of K have drained
@@ -664,6 +758,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
       g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 2] = cp_rin;  // absolute ticks: entry, main loop start, main loop end
       g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 3] = cp_r0;
       g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 4] = cp_r1;
+      g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + 7] = cp_rq;
     }
   }
 #endif
@@ -672,6 +767,12 @@ __global__ __launch_bounds__(512) void k_lqer_gemm(GemmArgs g) {
     for (int i = 0; i < 8; ++i) g_stamp_buf[(blockIdx.x * 8 + wave) * 8 + i] = st_sum[i];
 #endif
 
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][k] += sp[i][k];
+  }
   // ---- store ----------------------------------------------------------------------------------
   // per 32x32 tile and quad q: regs 4q..4q+3 = columns n = nb + 8q + 4 lh + (0..3) of token row m
 #ifdef LQER_ABL_NO_STORE
@@ -1060,9 +1161,21 @@ static int launch_gemm(const GemmArgs& g, bool lowrank, int bout, hipStream_t st
     return check_launch("lqer_gemm");
   }
 #undef LQER_GEMM_LAUNCH_H64
+  // B_out in blocks of 16 re-quantized under the first 16 k-steps instead of in front of the main loop (DEFER above): K >= 1024,
+  // clamps within the magic-number rounding, and the 1e-8 pass-through that makes the clamped scale exponent exact
+  const bool defer = lowrank && bout == 1 && !(g.tuning & LQER_TUNE_BOUT_IN_PROLOGUE) && g.Kp / BK >= 16 && g.bout.kind == LQER_Q_MXINT &&
+                     g.bout.mmax <= 4194304.0f && g.bout.mneg <= 4194304.0f && g.bout.tiny >= 1e-8f;
+#define LQER_GEMM_LAUNCH_DEFER(ST)                                                                              \
+  do {                                                                                                          \
+    static LdsLimitOnce lds_once;                                                                               \
+    lds_once.set((const void*)k_lqer_gemm<DT, true, 1, ST, 4, false, false, true>, gemm_lds_bytes(4));          \
+    k_lqer_gemm<DT, true, 1, ST, 4, false, false, true><<<grid, 512, gemm_lds_bytes(4), st>>>(g);               \
+  } while (0)
   if (!lowrank)
     LQER_GEMM_LAUNCH(false, 0);
-  else if (bout == 1) {
+  else if (bout == 1 && defer) {
+    if (staged) LQER_GEMM_LAUNCH_DEFER(true); else LQER_GEMM_LAUNCH_DEFER(false);
+  } else if (bout == 1) {
     if (staged) LQER_GEMM_LAUNCH_STAGED(1); else LQER_GEMM_LAUNCH(true, 1);
   } else if (bout == 2) {
     if (staged) LQER_GEMM_LAUNCH_STAGED(2); else LQER_GEMM_LAUNCH(true, 2);

@@ -131,3 +131,56 @@ def test_gemm_summing_the_partial_tiles_equals_the_reduce_launch(lq, M, K, N, r,
     ref = O.lqer_linear_forward(h(x), h(W), h(case[4]) if bias else None, h(A), h(B), qc)
     err = float((y2.float().cpu() - ref).norm() / ref.norm())
     assert err <= (4e-3 if dtype == torch.bfloat16 else 1e-3), err
+
+
+DEFER_CASES = [  # M, K, N, rank, bias, dtype
+    (2048, 4096, 4096, 32, False, torch.float16),   # BASELINE configs[1]: the direct side path (two 16-deep slices)
+    (300, 1024, 520, 20, True, torch.bfloat16),     # the shortest K that defers (16 k-steps), ragged M / N, padded rank, bias
+    (1500, 2048, 768, 64, True, torch.float16),     # rank 64: the staged side path
+    (640, 1100, 512, 32, False, torch.float32),     # ragged K (18 k-steps), fp32 outputs: the accumulator's own bits
+]
+
+
+@pytest.mark.parametrize("M,K,N,r,bias,dtype", DEFER_CASES)
+def test_b_out_requantized_under_the_main_loop_equals_in_front_of_it(lq, M, K, N, r, bias, dtype):
+    """Round 6 (k_lqer_gemm DEFER): B_out in blocks of 16 is re-quantized piece by piece under the first 16 k-steps and the side product
+    added behind the last one; LQER_TUNE_BOUT_IN_PROLOGUE pins the rounds-1-5 order (re-quantized in front of the main loop, the
+    accumulators opened on it).  Same formula: on MXINT data (every partial sum exact in fp32) the same bits; with a side product whose
+    blocks are zero, below the 1e-8 pass-through, and spread over 28 binades both stay the oracle's (linear.py:145-157) - there the
+    two summation orders may differ in the last fp32 bit, like gemm_smallm.hip / decode1.hip (which always added last) and the tile kernels did."""
+    from bench import MXINT_Q, make_case
+    from lqer_amd import _lib
+
+    case = make_case(M, K, N, max(r, 16), seed=41, bias=bias)
+    x, W, A, B = case[:4]
+    A, B = A[:, :r].contiguous(), B[:r].contiguous()
+    h = lambda t: None if t is None else t.to(dtype).float()
+
+    def both(Bm):
+        mod = lq.LinearFlexibleLqer(K, N, bias=bias, q_config=MXINT_Q, l_config={"rank": r})
+        sd = {"weight": W, "A": A, "B": Bm}
+        if bias:
+            sd["bias"] = case[4]
+        mod.load_state_dict(sd)
+        mod = mod.to(DEV).to(dtype)
+        xd = x.to(dtype).to(DEV)
+        mod.tuning = _lib.TUNE_TILE_ROWS_128
+        y_new = mod(xd).clone()
+        mod.tuning = _lib.TUNE_TILE_ROWS_128 | _lib.TUNE_BOUT_IN_PROLOGUE
+        y_old = mod(xd).clone()
+        ref = O.lqer_linear_forward(h(x), h(W), h(case[4]) if bias else None, h(A), h(Bm), MXINT_Q)
+        tol = 4e-3 if dtype == torch.bfloat16 else 1e-3
+        for y in (y_new, y_old):
+            assert float((y.float().cpu() - ref).norm() / ref.norm()) <= tol
+        return y_new, y_old, ref
+
+    y_new, y_old, _ = both(B)
+    assert torch.equal(y_new, y_old)
+    # columns of B: zero (blocks with maximum 0), 1e-10 (every element of the side product below 1e-8: passed through unquantized),
+    # and powers of two over 28 binades (block exponents far apart; sums no longer exact; fp16 outputs stay finite)
+    g = torch.Generator().manual_seed(5)
+    scale = torch.pow(2.0, torch.randint(-20, 8, (N,), generator=g).float())
+    scale[: N // 8] = 0.0
+    scale[N // 8: N // 4] = 1e-10
+    y_new, y_old, ref = both((B * scale[None, :]).contiguous())
+    assert float((y_new.float() - y_old.float()).abs().max()) <= 2e-3 * float(ref.abs().max())

@@ -45,3 +45,7 @@ for i, nm in enumerate(names):
     print(f"  {nm:20s} median {us(q(col, 0.5)):7.2f} us   first {us(col.min().item()):7.2f}   last {us(col.max().item()):7.2f}")
 print(f"  per wave: prologue {q(ab[:, :, 1] - ab[:, :, 0], 0.5) / 100:.2f} us, main loop {q(ab[:, :, 2] - ab[:, :, 1], 0.5) / 100:.2f} us, "
       f"convert + store issue {q(ab[:, :, 3] - ab[:, :, 2], 0.5) / 100:.2f} us, store drain {q(ab[:, :, 4] - ab[:, :, 3], 0.5) / 100:.2f} us")
+rq = buf.cpu().view(256, 8, 8)[:, :, 7].double()
+if rq.max().item() > 0:
+    print(f"  prologue split: entry -> side operands landed {q(rq - ab[:, :, 0], 0.5) / 100:.2f} us, B_out re-quantization + bias + barrier "
+          f"{q(ab[:, :, 1] - rq, 0.5) / 100:.2f} us")
