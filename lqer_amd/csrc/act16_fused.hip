@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
       amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
       uint32_t w[4] = {0, 0, 0, 0};
       if (amax > 0.f) {
-        const int e = block_exponent(amax, qx);
+        const int e = block_exponent_u(amax, qx);
         if (mxint16_fast_ok(e, qx)) {
           mxint16_bf16_fast<DT != LQER_F16, 8>(v, e, qx, w);
         } else {

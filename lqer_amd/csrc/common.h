@@ -140,6 +140,19 @@ __device__ __forceinline__ int block_exponent(float amax, const QP& q) {
   return e < q.emin ? q.emin : (e > q.emax ? q.emax : e);
 }
 
+// The same exponent behind ONE wave-uniform branch: the largest slack of the rule is 22, so a maximum more than 22 ulps above its
+// power of two takes k + 1 whatever the binade - five instructions instead of ~30; the rule itself runs only when some lane of the wave
+// sits that close to a power of two (or on it, or at zero).  For the quantizer kernels (a block per lane or lane pair: the rule was a
+// third of their vector work); NOT for code that shares a scheduling region with MFMAs (a branch ends the region).
+__device__ __forceinline__ int block_exponent_u(float amax, const QP& q) {
+  const uint32_t bits = __float_as_uint(amax);
+  const int mant = (int)(bits & 0x7fffffu);
+  int e;
+  if (__builtin_amdgcn_ballot_w64(mant <= 22) == 0) e = (int)((bits >> 23) & 0xff) - 126;
+  else e = ceil_log2_rule(amax);
+  return e < q.emin ? q.emin : (e > q.emax ? q.emax : e);
+}
+
 // Signed mantissa of one element given its block exponent (block_fp.py:55-65):
 //   m = min(rne((|x| + 1e-9) / 2^e * 2^mbits), 2^mbits - 1), sign from x.
 // |x| <= 1e-8 is the reference's pass-through (block_fp.py:79-80); packed images flush it to 0.

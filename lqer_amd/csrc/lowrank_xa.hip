@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_quant_xa128(const uint8_t* __res
     // the block's other half lies in lane ^ 1 (chunks 2b, 2b + 1: the swizzle keeps the pair together)
     amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0xB1, 0xf, 0xf, true)));
     const bool any = amax > 0.f;
-    const int e = block_exponent(any ? amax : 1.0f, q);
+    const int e = block_exponent_u(any ? amax : 1.0f, q);
     uint32_t w[4];
     if (__builtin_expect(mxint16_fast_ok(e, q), 1)) {  // (per block, like the standalone quantizer: the two routes differ in the sign of a zero)
       const float sc = __uint_as_float((uint32_t)(127 + q.mbits - e) << 23);
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(QX_K) void k_quant_xa16(const void* __restrict__ x,
 #pragma unroll
         for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
         if (amax > 0.f) {
-          const int e = block_exponent(amax, q);
+          const int e = block_exponent_u(amax, q);
           if (mxint16_fast_ok(e, q)) {
             mxint16_bf16_fast<DT != LQER_F16>(v, e, q, w);
           } else {

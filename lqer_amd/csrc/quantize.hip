@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_quant_seg16(const void* __restrict__ x,
 #pragma unroll
     for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(v[i]));
     const bool any = amax > 0.0f;
-    const int e = any ? block_exponent(amax, q) : 0;
+    const int e = any ? block_exponent_u(amax, q) : 0;
     emit16(v, any, e, q, o, row, k0, cols);
     if (o.exps && k0 < cols) o.exps[row * o.nblk + k0 / 16] = (int8_t)(e > 127 ? 127 : e);
   }
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_quant_row(const void* __restrict__ x, i
   __syncthreads();
   amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   const bool any = amax > 0.0f;
-  const int e = any ? block_exponent(amax, q) : 0;
+  const int e = any ? block_exponent_u(amax, q) : 0;
   if (keep) {
 #pragma unroll
     for (int j = 0; j < QR_KEEP; ++j) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_quant_row8(const void* __restrict__ x, 
 #pragma unroll
   for (int s = 32; s >= 1; s >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s, 64));
   const bool any = amax > 0.f;
-  const int e = any ? block_exponent(amax, q) : 0;
+  const int e = any ? block_exponent_u(amax, q) : 0;
   if (lane == 0 && xscale) xscale[row] = any ? ldexpf(1.0f, e - q.mbits) : 1.0f;
   int8_t* const dst = xq8 + row * cols_p8;
   const bool fast = mxint16_fast_ok(e, q);  // (wave-uniform)
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_quant_blk(const void* __restrict__ x, i
     float amax = 0.0f;
     for (int64_t k = b0; k < b1 && k < cols; ++k) amax = fmaxf(amax, fabsf(load_elem<DT>(x, row * ld + k)));
     const bool any = amax > 0.0f;
-    const int e = any ? block_exponent(amax, q) : 0;
+    const int e = any ? block_exponent_u(amax, q) : 0;
     for (int64_t k0 = b0; k0 < b1; k0 += 16) {
       float v[16];
       load16<DT, false>(x, row * ld, k0, cols, v);

@@ -386,7 +386,9 @@ def test_int8_tile_rows_default_choice(lq):
 
 
 @pytest.mark.parametrize("M,K,N,r", [(2048, 512, 4096, 32), (300, 256, 1000, 16), (4096, 384, 2048, 64), (16384, 256, 1024, 64),
-                                     (640, 256, 512, 128)])
+                                     (640, 256, 512, 128),
+                                     (2048, 256, 11008, 32),   # round 6: beyond N = 4096 the pinned partials are 32 cells per row
+                                     (16384, 256, 5120, 64)])  # round 6: C4's N - the pre-pass uses 16 segments anyway: partials by default
 def test_int8_bout_row_maxima_as_segment_partials(lq, M, K, N, r):
     """B_out with one block per row on the int8 route: the pre-pass leaves per-column-segment partial maxima in plain stores and
     the GEMM folds them (round 5: no atomics, no zero-fill launch) - against the atomicMax cells behind a memset (descriptor tuning
