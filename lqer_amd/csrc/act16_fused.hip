@@ -27,6 +27,13 @@ __host__ inline size_t lds_bytes(int rp) { return (size_t)WAVES * ROWS * PITCH +
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16v8;
 
+#ifdef LQER_CLOCKPROBE
+__device__ unsigned long long* g_a16_stamp_buf = nullptr;  // diagnostic build: shader cycles at the phase boundaries of a wave's FIRST slab
+#define A16_STAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cp[i])::"memory")
+#else
+#define A16_STAMP(i)
+#endif
+
 template <int DT, int RT>
 __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x, int64_t M, int64_t K, int64_t ld, QP qx, bf16_t* __restrict__ xq,
                                                       int64_t Kp, const bf16_t* __restrict__ a_frag, QP qa, int L_aout, bf16_t* __restrict__ xaq) {
@@ -46,6 +53,10 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
   f32x4 acc[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef LQER_CLOCKPROBE
+  unsigned long long cp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  A16_STAMP(0);
+#endif
 
   for (int s = wave; s < nslab; s += WAVES) {
     const int64_t k0 = (int64_t)s * SLAB + 8 * lane;  // this lane's 8 elements of every row
@@ -71,8 +82,10 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
     // fragment requests in a row stands still until the path has taken them, and with it its rows' arithmetic: act8_fused.hip found the
     // same, tools/clock_probe_a8.py)
     // ---- quantize: the lane's 8 values of each row; the block's other half sits in lane ^ 1
+    if (s == wave) A16_STAMP(1);  // the rows' requests are out
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
+      if (r == 1 && s == wave) A16_STAMP(2);  // row 0 landed and quantized
       if (r == 2) {
         asm volatile("" ::: "memory");
         load_part(fa, 0);
@@ -117,6 +130,7 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
       if (in_img) *(u32x4*)(xq + (m0 + r) * Kp + k0) = wv;  // (rows up to the padded M are allocated; rows past M and k past K: zeros)
       *(u32x4*)(wb + r * PITCH + 16 * lane) = wv;
     }
+    if (s == wave) A16_STAMP(3);  // all rows quantized, image stores issued
     // (the wave reads back what it wrote itself: LDS executes a wave's accesses in order - no workgroup barrier; the fence keeps the
     // compiler from moving the reads up)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -144,6 +158,12 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
     // (the next slab overwrites the wave's LDS slab: its reads above must have been issued - they have, in program order)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef LQER_CLOCKPROBE
+    if (s == wave) {
+      asm volatile("" ::"v"(acc[0]));
+      A16_STAMP(4);  // the slab's fragments landed, 16 steps multiplied
+    }
+#endif
   }
   // D layout: column n = lane & 15, rows 4 g + j: token rows 0-7 live in g = 0, 1
   if (g < 2) {
@@ -153,6 +173,16 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
       for (int j = 0; j < 4; ++j) red[(wave * ROWS + 4 * g + j) * RP + 16 * t + (lane & 15)] = acc[t][j];
   }
   __syncthreads();
+#ifdef LQER_CLOCKPROBE
+  A16_STAMP(5);  // every wave's partial tile is in LDS
+  if (g_a16_stamp_buf && lane == 0) {
+    unsigned long long* o = g_a16_stamp_buf + ((size_t)blockIdx.x * WAVES + wave) * 8;
+    for (int i = 1; i < 6; ++i) o[i] = cp[i] - cp[0];
+    unsigned long long rt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    o[0] = cp[0], o[6] = rt;
+  }
+#endif
   // ---- fixed-order sum of the 8 partial tiles, A_out (k_xa_reduce4's arithmetic), bf16 store
   const int tid = threadIdx.x;
   const bool live = tid < ROWS * RP / 4;
@@ -203,6 +233,10 @@ __global__ __launch_bounds__(256) void k_a_b16(const bf16_t* __restrict__ limb0,
 }
 
 }  // namespace a16f
+
+#ifdef LQER_CLOCKPROBE
+extern "C" int lqer_debug_set_a16_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(a16f::g_a16_stamp_buf), &p, sizeof(p)); }
+#endif
 
 size_t a_b16_image_bytes(int64_t K, int64_t r) { return (size_t)2 * lqer_padded_r(r) * lqer_padded_k(K) * sizeof(bf16_t); }
 
