@@ -139,6 +139,10 @@ typedef struct lqer_linear_desc {
                                          summation order)                                                                            */
 #define LQER_TUNE_ACT16_FUSED 0x1000000 /* ... the one-launch kernel at every token count (default: 1024 <= M <= 4096; the same window
                                          applies to LQER_TUNE_ACT8_FUSED's kernel)                                                    */
+#define LQER_TUNE_AMAX_NO_MRX 0x4000000 /* int8 route, SEVERAL rounds of 128-row tiles on a resident grid (up to 2048 tokens), one B_out block per
+                                           row, 4-bit weights: keep the k_bout_amax pre-pass launch (rounds 3-5) instead of the default - the
+                                           GEMM's workgroups compute the pre-pass themselves, one item each at their start, and exchange
+                                           tagged granules (csrc/gemm_w4a8_i8.hip, MRX)                                                   */
 #define LQER_TUNE_BOUT_IN_PROLOGUE 0x2000000 /* 128-row tile kernel, B_out in blocks of 16: re-quantize the side product in front of the main
                                               loop (rounds 1-5) instead of under its first 16 k-steps with the product added behind the
                                               last one (default from K = 1024; csrc/gemm_w4a8.hip, DEFER)                               */

@@ -21,6 +21,7 @@ TUNE_TILE_ROWS_128, TUNE_TILE_ROWS_64, TUNE_DECODE_NO_POLL, TUNE_XA_REDUCE_IN_GE
 TUNE_I8_ROWS_128, TUNE_I8_ROWS_256, TUNE_AMAX_ATOMIC, TUNE_AMAX_PARTS = 0x4, 0x8, 0x40000, 0x80000
 TUNE_ACT16_SPLIT, TUNE_ACT16_FUSED = 0x800000, 0x1000000  # block-16 MXINT activation side: two launches / the one-launch kernel at every M
 TUNE_ACT8_SPLIT, TUNE_ACT8_FUSED = 0x200000, 0x400000  # int8 route's activation side: three launches / the one-launch kernel at every M
+TUNE_AMAX_NO_MRX = 0x4000000  # int8 route over several rounds of 128-row tiles: the k_bout_amax pre-pass launch instead of the in-GEMM items
 TUNE_BOUT_IN_PROLOGUE = 0x2000000  # 128-row tile kernel: the B_out re-quantization in front of the main loop (rounds 1-5) instead of under it
 TUNE_AMAX_XCH_MISS = 0x100000  # int8 route's in-GEMM exchange of the B_out row maxima: every workgroup takes its fall-back
 

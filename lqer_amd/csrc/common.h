@@ -623,8 +623,9 @@ bool m256_eligible(const GemmArgs& g);  // gemm_w4a8_m256.hip: fewer (weighted) 
 int m256_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
 bool i8_eligible(const GemmArgs& g, int bout);     // gemm_w4a8_i8.hip: the int8 MFMA main loop (g.w8 set, large M)
 int i8_dispatch(const GemmArgs& g, int dtype, bool lowrank, int bout, hipStream_t st);
-int i8_tile_rows(const GemmArgs& g);
-bool i8_amax_exchange_ok(const GemmArgs& g, bool lowrank, int bout);  // the int8 kernel can exchange the B_out row maxima itself  // 256, or 128 where that takes fewer (weighted) rounds of one tile per CU
+int i8_tile_rows(const GemmArgs& g);  // 256, or 128 where that takes fewer (weighted) rounds of one tile per CU
+bool i8_amax_exchange_ok(const GemmArgs& g, bool lowrank, int bout);  // the int8 kernel can exchange the B_out row maxima itself (one round)
+bool i8_amax_mrx_ok(const GemmArgs& g, bool lowrank, int bout);       // ... or compute and exchange them over several rounds (MRX)
 int i8_prepare_dispatch(const void* w_packed, int64_t N, int64_t K, int mbits, void* w_i8, int32_t* flags, hipStream_t st);
 int i8_unpack_dispatch(const void* w_i8, int64_t N, int64_t K, float* out, hipStream_t st, bool codes8 = false);
 bool smallm_eligible(const GemmArgs& g, int bout);  // gemm_smallm.hip: M <= 64, B_out pass-through or blocks of 16

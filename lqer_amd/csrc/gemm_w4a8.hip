@@ -1269,7 +1269,7 @@ int gemm_tile_rows(const GemmArgs& g) {
 //           than LQER_AMAX_NSEG segments anyway (token counts from ~16k: C4 - the same pre-pass grid, minus the zero fill);
 //   else  - one atomicMax cell per (row, block), zeroed first: `need` bytes at the head of the scratch.
 struct AmaxPlan {
-  bool parts, xch;
+  bool parts, xch, mrx;
   size_t need;
 };
 static AmaxPlan amax_plan(const GemmArgs& g, bool lowrank, int bout) {
@@ -1289,7 +1289,12 @@ static AmaxPlan amax_plan(const GemmArgs& g, bool lowrank, int bout) {
             (tiles_n32 <= 8 * LQER_AMAX_NSEG || uncapped <= LQER_AMAX_NSEG || (g.tuning & LQER_TUNE_AMAX_PARTS));
   // ... or no pre-pass at all: one round of the int8 kernel's 128-row tiles exchanges the maxima inside the GEMM launch
   p.xch = one && !(g.tuning & (LQER_TUNE_AMAX_ATOMIC | LQER_TUNE_AMAX_PARTS)) && i8_eligible(g, bout) && i8_amax_exchange_ok(g, lowrank, bout);
-  p.need = (size_t)lqer_padded_m(g.M) * (p.xch ? 2 * LQER_AMAX_NSEG : (p.parts ? LQER_AMAX_NSEG_WIDE : g.bout_nblk)) * sizeof(float);
+  //   mrx - several rounds of 128-row tiles on a resident grid: the GEMM's workgroups each compute one item of the pre-pass at their start
+  //         and exchange {maximum, tag} granules (gemm_w4a8_i8.hip, MRX): no pre-pass launch, nothing zeroed
+  p.mrx = one && !p.xch && !(g.tuning & (LQER_TUNE_AMAX_NO_MRX | LQER_TUNE_AMAX_ATOMIC | LQER_TUNE_AMAX_PARTS)) && i8_eligible(g, bout) &&
+          i8_amax_mrx_ok(g, lowrank, bout);
+  if (p.mrx) p.parts = false;
+  p.need = (size_t)lqer_padded_m(g.M) * ((p.xch || p.mrx) ? 2 * LQER_AMAX_NSEG : (p.parts ? LQER_AMAX_NSEG_WIDE : g.bout_nblk)) * sizeof(float);
   return p;
 }
 
@@ -1301,8 +1306,11 @@ size_t gemm_amax_zero_bytes(GemmArgs g, bool lowrank) {
   int L = 0;
   if (g.M == 0 || g.N == 0 || bout_mode(g, lowrank, &L) != 2 || g.bout.kind != LQER_Q_MXINT) return 0;
   g.bout_L = L, g.bout_nblk = (g.Np + L - 1) / L;
+  // (asked before the GEMM call's limb count is known: the permissive answer - a launch that then cannot exchange the maxima itself
+  // finds nothing prepared and zero-fills its cells as ever)
+  if (g.b_limbs == 0) g.b_limbs = 1;
   const AmaxPlan p = amax_plan(g, lowrank, 2);
-  return (p.parts || p.xch) ? 0 : p.need;
+  return (p.parts || p.xch || p.mrx) ? 0 : p.need;
 }
 
 int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scratch_bytes, hipStream_t st) {
@@ -1317,7 +1325,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
       g.bout_nblk = (g.Np + L - 1) / L;
       const int tiles_n32 = g.Np / 32;
       const AmaxPlan ap = amax_plan(g, lowrank, bout);
-      const bool parts = ap.parts, xch = ap.xch;
+      const bool parts = ap.parts, xch = ap.xch || ap.mrx;
       const size_t need = ap.need;
       if (!scratch || scratch_bytes < need) {
         set_error("linear_gemm: scratch %zu B < %zu B for the B_out row-block maxima", scratch_bytes, need);
@@ -1329,7 +1337,7 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
       if (xch) {
         // the call's tag: a counter spread over all 32 bits (odd multiplier: a bijection); the kernel mixes in its dispatch id and queue
         static std::atomic<uint32_t> xch_calls{1};
-        g.bout_xch = 1;
+        g.bout_xch = ap.mrx ? 2 : 1;
         g.xch_nonce = xch_calls.fetch_add(1, std::memory_order_relaxed) * 0x9E3779B1u;
       } else {
       if (!parts && !g.amax_zeroed) (void)hipMemsetAsync(scratch, 0, need, st);  // (amax_zeroed: the activation kernel of the same forward did it)

@@ -360,8 +360,16 @@ __global__ __launch_bounds__(256) void k_i8_unpack8(const uint8_t* __restrict__ 
 // the runtime flag g.bout_xch) - no tile loop, every operand of the epilogue requested in the prologue (the xAq panel in an LDS region
 // of its own behind the row tables, the wave's B^T fragments, column scale and bias in registers across the main loop), the first ring
 // step requested before anything else.
-template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT, bool W8 = false, bool XCH = false>
+// MRX (round 6): the same exchange for grids of SEVERAL rounds of 128-row tiles (2048 x 4096 -> 11008: 688 tiles on 256 resident
+// workgroups), where the maxima of a row band are needed by its first epilogue but its tiles run in different rounds.  Every workgroup
+// starts with ONE item of the pre-pass - (row band, sixteenth of the columns): the band's xAq panel into LDS, xch_load_s / xch_compute_s
+// over its two or three column tiles, the waves' maxima through LDS - and publishes {maximum, tag} granules [row][16 segments] (sc1 stores;
+// the launch's tag as in the one-round exchange: nothing is zeroed).  A tile's row constants are folded from its band's 16 granules per
+// row (sc1 loads, a tile ahead as before; the first tile's behind its main loop); where a tag is missing the workgroup polls, bounded,
+// and then computes the band's sixteen items itself (same routine, same bits).  Replaces the k_bout_amax launch (7.7 us + its zero fill).
+template <int DT, bool LOWRANK, int BOUT, bool SHIFT, int NT, bool W8 = false, bool XCH = false, bool MRX = false>
 __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
+  static_assert(!MRX || (!XCH && !W8 && LOWRANK && BOUT == 2 && NT == 4), "multi-round exchange: 4-bit weights on 128-row tiles, one B_out block per row");
   static_assert(!W8 || !SHIFT, "8-bit weight codes: one exponent per weight row");
   static_assert(!XCH || (NT == 4 && LOWRANK && BOUT == 2), "the in-launch exchange: 128-row tiles, one B_out block per row");
   constexpr bool W8D = W8 && NT == 4;  // ... on 128-row tiles: the codes go straight from global memory into registers (step4_w8)
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   I8_STAMP(cp_c[0], cp_r[0]);
 #endif
 
-  if constexpr (XCH) {
+  if constexpr (XCH || MRX) {
     // every kernel argument the prologue and the epilogue read, asked for in ONE batch of scalar loads (an empty asm that names them all:
     // they must be in registers here, so the loads go out together and are awaited once) - left to itself hipcc requested them where
     // first used, five dependent scalar round trips in front of the first ring request
@@ -419,10 +427,10 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   // largest exponent - the exponent of a maximum is the maximum of the exponents: the bits of the pre-pass.  The tag is the launch's nonce (host counter + dispatch id + queue: a replayed graph node
   // gets a fresh one).  Nobody has to wait for anybody: a workgroup that does not see a neighbour's granules in time (a grid that is
   // not resident at once: another stream's kernel on the CUs) computes the whole band's maxima itself, same routine.
-  constexpr bool XCH_OK = XCH;
+  constexpr bool XCH_OK = XCH || MRX;  // (the pre-phase routines: xch_load_s / xch_compute_s / xch_reduce)
   constexpr bool xch = XCH;
   uint32_t xtag = 0;
-  if constexpr (XCH) {
+  if constexpr (XCH || MRX) {
     // host call counter, dispatch id and queue are mixed INDEPENDENTLY (distinct odd multipliers, then a murmur-style finaliser), with
     // the launch's shape on top: two launches share a tag only by a 2^-32 accident, never by calls + dispatch id adding up alike
     uint32_t h = g.xch_nonce ^ ((uint32_t)lqer_dispatch_id() * 0xC2B2AE35u) ^
@@ -434,13 +442,16 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   const int64_t xch_Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
   const int ep_stage = XCH ? G::EP_XAQ : (one_panel ? A_SLOT : EP_STAGE);
   float t_xs = 0.f, t_amax = 0.f;  // this lane's row constants of the tile whose tables are written next
+  uint32_t t_bad = 0;              // MRX: some granule of that row did not carry this launch's tag
+  int mrx_epoch = 0;               // MRX: votes of the workgroup (wg_any)
   bool first = true;
   // the tile's MODE byte travels as the aligned dword around it, requested a tile ahead (here: the first tile's, a scalar load - nothing
   // has been stored yet; the next tile's where the epilogue requests its row constants) and looked at only where the main loop is
   // chosen: a byte load at the head of the tile sat, with its vmcnt(0), in front of the ring fill
   // XCH: this wave's B^T fragments (the side product's B operand, <= 2 limbs x 4 slices), its column's scale and bias: requested once, in
   // the prologue, for the row-maxima pre-phase AND the epilogue
-  bf16x8 sbx[XCH ? 8 : 1];
+  bf16x8 sbx[XCH_OK ? 8 : 1];
+  bf16x8 mfr[MRX ? 12 : 1];  // MRX: the B^T fragments of one batch of an item's column tiles (3 tiles x <= 4 fragments, or 1 x 8)
   float ws_x = 0.f, bv_x = 0.f;
   uint32_t mode_word = 0, mode_sh = 0;
   auto load_mode = [&](int tn_) {
@@ -561,6 +572,22 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       if constexpr (LOWRANK && BOUT == 2) {
         if (xch) {  // (gathered at the epilogue)
           t_amax = 1.0f;
+        } else if constexpr (MRX) {
+          // the row's 16 {maximum, tag} granules: 128 contiguous bytes, agent scope (published inside this launch by other workgroups)
+          const int64_t Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
+          const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, (int)(Mp * LQER_AMAX_NSEG * 8), 0x00020000);
+          i32x4 q[LQER_AMAX_NSEG / 2];
+#pragma unroll
+          for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j)
+            q[j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, (int)(((m0_ + tid) * LQER_AMAX_NSEG + 2 * j) * 8), 0, 16));
+          float m = 0.f;
+          uint32_t bad = 0;
+#pragma unroll
+          for (int j = 0; j < LQER_AMAX_NSEG / 2; ++j) {
+            m = fmaxf(m, fmaxf(__int_as_float(q[j][0]), __int_as_float(q[j][2])));
+            bad |= ((uint32_t)q[j][1] ^ xtag) | ((uint32_t)q[j][3] ^ xtag);
+          }
+          t_amax = m, t_bad = bad;
         } else if (g.bout_nseg > 0) {  // the pre-pass left one partial per column segment (no atomics, no zero-fill): fold them
           const int64_t Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
           // (all cells requested at once - a runtime loop waits for every load in turn, 16 round trips in front of the ring
@@ -686,6 +713,192 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     }
     return r;
   };
+  // MRX: one item of the pre-pass - row band item / 16, column tiles [seg tiles_n / 16, (seg + 1) tiles_n / 16) - by the whole workgroup:
+  // the band's xAq panel into the exchange's LDS region, the side product of each column tile against it (this wave's 32 columns; B^T
+  // fragments of up to three tiles requested together: one cold round trip), the waves' row maxima through LDS, then {maximum, tag} of
+  // row r as granule [r][seg] (one 8-byte sc1 store: value and tag arrive together).  In three steps, so that a workgroup's OWN item can
+  // put its requests in front of the first tile's ring fill and compute behind it (mrx_issue - ring_fill - mrx_finish with a counted
+  // wait); the fall-back (mrx_item) runs them back to back.
+  auto mrx_span = [&](int item, int& t_lo, int& t_hi) {
+    const int seg = item & (LQER_AMAX_NSEG - 1);
+    t_lo = (seg * g.tiles_n) >> 4, t_hi = ((seg + 1) * g.tiles_n) >> 4;
+  };
+  auto mrx_load_batch = [&](int t0, int t_hi, auto nl_c, auto nsl_c) {  // tiles t0 .. of the item -> mfr
+    if constexpr (MRX) {
+      constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value, TP = NL * NSL <= 4 ? 3 : 1;
+      const int64_t limb = (int64_t)g.Np * g.rp;
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+        const int tt = t0 + j < t_hi ? t0 + j : t_hi - 1;  // (past the segment: a tile it has, computed twice - max does not mind)
+        const bf16_t* const bl = g.bt + (int64_t)(tt * BN + wave * 32 + l31) * g.rp + 8 * lh;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+          for (int ks = 0; ks < NSL; ++ks) mfr[j * NL * NSL + l * NSL + ks] = *(const bf16x8*)(bl + l * limb + ks * 16);
+      }
+    }
+  };
+  auto mrx_issue = [&](int item) {  // the band's panel (LDS-DMA: NPA requests per wave) and the first batch of fragments
+    if constexpr (MRX) {
+      using std::integral_constant;
+      int t_lo, t_hi;
+      mrx_span(item, t_lo, t_hi);
+      const int mb = (item >> 4) * BM;
+      const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xaq + (int64_t)mb * g.xaq_ld), 0, BM * g.xaq_ld * 2, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        const int row = wave * (8 * NPA) + i * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + G::EP_XAQ + wave * (8 * NPA) * 128 + i * 1024), 16,
+                                                 row * g.xaq_ld * 2 + chunk * 16, 0, 0, 0);
+      }
+      if (t_hi > t_lo) {
+        switch (xch_key) {
+          case 16 + 1: mrx_load_batch(t_lo, t_hi, integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+          case 16 + 2: mrx_load_batch(t_lo, t_hi, integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
+          case 16 + 4: mrx_load_batch(t_lo, t_hi, integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+          case 32 + 1: mrx_load_batch(t_lo, t_hi, integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+          case 32 + 2: mrx_load_batch(t_lo, t_hi, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+          default: mrx_load_batch(t_lo, t_hi, integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+        }
+      }
+    }
+  };
+  auto mrx_finish = [&](int item) {  // (the panel has landed for every wave: the caller's wait + barrier)
+    if constexpr (MRX) {
+      using std::integral_constant;
+      int t_lo, t_hi;
+      mrx_span(item, t_lo, t_hi);
+      const int seg = item & (LQER_AMAX_NSEG - 1), mb = (item >> 4) * BM;
+      float mx[4] = {0.f, 0.f, 0.f, 0.f};
+      auto batches = [&](auto nl_c, auto nsl_c) {
+        constexpr int NL = decltype(nl_c)::value, NSL = decltype(nsl_c)::value, TP = NL * NSL <= 4 ? 3 : 1;
+        for (int t0 = t_lo; t0 < t_hi; t0 += TP) {
+          if (t0 > t_lo) mrx_load_batch(t0, t_hi, nl_c, nsl_c);  // (the first batch: requested by mrx_issue)
+          // two row groups at a time (their xAq fragments from the panel - asm reads, see xch_compute_s -, two interleaved accumulator
+          // chains per tile): four at once, beside three tiles' fragments, spill
+#pragma unroll
+          for (int up = 0; up < 2; ++up) {
+            bf16x8 pxf[2][NSL];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int ks = 0; ks < NSL; ++ks) {
+                if (up == 0) asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(pxf[u][ks]) : "v"(lds0 + G::EP_XAQ + swz(l31, 2 * ks + lh)), "i"(u * 4096) : "memory");
+                else asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(pxf[u][ks]) : "v"(lds0 + G::EP_XAQ + swz(l31, 2 * ks + lh)), "i"((u + 2) * 4096) : "memory");
+              }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pxf[0][0])::"memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int ks = 0; ks < NSL; ++ks) asm volatile("" : "+v"(pxf[u][ks]));
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+              f32x16 acc2[2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u) acc2[u] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+              for (int l = 0; l < NL; ++l)  // (k_bout_amax's order per accumulator: limb-major, slices ascending)
+#pragma unroll
+                for (int ks = 0; ks < NSL; ++ks)
+#pragma unroll
+                  for (int u = 0; u < 2; ++u)
+                    acc2[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mfr[j * NL * NSL + l * NSL + ks], pxf[u][ks], acc2[u], 0, 0, 0);
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                float m = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2) m = fmaxf(fmaxf(m, fabsf(acc2[u][k])), fabsf(acc2[u][k + 1]));
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);  // lanes l and l ^ 32
+                mx[2 * up + u] = fmaxf(mx[2 * up + u], fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+              }
+            }
+          }
+        }
+      };
+      if (t_hi > t_lo) {
+        switch (xch_key) {
+          case 16 + 1: batches(integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+          case 16 + 2: batches(integral_constant<int, 1>{}, integral_constant<int, 2>{}); break;
+          case 16 + 4: batches(integral_constant<int, 1>{}, integral_constant<int, 4>{}); break;
+          case 32 + 1: batches(integral_constant<int, 2>{}, integral_constant<int, 1>{}); break;
+          case 32 + 2: batches(integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+          default: batches(integral_constant<int, 2>{}, integral_constant<int, 4>{}); break;
+        }
+      }
+      const float r = xch_reduce(mx);  // (its barrier: every wave is done with the panel)
+      if (tid < BM) {
+        const int64_t Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
+        const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, (int)(Mp * LQER_AMAX_NSEG * 8), 0x00020000);
+        const u32x2_g gv = {__float_as_uint(r), xtag};
+        __builtin_amdgcn_raw_buffer_store_b64(gv, m_rsrc, (int)((((mb + tid) * LQER_AMAX_NSEG) + seg) * 8), 0, 16);  // sc1
+      }
+    }
+  };
+  // the fall-back (a band whose producers did not publish in time): the same item, slowly - one row group, one fragment at a time, runtime
+  // loops - so that it fits beside the live accumulators behind the main loop, where it is called (the fast form there spills)
+  auto mrx_item = [&](int item) {
+    if constexpr (MRX) {
+      int t_lo, t_hi;
+      mrx_span(item, t_lo, t_hi);
+      const int seg = item & (LQER_AMAX_NSEG - 1), mb = (item >> 4) * BM;
+      {
+        const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.xaq + (int64_t)mb * g.xaq_ld), 0, BM * g.xaq_ld * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+          const int row = wave * (8 * NPA) + i * 8 + (lane >> 3);
+          const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + G::EP_XAQ + wave * (8 * NPA) * 128 + i * 1024), 16,
+                                                   row * g.xaq_ld * 2 + chunk * 16, 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      float mx[4] = {0.f, 0.f, 0.f, 0.f};
+      const int64_t limb = (int64_t)g.Np * g.rp;
+      for (int t = t_lo; t < t_hi; ++t) {
+        const bf16_t* const bl = g.bt + (int64_t)(t * BN + wave * 32 + l31) * g.rp + 8 * lh;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          for (int l = 0; l < g.b_limbs; ++l)
+            for (int ks = 0; ks < xch_nsl; ++ks) {
+              const bf16x8 fr = *(const bf16x8*)(bl + l * limb + ks * 16);
+              bf16x8 px;
+              asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(px) : "v"(lds0 + G::EP_XAQ + u * 4096 + swz(l31, 2 * ks + lh)) : "memory");
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr, px, acc, 0, 0, 0);
+            }
+          float m = 0.f;
+#pragma unroll
+          for (int k = 0; k < 16; k += 2) m = fmaxf(fmaxf(m, fabsf(acc[k])), fabsf(acc[k + 1]));
+          auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+          mx[u] = fmaxf(mx[u], fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+        }
+      }
+      const float r = xch_reduce(mx);
+      if (tid < BM) {
+        const int64_t Mp = (int64_t)(g.M + LQER_M_ALIGN - 1) / LQER_M_ALIGN * LQER_M_ALIGN;
+        const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, (int)(Mp * LQER_AMAX_NSEG * 8), 0x00020000);
+        const u32x2_g gv = {__float_as_uint(r), xtag};
+        __builtin_amdgcn_raw_buffer_store_b64(gv, m_rsrc, (int)((((mb + tid) * LQER_AMAX_NSEG) + seg) * 8), 0, 16);  // sc1
+      }
+    }
+  };
+  // MRX: a vote of the workgroup - true when `c` holds for some lane of waves 0-1 (the row threads); two barriers.  The word carries the
+  // vote's number, so nothing has to be reset (a reset could overtake the next vote's write)
+  auto wg_any = [&](bool c) -> bool {
+    bool any = false;
+    if constexpr (MRX) {
+      ++mrx_epoch;
+      const uint32_t wa = lds0 + EP_TAB + 1020;
+      if (wave < 2 && __builtin_amdgcn_ballot_w64(c) != 0 && lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(wa), "v"(mrx_epoch) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      int f;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(wa) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+      any = __builtin_amdgcn_readfirstlane(f) == mrx_epoch;
+    }
+    return any;
+  };
   // granules [Mp / 4][LQER_AMAX_NSEG] x {exponent bytes of 4 rows, tag}: a row quad's 16 granules are 128 contiguous bytes
   const auto xch_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.bout_amax, 0, XCH_OK && xch ? (int)(xch_Mp / 4 * LQER_AMAX_NSEG * 8) : 0, 0x00020000);
   // The ring fill in two halves (round 6).  HEAD: the tile's first step - the request everything waits for - goes out before anything else
@@ -754,7 +967,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   };
   auto ring_fill = [&]() {
     ring_fill_head();
-    if (first) load_tables(m0);
+    if (first && !MRX) load_tables(m0);  // (MRX: nothing is published yet - the first tile's tables are written behind its main loop)
     ring_fill_tail();
   };
   // exchange: the tile's first ring step first, then - in this order, all of them L2 hits - the xAq panel (LDS-DMA into its own region:
@@ -816,7 +1029,26 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
     I8_STAMP(cp_p[2], cp_x);
 #endif
   } else {
+    // MRX, first tile: this workgroup's item of the pre-pass - its requests (the band's panel, the first fragments) in FRONT of the tile's
+    // ring fill, its arithmetic behind it (loads return in issue order: the counted wait leaves the ring's 15 requests in flight)
+    const bool mrx_mine = MRX && first && (int)blockIdx.x < g.tiles_m * LQER_AMAX_NSEG;  // (workgroup-uniform)
+    if constexpr (MRX) {
+      if (first && tid == 0) asm volatile("ds_write_b32 %0, %1 offset:1020" ::"v"(lds0 + EP_TAB), "v"(0u) : "memory");  // (the vote word)
+      if (mrx_mine) mrx_issue((int)blockIdx.x);
+    }
     ring_fill();
+    if constexpr (MRX) {
+#ifdef LQER_CLOCKPROBE
+      if (first) I8_STAMP(cp_p[0], cp_x);  // the item's and the first tile's requests are out
+#endif
+      if (mrx_mine) {
+        asm volatile("s_waitcnt vmcnt(15)\n\ts_barrier" ::: "memory");
+        mrx_finish((int)blockIdx.x);
+      }
+#ifdef LQER_CLOCKPROBE
+      if (first) I8_STAMP(cp_p[1], cp_x);  // the item is published
+#endif
+    }
   }
   if constexpr (XCH_OK) {
     if (xch) {  // this tile's row maxima -> granules [tn][m0 + row]; the miss vote of the epilogue starts clean
@@ -861,6 +1093,7 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   if (late) asm volatile("s_barrier" ::: "memory");
 #ifdef LQER_CLOCKPROBE
   I8_STAMP(cp_c[1], cp_r[1]);
+  if constexpr (MRX) { if (first) cp_p[3] = cp_c[1]; }
 #endif
   i32x4 wf[4];     // the step's expanded weight fragments (slices 0..3): live across both half-steps
   uint32_t sv = 0;  // this lane's (column's) shift of the step's 128-k group
@@ -1435,6 +1668,34 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
   asm volatile("s_barrier" ::: "memory");
   // the next tile of this workgroup: its first step goes into ring slot 0 NOW (one panel of xAq: the epilogue keeps out of
   // slot 0), its row constants are requested; the second step follows when the epilogue has released slot 1
+  if constexpr (MRX) {
+    // the tile's row constants: folded a tile ahead from the band's granules - unless some tag was missing then (the first tile: nothing
+    // had been published when its tables were written).  Then: read again, bounded; a band that stays incomplete (its producers are not
+    // resident: another stream holds their CUs) is computed here, all sixteen items - same routine, same bits.  (Behind the main
+    // loop: the first tile's wait passes under it; the fall-back there is the register-light mrx_item.)
+    if (wg_any(first || t_bad != 0)) {
+      int sweeps = 0;
+      for (;;) {
+        load_tables(m0);
+        if (!wg_any(t_bad != 0)) break;
+        if (++sweeps > LQER_XCH_SWEEPS) {
+          for (int sg = 0; sg < LQER_AMAX_NSEG; ++sg) mrx_item((m0 / BM) * LQER_AMAX_NSEG + sg);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          load_tables(m0);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      write_tables();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef LQER_CLOCKPROBE
+      if (first) {
+        I8_STAMP(cp_p[2], cp_x);  // the band's granules seen, tables written
+        cp_tries = (unsigned long long)sweeps;
+      }
+#endif
+    }
+  }
   const int vb_next = vb + (int)gridDim.x;
   const bool has_next = !XCH && vb_next < nt;  // (workgroup-uniform; XCH: one round by construction)
   int m0_next = 0, n0_next = 0, tn_next = 0;
@@ -1951,6 +2212,19 @@ static int launch(GemmArgs g, bool lowrank, int bout, hipStream_t st) {
     }                                                                                             \
   } while (0)
   if constexpr (NT == 4) {
+    if (g.bout_xch == 2) {  // several rounds, the row maxima computed and exchanged by the GEMM's own workgroups (MRX)
+      constexpr int LDS_X = Geo<NT>::KERNEL_LDS_XCH;
+      if (g.i8_shift) {
+        static LdsLimitOnce lds_once;
+        lds_once.set((const void*)k_lqer_gemm_i8<DT, true, 2, true, NT, false, false, true>, LDS_X);
+        k_lqer_gemm_i8<DT, true, 2, true, NT, false, false, true><<<grid, 512, LDS_X, st>>>(g);
+      } else {
+        static LdsLimitOnce lds_once;
+        lds_once.set((const void*)k_lqer_gemm_i8<DT, true, 2, false, NT, false, false, true>, LDS_X);
+        k_lqer_gemm_i8<DT, true, 2, false, NT, false, false, true><<<grid, 512, LDS_X, st>>>(g);
+      }
+      return check_launch("lqer_gemm_i8 (multi-round exchange)");
+    }
     if (g.bout_xch) {  // one round, the B_out row maxima exchanged inside the launch: its own instantiation
       constexpr int LDS_X = Geo<NT>::KERNEL_LDS_XCH;
       if (g.i8_shift) {
@@ -2022,6 +2296,20 @@ bool i8_amax_exchange_ok(const GemmArgs& g, bool lowrank, int bout) {
   const int64_t tn = g.Np / i8::BN, tm = (g.M + 127) / 128;
   const int cus = device_cus();
   if (tn > LQER_AMAX_NSEG || tm * tn > (cus < 256 ? cus : 256)) return false;
+  const int nsl = g.rp / 16;
+  return (g.b_limbs == 1 || g.b_limbs == 2) && (nsl == 1 || nsl == 2 || nsl == 4);
+}
+
+// ... and over SEVERAL rounds of 128-row tiles (MRX: 4-bit weights): the persistent grid of min(tiles, 256) workgroups is resident at
+// once, and every (row band, sixteenth of the columns) item of the pre-pass has a workgroup of its own.
+bool i8_amax_mrx_ok(const GemmArgs& g, bool lowrank, int bout) {
+  if (!lowrank || bout != 2 || g.bout_nblk != 1 || g.w_i8codes || g.rp > 64) return false;
+  if (i8_tile_rows(g) != 128) return false;
+  const int64_t tn = g.Np / i8::BN, tm = (g.M + 127) / 128;
+  const int cus = device_cus();
+  const int64_t grid = tm * tn < 256 ? tm * tn : 256;
+  if (tm * tn <= (cus < 256 ? cus : 256) && tn <= LQER_AMAX_NSEG) return false;  // (one round: the exchange instantiation)
+  if (grid > cus || tm * LQER_AMAX_NSEG > grid) return false;
   const int nsl = g.rp / 16;
   return (g.b_limbs == 1 || g.b_limbs == 2) && (nsl == 1 || nsl == 2 || nsl == 4);
 }

@@ -224,11 +224,12 @@ def test_gemm_prepass_zero_fill_handed_to_the_activation_kernel(lq):
         torch.cuda.synchronize()
         return y, ready.value, head
 
-    y0, _, _ = run(0, False, 0x5A)
-    y1, ready, head = run(0, True, 0xFF)
+    NM = _lib.TUNE_AMAX_NO_MRX  # (the pre-pass launch pinned: by default this shape computes the pre-pass inside the GEMM - no cells at all)
+    y0, _, _ = run(NM, False, 0x5A)
+    y1, ready, head = run(NM, True, 0xFF)
     assert ready == L.lqer_padded_m(M) * 4 and int(head.max()) == 0  # one fp32 cell per row (one B_out block per row), zeroed
     assert torch.equal(y0.view(torch.int16), y1.view(torch.int16)) and torch.equal(y0.view(torch.int16), y_fwd.view(torch.int16))
-    y2, ready2, _ = run(_lib.TUNE_ACT8_SPLIT, True, 0xFF)  # three launches: nobody prepared anything, the GEMM fills its cells itself
+    y2, ready2, _ = run(NM | _lib.TUNE_ACT8_SPLIT, True, 0xFF)  # three launches: nobody prepared anything, the GEMM fills its cells itself
     assert ready2 == 0 and torch.equal(y0.view(torch.int16), y2.view(torch.int16))
     ref = O.lqer_linear_forward(x.half().float(), W.half().float(), None, A.half().float(), B.half().float(), qc)
     assert float((y1.float().cpu() - ref).norm() / ref.norm()) <= 1e-3
@@ -246,3 +247,5 @@ def test_gemm_prepass_zero_fill_handed_to_the_activation_kernel(lq):
                                            L.lqer_lowrank_xa_scratch_bytes(C.byref(desc4), M), scr, C.byref(rdy), st), "quantize_act_xa_prep")
     torch.cuda.synchronize()
     assert rdy.value == 0
+    y3, ready3, _ = run(0, True, 0xFF)  # ... nor does the default route of the 11008-column launch (the in-GEMM pre-pass): same bits
+    assert ready3 == 0 and torch.equal(y0.view(torch.int16), y3.view(torch.int16))

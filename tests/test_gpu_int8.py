@@ -621,3 +621,49 @@ def test_w8_blocks_of_128_take_the_int8_route_only_with_one_exponent_per_row(lq)
         ref = O.lqer_linear_forward(x.half().float(), Wv.half().float(), None, A.half().float(), B.half().float(), qc)
         assert float((y.float().cpu() - ref).norm() / ref.norm()) <= 1e-3
         outs.append(y)
+
+
+@pytest.mark.parametrize("M,K,N,r,qname,dtype", [(2048, 256, 11008, 32, "int", torch.float16),    # the Llama-7B gate / up shape: 16 x 43 tiles, 2.7 rounds
+                                                 (1000, 384, 8192, 16, "int", torch.bfloat16),    # ragged M: 8 bands x 32 column tiles, 128 items on 256 workgroups
+                                                 (2048, 256, 5120, 64, "introw", torch.float16),  # rank 64, one weight block per row (no shift bytes)
+                                                 (640, 128, 16384, 32, "int", torch.float32)])
+def test_int8_bout_row_maxima_over_several_rounds_inside_the_gemm(lq, M, K, N, r, qname, dtype):
+    """(default; LQER_TUNE_AMAX_NO_MRX pins the pre-pass launch) a grid of several rounds of 128-row tiles computes the pre-pass itself - one (row band, sixteenth of the columns)
+    item per workgroup at its start, {maximum, tag} granules, the fold a tile ahead - instead of the k_bout_amax launch.  Same bits as the
+    pre-pass on cells (max is order-independent); garbage in the scratch must not matter (the tag is per launch); repeated launches and two
+    streams at once finish with the same bits (a workgroup that does not see a band's granules in time computes them itself)."""
+    from bench import INT_Q, INTROW_Q, make_case
+    from lqer_amd import _lib, ops
+
+    qc = {"int": INT_Q, "introw": INTROW_Q}[qname]
+    x, W, A, B = make_case(M, K, N, r, seed=N + r + M, quantize_ab=False)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).to(dtype)
+    xd = x.to(dtype).to(DEV)
+    mod.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_NO_MRX
+    want = mod(xd).clone()
+    assert mod._x_i8
+    mod.tuning = _lib.TUNE_I8_ROWS_128
+    ws = ops.workspace(torch.device(DEV), 16)
+    ws.fill_(0x7F)
+    for _ in range(3):
+        assert torch.equal(mod(xd), want)
+    ws.fill_(0xFF)
+    assert torch.equal(mod(xd), want)
+    # two streams at once: the grids are not resident together - bounded polls, then the fall-back
+    mod2 = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
+    mod2.load_state_dict({"weight": W, "A": A, "B": B})
+    mod2 = mod2.to(DEV).to(dtype)
+    mod2.tuning = mod.tuning
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(4):
+        with torch.cuda.stream(s1):
+            outs.append(mod(xd))
+        with torch.cuda.stream(s2):
+            outs.append(mod2(xd))
+    torch.cuda.synchronize()
+    for y in outs:
+        assert torch.equal(y, want)

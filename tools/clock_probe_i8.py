@@ -75,7 +75,13 @@ for w in (0, 4):
           f"vmcnt(0) {parts[2][:, w].median().item():.0f}, barrier {parts[3][:, w].median().item():.0f} cycles")
 print(f"  epilogue    {med(b[:, :, 4]):9.0f} cycles, {med(b[:, :, 5]) / 100:7.2f} us")
 print(f"     of which staging + barrier {med(b[:, :, 6]):7.0f} cycles, math of the first two token tiles {med(b[:, :, 7]):7.0f} cycles")
-if S >= 16 and float(b[:, :, 8].max()) > 0:  # round 6: the exchange instantiation's prologue sections, cycles from the wave's start
+if S >= 16 and tiles > 256 and BMt == 128 and not (a.tuning & 0x40C0000) and float(b[:, :, 8].max()) > 0:  # round 6, MRX: the FIRST tile's prologue, cycles from the kernel's start
+    for w in (0, 4):
+        print(f"  wave {w} first tile: ring requests out {med(b[:, w, 8]):.0f}, item published {med(b[:, w, 9]):.0f}, band's granules seen + tables "
+              f"{med(b[:, w, 10]):.0f} (polls: median {med(b[:, w, 12]):.0f}, max {b[:, w, 12].max().item():.0f}), main loop starts {med(b[:, w, 11]):.0f}")
+    t0, t1 = b[:, 0, 13], b[:, 0, 14]
+    print(f"  first start to last end {(t1.max() - t0.min()).item() / 100:.2f} us")
+elif S >= 16 and float(b[:, :, 8].max()) > 0:  # round 6: the exchange instantiation's prologue sections, cycles from the wave's start
     for w in (0, 4):
         print(f"  wave {w} prologue: first request out {med(b[:, w, 8]):.0f}, all requests out + tables {med(b[:, w, 9]):.0f}, row maxima computed "
               f"{med(b[:, w, 10]):.0f}, reduced + published {med(b[:, w, 11]):.0f}, main loop starts {med(b[:, w, 2]):.0f}")
