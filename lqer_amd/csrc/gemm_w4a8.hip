@@ -1259,6 +1259,11 @@ int gemm_tile_rows(const GemmArgs& g) {
   return BM;
 }
 
+__global__ void k_zero_cells(uint32_t* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 // How a launch with one or more B_out blocks per row (bout == 2, block_fp; g.bout_nblk set) gets its row-block maxima:
 //   xch   - one round of the int8 kernel's 128-row tiles: exchanged inside the GEMM launch, no pre-pass;
 //   parts - one block per row, consumed by the int8 kernel: every wave of the pre-pass leaves the maximum of ITS column segment in its
@@ -1340,7 +1345,9 @@ int gemm_dispatch(GemmArgs g, int dtype, bool lowrank, void* scratch, size_t scr
         g.bout_xch = ap.mrx ? 2 : 1;
         g.xch_nonce = xch_calls.fetch_add(1, std::memory_order_relaxed) * 0x9E3779B1u;
       } else {
-      if (!parts && !g.amax_zeroed) (void)hipMemsetAsync(scratch, 0, need, st);  // (amax_zeroed: the activation kernel of the same forward did it)
+      // (amax_zeroed: the activation kernel of the same forward did it.  A kernel, not hipMemsetAsync: as a memset NODE of a captured graph
+      // the fill left two of every four cells untouched on replay - ROCm 7.2, tools/graph_replay_gemm.py - while the eager call was fine)
+      if (!parts && !g.amax_zeroed) k_zero_cells<<<(unsigned)((need / 4 + 255) / 256), 256, 0, st>>>((uint32_t*)scratch, (int64_t)(need / 4));
       // padded rank (x limbs of x A) -> 16-deep slices (a template parameter: exact, no per-slice branch) and row groups per wave
       const int nks = g.rp / 16;
       int RG = g.rp <= 64 ? 4 : (g.rp <= 128 ? 2 : 1);

@@ -1677,8 +1677,9 @@ __global__ __launch_bounds__(512) void k_lqer_gemm_i8(GemmArgs g) {
       int sweeps = 0;
       for (;;) {
         load_tables(m0);
-        if (!wg_any(t_bad != 0)) break;
-        if (++sweeps > LQER_XCH_SWEEPS) {
+        const bool miss = (g.tuning & LQER_TUNE_AMAX_XCH_MISS) != 0;  // (test knob: take the fall-back)
+        if (!wg_any(t_bad != 0) && !miss) break;
+        if (miss || ++sweeps > LQER_XCH_SWEEPS) {
           for (int sg = 0; sg < LQER_AMAX_NSEG; ++sg) mrx_item((m0 / BM) * LQER_AMAX_NSEG + sg);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           load_tables(m0);

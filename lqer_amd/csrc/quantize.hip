@@ -395,14 +395,21 @@ __global__ __launch_bounds__(256) void k_tile_quant(const void* __restrict__ x, 
   }
 }
 
+__global__ void k_zero_u32(uint32_t* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 template <int DT>
 static int launch_tiles(const void* x, int64_t batches, int64_t rows, int64_t cols, int64_t R, int64_t L, const QP& q, float* out,
                         float* amax, hipStream_t st) {
   const int64_t tr = (rows + R - 1) / R, tc = (cols + L - 1) / L;
-  if (hipMemsetAsync(amax, 0, (size_t)(batches * tr * tc) * sizeof(float), st) != hipSuccess) {
-    (void)hipGetLastError();
-    set_error("quantize_mxint_tiles: zero fill of the tile maxima failed");
-    return LQER_E_LAUNCH;
+  // (a kernel, not hipMemsetAsync: as a memset node of a captured graph the fill leaves cells untouched on replay - gemm_w4a8.hip)
+  {
+    const int64_t nz = batches * tr * tc;
+    k_zero_u32<<<(unsigned)((nz + 255) / 256), 256, 0, st>>>((uint32_t*)amax, nz);
+    const int rc = check_launch("quantize_mxint_tiles (zero fill of the tile maxima)");
+    if (rc) return rc;
   }
   const int64_t segs = batches * rows * tc, total = batches * rows * cols;
   const unsigned g1 = (unsigned)((segs + 3) / 4 < 65536 ? (segs + 3) / 4 : 65536);

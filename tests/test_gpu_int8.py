@@ -651,6 +651,19 @@ def test_int8_bout_row_maxima_over_several_rounds_inside_the_gemm(lq, M, K, N, r
         assert torch.equal(mod(xd), want)
     ws.fill_(0xFF)
     assert torch.equal(mod(xd), want)
+    # a captured graph, replayed with other tokens: the tag carries the dispatch id, a replay never accepts the previous replay's granules
+    from lqer_amd.graph import GraphedCallable
+
+    xs = xd.clone()
+    gc = GraphedCallable(mod, xs, warmup=1)
+    for scale in (1.0, -0.5, 3.0):
+        xn = (x * scale).to(dtype).to(DEV)
+        mod.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_NO_MRX
+        ref = mod(xn).clone()
+        mod.tuning = _lib.TUNE_I8_ROWS_128
+        got = gc(xn).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), scale
     # two streams at once: the grids are not resident together - bounded polls, then the fall-back
     mod2 = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
     mod2.load_state_dict({"weight": W, "A": A, "B": B})
@@ -667,3 +680,58 @@ def test_int8_bout_row_maxima_over_several_rounds_inside_the_gemm(lq, M, K, N, r
     torch.cuda.synchronize()
     for y in outs:
         assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_prepass_on_cells_under_graph_replay(lq, dtype):
+    """Regression (round 6): the pre-pass on atomicMax cells zero-filled them with hipMemsetAsync; captured in a hipGraph, the memset NODE
+    left two of every four cells untouched on replay (the eager call was fine) - stale or garbage maxima for half the rows, in every
+    forward replayed from a graph that took this route (multi-round int8 launches, fp32 tensors: three limbs of B - no in-GEMM exchange).
+    The fill is a kernel now.  Split calls (no activation-kernel hand-over), replayed with other tokens, against the eager calls."""
+    import ctypes as C
+
+    from bench import INT_Q, make_case
+    from lqer_amd import _lib, ops
+
+    M, K, N, r = 640, 128, 16384, 32
+    x, W, A, B = make_case(M, K, N, r, seed=9, quantize_ab=False)
+    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=INT_Q, l_config={"rank": r})
+    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    mod = mod.to(DEV).to(dtype)
+    mod.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_NO_MRX
+    xd = x.to(dtype).to(DEV)
+    mod(xd)
+    L, desc, p, dt = _lib.lib(), mod._desc(), mod._packed, ops.dtype_code(xd)
+    a_t, a_limbs = mod._side_image(M, desc, dt)
+    wsb = ops.linear_sizes(desc, M).workspace
+    Kp, Mp, rp = L.lqer_padded_k(K), L.lqer_padded_m(M), L.lqer_padded_r(r)
+    act = L.lqer_act_image_bytes(C.byref(desc), M)
+    offs = act + ((Mp * rp * 2 + 255) // 256) * 256
+    nscr, gscr = L.lqer_lowrank_xa_scratch_bytes(C.byref(desc), M), L.lqer_linear_gemm_scratch_bytes(C.byref(desc), M)
+    cur = lambda: torch.cuda.current_stream().cuda_stream
+
+    def fwd(xt, y, ws):
+        _lib.check(L.lqer_quantize_act_xa(C.byref(desc), xt.data_ptr(), dt, M, K, a_t, a_limbs, ws.data_ptr(), ws.data_ptr() + act,
+                                          ws.data_ptr() + offs, nscr, cur()), "quantize_act_xa")
+        _lib.check(L.lqer_linear_gemm(C.byref(desc), ws.data_ptr(), M, p["w"].data_ptr(), ws.data_ptr() + act, p["b_t"].data_ptr(), p["b_limbs"],
+                                      None, y.data_ptr(), dt, N, ws.data_ptr() + offs, gscr, cur()), "linear_gemm")
+
+    xs = xd.clone()
+    yg, ye = torch.empty(M, N, dtype=dtype, device=DEV), torch.empty(M, N, dtype=dtype, device=DEV)
+    wsg, wse = torch.zeros(wsb, dtype=torch.uint8, device=DEV), torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd(xs, yg, wsg)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fwd(xs, yg, wsg)
+    for scale in (1.0, -0.5, 3.0):
+        xn = (x * scale).to(dtype).to(DEV)
+        fwd(xn, ye, wse)
+        xs.copy_(xn)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, ye), scale
