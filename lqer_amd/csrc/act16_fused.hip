@@ -38,7 +38,7 @@ template <int DT, int RT>
 __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x, int64_t M, int64_t K, int64_t ld, QP qx, bf16_t* __restrict__ xq,
                                                       int64_t Kp, const bf16_t* __restrict__ a_frag, QP qa, int L_aout, bf16_t* __restrict__ xaq) {
   constexpr int RP = 16 * RT;
-  constexpr int HB = RT == 4 ? 4 : 8;  // steps per part of a slab (16 / HB parts, two register sets of HB x RT fragments = 128 registers)
+  constexpr int HB = RT == 8 ? 2 : (RT == 4 ? 4 : 8);  // steps per part of a slab (16 / HB parts, two register sets of HB x RT fragments: <= 128 registers)
   constexpr int NPART = 16 / HB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(512) void k_act16_fused(const void* __restrict__ x,
         for (int t = 0; t < RT; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16v8, tk[i]), __builtin_bit_cast(bf16v8, f[i][t]), acc[t], 0, 0, 0);
     };
-    half(fa, 0);
-    if constexpr (NPART > 2) load_part(fa, 2);
-    half(fb, HB);
-    if constexpr (NPART > 2) {
-      load_part(fb, 3);
-      half(fa, 2 * HB);
-      half(fb, 3 * HB);
+    // parts alternate between the two register sets; a set is refilled (part + 2) as soon as its steps have been multiplied
+#pragma unroll
+    for (int pp = 0; pp < NPART; pp += 2) {
+      half(fa, pp * HB);
+      if (pp + 2 < NPART) load_part(fa, pp + 2);
+      half(fb, (pp + 1) * HB);
+      if (pp + 3 < NPART) load_part(fb, pp + 3);
     }
     // (the next slab overwrites the wave's LDS slab: its reads above must have been issued - they have, in program order)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -260,6 +260,8 @@ int act16_fused_dispatch(const void* x, int dtype, int64_t M, int64_t K, int64_t
   if (tuning & LQER_TUNE_ACT16_SPLIT) return LQER_E_UNSUPPORTED;
   const int64_t rp = lqer_padded_r(r), Kp = lqer_padded_k(K);
   if (dtype == LQER_F32 || !a_b16 || !xaq || !xq || r <= 0 || M <= 0) return LQER_E_UNSUPPORTED;
+  // (rank 128 - RT = 8, eight parts of two steps - was built and measured in round 6: c5 1049 against 1129 with k_quant_xa128 + k_xa_reduce4:
+  // every 8-row workgroup streams 1-4 MB of A^T fragments; not instantiated)
   if (!(rp == 16 || rp == 32 || rp == 64)) return LQER_E_UNSUPPORTED;
   if (qx.kind != LQER_Q_MXINT || qx.block != 16 || qx.mbits > 8) return LQER_E_UNSUPPORTED;
   if (((uintptr_t)x % 16) != 0 || ((ldx * 2) % 16) != 0 || K % 16 != 0) return LQER_E_UNSUPPORTED;
