@@ -626,7 +626,8 @@ def test_w8_blocks_of_128_take_the_int8_route_only_with_one_exponent_per_row(lq)
 @pytest.mark.parametrize("M,K,N,r,qname,dtype", [(2048, 256, 11008, 32, "int", torch.float16),    # the Llama-7B gate / up shape: 16 x 43 tiles, 2.7 rounds
                                                  (1000, 384, 8192, 16, "int", torch.bfloat16),    # ragged M: 8 bands x 32 column tiles, 128 items on 256 workgroups
                                                  (2048, 256, 5120, 64, "introw", torch.float16),  # rank 64, one weight block per row (no shift bytes)
-                                                 (640, 128, 16384, 32, "int", torch.float32)])
+                                                 (640, 128, 16384, 32, "int", torch.float32),     # fp32: three limbs of B - the pre-pass launch stays (and must replay: see below)
+                                                 (1500, 256, 10992, 32, "intbias", torch.float16)])  # ragged M and N (43 column tiles, the last one part-filled), bias
 def test_int8_bout_row_maxima_over_several_rounds_inside_the_gemm(lq, M, K, N, r, qname, dtype):
     """(default; LQER_TUNE_AMAX_NO_MRX pins the pre-pass launch) a grid of several rounds of 128-row tiles computes the pre-pass itself - one (row band, sixteenth of the columns)
     item per workgroup at its start, {maximum, tag} granules, the fold a tile ahead - instead of the k_bout_amax launch.  Same bits as the
@@ -635,10 +636,15 @@ def test_int8_bout_row_maxima_over_several_rounds_inside_the_gemm(lq, M, K, N, r
     from bench import INT_Q, INTROW_Q, make_case
     from lqer_amd import _lib, ops
 
-    qc = {"int": INT_Q, "introw": INTROW_Q}[qname]
-    x, W, A, B = make_case(M, K, N, r, seed=N + r + M, quantize_ab=False)
-    mod = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
-    mod.load_state_dict({"weight": W, "A": A, "B": B})
+    bias = qname == "intbias"
+    qc = {"int": INT_Q, "introw": INTROW_Q, "intbias": INT_Q}[qname]
+    case = make_case(M, K, N, r, seed=N + r + M, quantize_ab=False, bias=bias)
+    x, W, A, B = case[:4]
+    sd = {"weight": W, "A": A, "B": B}
+    if bias:
+        sd["bias"] = case[4]
+    mod = lq.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    mod.load_state_dict(sd)
     mod = mod.to(DEV).to(dtype)
     xd = x.to(dtype).to(DEV)
     mod.tuning = _lib.TUNE_I8_ROWS_128 | _lib.TUNE_AMAX_NO_MRX
@@ -651,6 +657,9 @@ def test_int8_bout_row_maxima_over_several_rounds_inside_the_gemm(lq, M, K, N, r
         assert torch.equal(mod(xd), want)
     ws.fill_(0xFF)
     assert torch.equal(mod(xd), want)
+    h = lambda t: None if t is None else t.to(dtype).float()
+    ref = O.lqer_linear_forward(h(x), h(W), h(case[4]) if bias else None, h(A), h(B), qc)
+    assert float((want.float().cpu() - ref).norm() / ref.norm()) <= (4e-3 if dtype == torch.bfloat16 else 1e-3)
     # a captured graph, replayed with other tokens: the tag carries the dispatch id, a replay never accepts the previous replay's granules
     from lqer_amd.graph import GraphedCallable
 
@@ -665,8 +674,8 @@ def test_int8_bout_row_maxima_over_several_rounds_inside_the_gemm(lq, M, K, N, r
         torch.cuda.synchronize()
         assert torch.equal(got, ref), scale
     # two streams at once: the grids are not resident together - bounded polls, then the fall-back
-    mod2 = lq.LinearFlexibleLqer(K, N, bias=False, q_config=qc, l_config={"rank": r})
-    mod2.load_state_dict({"weight": W, "A": A, "B": B})
+    mod2 = lq.LinearFlexibleLqer(K, N, bias=bias, q_config=qc, l_config={"rank": r})
+    mod2.load_state_dict(sd)
     mod2 = mod2.to(DEV).to(dtype)
     mod2.tuning = mod.tuning
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
