@@ -354,6 +354,32 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         torch.cuda.synchronize()
     elapsed = sweep.max_over_ranks(elapsed_rank, dev)
 
+    # second timed region: the same K steps through the drop-in module (torch.empty, descriptor cache, ctypes marshalling
+    # included) - the boundary the reference's callers use.  Right behind the first region, in the same thermal state: behind the clock probe's
+    # seconds of back-to-back GEMMs (below) it read 7-11 % slower than the C ABI at the single-Linear workloads, where the three doors -
+    # split calls, lqer_linear_forward, the module - take the same time to a tenth of a microsecond (tools/fwd_paths_time.py)
+    module = None
+    if o.module and live:
+        for _ in range(max(1, warmup // 2)):
+            step_module()
+        el_mod = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_module() for _ in range(n)], steps), dev)
+        module = {"ms_per_step": round(el_mod / steps * 1e3, 4), "vs_c_abi": round(el_mod / elapsed, 4)}
+        if M <= 64 and graph is None:
+            # decode sizes are host-bound through the module (torch.empty + ctypes per call ~8 us on a ~8 us kernel): the way a
+            # serving loop runs them is ONE captured graph per token step - here G module forwards (one per rotated weight)
+            # captured by lqer_amd.graph.GraphedCallable and replayed; the one-launch decode route is capturable
+            from lqer_amd.graph import GraphedCallable
+
+            G = max(rotate, 1) * max(1, 48 // max(rotate, 1))
+            while steps % G:
+                G -= 1
+            gm = GraphedCallable(lambda: [step_module() for _ in range(G)][-1], warmup=2)
+            gm()
+            el_g = sweep.max_over_ranks(timed_region(ctx, lambda n: [gm() for _ in range(n // G)], steps), dev)
+            module.update(graph_ms_per_step=round(el_g / steps * 1e3, 4), graph_vs_c_abi=round(el_g / elapsed, 4),
+                          graph_forwards_per_replay=G)
+
+
     # the same K steps once more WITHOUT the event pairs (the instrumented region above is what the contract asks
     # `value` and the roofline sample to share; this one says what the instrumentation costs)
     uninstrumented = None
@@ -399,29 +425,6 @@ def run_workload(ctx: Ctx, o: Opts) -> Optional[dict]:
         resident[0] = False
         res_events, gemm_events = gemm_events, rot_events
         resident_fig = {"ms_per_step": round(el_res / steps * 1e3, 4), "events": res_events}
-
-    # second timed region: the same K steps through the drop-in module (torch.empty, descriptor cache, ctypes marshalling
-    # included) - the boundary the reference's callers use
-    module = None
-    if o.module and live:
-        for _ in range(max(1, warmup // 2)):
-            step_module()
-        el_mod = sweep.max_over_ranks(timed_region(ctx, lambda n: [step_module() for _ in range(n)], steps), dev)
-        module = {"ms_per_step": round(el_mod / steps * 1e3, 4), "vs_c_abi": round(el_mod / elapsed, 4)}
-        if M <= 64 and graph is None:
-            # decode sizes are host-bound through the module (torch.empty + ctypes per call ~8 us on a ~8 us kernel): the way a
-            # serving loop runs them is ONE captured graph per token step - here G module forwards (one per rotated weight)
-            # captured by lqer_amd.graph.GraphedCallable and replayed; the one-launch decode route is capturable
-            from lqer_amd.graph import GraphedCallable
-
-            G = max(rotate, 1) * max(1, 48 // max(rotate, 1))
-            while steps % G:
-                G -= 1
-            gm = GraphedCallable(lambda: [step_module() for _ in range(G)][-1], warmup=2)
-            gm()
-            el_g = sweep.max_over_ranks(timed_region(ctx, lambda n: [gm() for _ in range(n // G)], steps), dev)
-            module.update(graph_ms_per_step=round(el_g / steps * 1e3, 4), graph_vs_c_abi=round(el_g / elapsed, 4),
-                          graph_forwards_per_replay=G)
 
     # third timed region (model workloads): the same Linears the way the model runs them - q/k/v and
     # gate/up receive ONE tensor, so its activation image and one side GEMM over the members' concatenated A are made once
